@@ -1,0 +1,165 @@
+/*
+ * vg_kernels.h — C ABI of libvgkernels.so, the hand-written gfx950 (MI355X / CDNA4) kernel
+ * library behind the VideoGLaMM inference hot path.
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is owned by the
+ *     caller and lives in device memory; no hidden allocation, no implicit synchronisation;
+ *   - every entry point is stateless, re-entrant and stream-ordered on the hipStream_t passed last;
+ *   - return value 0 = VG_OK, negative = error code; vg_last_error() gives a thread-local message;
+ *   - activations / weights are VG_F32 or VG_BF16 (raw uint16 storage), accumulation is always fp32;
+ *     bias / norm-weight / LayerScale vectors are always fp32;
+ *   - tensors are token-major ("channels last"): [tokens, channels] with channels contiguous.
+ *
+ * R/ = the reference tree /root/reference/VideoGLaMM/. The reference has no native boundary on this
+ * path (its only native file, sam2/csrc/connected_components.cu, is dead code on it —
+ * R/model/segment_anything_2/sam2/sam2_video_predictor.py:971-975); each entry point below therefore
+ * cites the PyTorch call site(s) whose arithmetic it replaces.
+ */
+#ifndef VG_KERNELS_H
+#define VG_KERNELS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vg_stream_t; /* hipStream_t */
+
+#define VG_F32 0
+#define VG_BF16 1
+
+#define VG_OK 0
+#define VG_ERR_ARG (-1)
+#define VG_ERR_LAUNCH (-2)
+#define VG_ERR_UNSUPPORTED (-3)
+
+#define VG_ACT_NONE 0
+#define VG_ACT_GELU 1       /* exact erf GELU: nn.GELU() */
+#define VG_ACT_QUICK_GELU 2 /* x*sigmoid(1.702x): HF CLIP "quick_gelu" */
+#define VG_ACT_RELU 3
+#define VG_ACT_SILU 4
+#define VG_ACT_SIGMOID 5
+
+int vg_version(void);
+const char* vg_last_error(void);
+/* Binds nothing; checks that `device` is a gfx950 part. Returns CU count (>0) or a negative code. */
+int vg_init(int device);
+
+/* ---- dense contraction (MFMA) ------------------------------------------------------------------
+ * C[b] = ((act(A[b] @ W[b]^T + bias)) * gamma) + R[b]      A:[M,K] lda, W:[N,K] ldw, C:[M,N] ldc
+ * Replaces every nn.Linear / 1x1 conv / im2col'd conv on the path, e.g.
+ *   R/model/videogpt_plus/model/internvideo/internvideo2.py:193,207,257-261 (qkv/proj/fc1/fc2 + LayerScale :283-284),
+ *   R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:56,82 ; sam2_utils.py:126-131 (MLP),
+ *   R/model/segment_anything_2/sam2/modeling/sam/transformer.py:238-258 (q/k/v/out proj),
+ *   R/model/segment_anything_2/sam2/modeling/sam/mask_decoder.py:227-234 (hypernetwork product, batched),
+ *   HF LlamaAttention/LlamaMLP projections and lm_head (R/model/videogpt_plus/model/language_model/llama3_1.py:63-75).
+ * in_dtype applies to A and W; out_dtype to C and R. K must be a multiple of 8 (bf16) / 4 (f32) and
+ * lda/ldw multiples of the same; M, N arbitrary. batch>1 uses element strides sA/sW/sC/sR (sW may be 0).
+ */
+int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
+            void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
+            const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
+            int in_dtype, int out_dtype, int act, vg_stream_t stream);
+
+/* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
+ * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)
+ * causal: key j visible to query i iff j <= i + (Skv - Sq).  D % 8 == 0, D <= 256.
+ * Strides are in elements: *_sb batch, *_ss token, *_sh head; the head dim is contiguous.
+ * Replaces F.scaled_dot_product_attention / naive softmax(QK^T)V at
+ *   R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:72-76,
+ *   R/model/segment_anything_2/sam2/modeling/sam/transformer.py:249-255,316-322,
+ *   R/model/videogpt_plus/model/internvideo/internvideo2.py:200-206,
+ *   HF CLIPAttention / LlamaAttention (third-party, transformers==4.41.0).
+ */
+int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                 int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                 int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                 int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, vg_stream_t stream);
+
+/* ---- row normalisation -------------------------------------------------------------------------
+ * LayerNorm over the last dim (biased variance, two-pass fp32): nn.LayerNorm and LayerNorm2d
+ * (R/model/segment_anything_2/sam2/modeling/sam2_utils.py:137-149 — channels-last makes them identical).
+ * RMSNorm: R/model/videogpt_plus/model/internvideo/internvideo2.py:134-145 and HF LlamaRMSNorm.
+ * x rows have stride ldx elements, y rows ldy.
+ */
+int vg_layernorm(const void* x, int64_t ldx, const float* w, const float* b, void* y, int64_t ldy,
+                 int64_t rows, int C, float eps, int in_dtype, int out_dtype, vg_stream_t stream);
+int vg_rmsnorm(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy, int64_t rows, int C,
+               float eps, int in_dtype, int out_dtype, vg_stream_t stream);
+
+/* ---- pointwise --------------------------------------------------------------------------------- */
+/* out[i] = alpha*a[i] + beta*b[i % b_period]  (b may be NULL -> alpha*a[i] + beta) */
+int vg_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta,
+             int64_t b_period, int a_dtype, int b_dtype, int out_dtype, vg_stream_t stream);
+/* y = act(x) */
+int vg_activation(const void* x, void* y, int64_t n, int act, int in_dtype, int out_dtype,
+                  vg_stream_t stream);
+/* y[m,f] = silu(gu[m,f]) * gu[m,F+f]  (HF LlamaMLP: down(act(gate(x))*up(x)); gate|up packed) */
+int vg_swiglu(const void* gu, void* y, int64_t M, int F, int dtype, vg_stream_t stream);
+/* out = in converted */
+int vg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, vg_stream_t stream);
+/* out[n,i] = cond[n] > 0 ? a[n,i] : (b ? b[i % b_period] : fill)   (fp32 cond)
+ * R/model/segment_anything_2/sam2/modeling/sam2_base.py:355-364,390-401 */
+int vg_where_rows(const float* cond, const void* a, const void* b, void* out, int64_t rows,
+                  int64_t inner, int64_t b_period, float fill, int dtype, vg_stream_t stream);
+/* mask fed to the memory encoder: out = (binarize ? (x>0) : sigmoid(x)) * scale + bias
+ * R/model/segment_anything_2/sam2/modeling/sam2_base.py:684-693 */
+int vg_mask_for_mem(const float* x, void* out, int64_t n, int binarize, float scale, float bias,
+                    int out_dtype, vg_stream_t stream);
+/* out[i] = x[i] > 0  (uint8)  R/model/VideoGLaMM.py:763,873 */
+int vg_threshold(const float* x, uint8_t* out, int64_t n, vg_stream_t stream);
+/* HF rotate-half RoPE, in place on x:[S,H,D] (token stride x_ss, head stride x_sh); cos/sin:[*,D/2] f32,
+ * row used for token s is pos0+s.  HF modeling_llama.apply_rotary_pos_emb. */
+int vg_rope_half(void* x, int64_t x_ss, int64_t x_sh, const float* cos, const float* sin, int S, int H,
+                 int D, int pos0, int dtype, vg_stream_t stream);
+/* SAM2 axial (complex-pair) RoPE, in place on x:[B,N,C] contiguous, only tokens n < n_rope;
+ * token n uses table row n % n_grid.  cos/sin:[n_grid,C/2] f32.
+ * R/model/segment_anything_2/sam2/modeling/position_encoding.py:174-216, sam/transformer.py:306-312 */
+int vg_rope_axial(void* x, const float* cos, const float* sin, int B, int N, int C, int n_rope,
+                  int n_grid, int dtype, vg_stream_t stream);
+/* out[i,:] = table[ids[i],:]   (nn.Embedding) */
+int vg_embed(const int64_t* ids, const void* table, void* out, int64_t n, int D, int dtype,
+             vg_stream_t stream);
+/* out[r] = first index of the row maximum (torch.argmax)  x:[rows,n] */
+int vg_argmax(const void* x, int64_t rows, int n, int64_t* out, int dtype, vg_stream_t stream);
+
+/* ---- spatial / layout (all NHWC) ---------------------------------------------------------------- */
+/* 5-D gather copy: out (contiguous, dims n0..n4) = in at element strides s0..s4 */
+int vg_permute5(const void* in, void* out, const int64_t dims[5], const int64_t strides[5], int dtype,
+                vg_stream_t stream);
+/* x:[B,H,W,C] -> cols:[B*Ho*Wo, Kpad], column (ky*kw+kx)*C + c, zero padded to Kpad.
+ * Feeds vg_gemm for nn.Conv2d: hieradet patch embed (R/.../backbones/utils.py:65-95), MaskDownSampler
+ * (R/.../memory_encoder.py:17-58), IV2/CLIP patch embeds. */
+int vg_im2col(const void* x, void* cols, int B, int H, int W, int C, int kh, int kw, int stride,
+              int pad, int Kpad, int dtype, vg_stream_t stream);
+/* depthwise kxk conv, stride 1, pad k/2, NHWC; w:[k*k, C] f32, bias:[C] f32  (CXBlock dwconv,
+ * R/.../memory_encoder.py:81-87) */
+int vg_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
+              int k, int dtype, vg_stream_t stream);
+/* ConvTranspose2d k2 s2 tail: g:[B,H,W,4,C] (GEMM output, tap = dy*2+dx) -> y:[B,2H,2W,C] (+bias)
+ * R/.../sam/mask_decoder.py:64-73 */
+int vg_pixel_shuffle2(const void* g, const float* bias, void* y, int B, int H, int W, int C, int dtype,
+                      vg_stream_t stream);
+/* 2x2 stride-2 max / mean pooling over an NHWC grid (Hiera q-pool hieradet.py:20-34,64-66;
+ * adaptive_avg_pool2d with integer ratio 2, R/model/videogpt_plus/model/arch.py:88-96) */
+int vg_pool2(const void* x, void* y, int B, int H, int W, int C, int64_t x_pix_stride, int is_max,
+             int dtype, vg_stream_t stream);
+/* window partition with zero padding / reverse with crop (R/.../backbones/utils.py:16-62) */
+int vg_window_partition(const void* x, void* win, int B, int H, int W, int C, int ws, int dtype,
+                        vg_stream_t stream);
+int vg_window_unpartition(const void* win, void* x, int B, int H, int W, int C, int ws, int dtype,
+                          vg_stream_t stream);
+/* bilinear resize, align_corners=False, no antialias, planar fp32 [N,Hi,Wi] -> [N,Ho,Wo]
+ * (F.interpolate at sam2_base.py:368-374, sam2_video_predictor.py:509-516, VideoGLaMM.py:147-153) */
+int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream);
+/* y:[B,2H,2W,C] = lateral + nearest2x(top:[B,H,W,C])   (FPN top-down, image_encoder.py:113-127) */
+int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C,
+                     int dtype, vg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VG_KERNELS_H */

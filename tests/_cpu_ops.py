@@ -1,0 +1,215 @@
+"""Plain-PyTorch statement of every operator in videoglamm_amd/ops.py (test infrastructure only).
+
+Used (a) on the GPU box as the fp32 reference each HIP kernel is compared with, and (b) on CPU to
+exercise the host-side graph code (videoglamm_amd/*.py) without a GPU by monkeypatching
+``videoglamm_amd.ops``.  Never imported by the product.
+"""
+import torch
+import torch.nn.functional as F
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+
+
+def _act(x, act):
+    if act == ACT_GELU:
+        return F.gelu(x)
+    if act == ACT_QUICK_GELU:
+        return x * torch.sigmoid(1.702 * x)
+    if act == ACT_RELU:
+        return F.relu(x)
+    if act == ACT_SILU:
+        return F.silu(x)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(x)
+    return x
+
+
+def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None):
+    odt = out_dtype if out_dtype is not None else x.dtype
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    y = _act(y, act)
+    if gamma is not None:
+        y = y * gamma
+    if residual is not None:
+        y = y + residual.float()
+    y = y.to(odt)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def bmm_nt(a, w, out_dtype=None):
+    odt = out_dtype if out_dtype is not None else a.dtype
+    return (a.float() @ w.float().transpose(-1, -2)).to(odt)
+
+
+def attention(q, k, v, scale, causal=False):
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, dim=1)
+    vf = v.float().permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, dim=1)
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    if causal:
+        i = torch.arange(Sq, device=q.device)[:, None]
+        j = torch.arange(Skv, device=q.device)[None, :]
+        s = s.masked_fill(j > i + (Skv - Sq), float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vf).permute(0, 2, 1, 3).contiguous().to(q.dtype)
+
+
+def layernorm(x, w, b, eps, out_dtype=None):
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(out_dtype or x.dtype)
+
+
+def rmsnorm(x, w, eps, out_dtype=None):
+    xf = x.float()
+    y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype).float()
+    if w is not None:
+        y = y * w
+    return y.to(out_dtype or x.dtype)
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out_dtype=None):
+    odt = out_dtype or a.dtype
+    if b is None:
+        return (alpha * a.float() + beta).to(odt)
+    reps = a.numel() // b.numel()
+    bb = b.float().reshape(-1).repeat(reps).reshape(a.shape)
+    return (alpha * a.float() + beta * bb).to(odt)
+
+
+def add(a, b):
+    return axpby(a, b, 1.0, 1.0)
+
+
+def activation(x, act, out_dtype=None):
+    return _act(x.float(), act).to(out_dtype or x.dtype)
+
+
+def swiglu(gu):
+    Fh = gu.shape[-1] // 2
+    g = F.silu(gu[..., :Fh].float()).to(gu.dtype).float()
+    return (g * gu[..., Fh:].float()).to(gu.dtype)
+
+
+def cast(x, dtype):
+    return x.to(dtype)
+
+
+def where_rows(cond, a, b=None, fill=0.0):
+    rows = cond.numel()
+    a2 = a.reshape(rows, -1)
+    if b is not None:
+        other = b.reshape(-1).repeat(a2.shape[1] // b.numel()).to(a.dtype)[None, :].expand_as(a2)
+    else:
+        other = torch.full_like(a2, fill)
+    return torch.where(cond.reshape(rows, 1) > 0, a2, other).reshape(a.shape)
+
+
+def mask_for_mem(x, binarize, scale, bias, out_dtype):
+    m = (x > 0).float() if binarize else torch.sigmoid(x)
+    return (m * scale + bias).to(out_dtype)
+
+
+def threshold(x):
+    return (x > 0).to(torch.uint8)
+
+
+def rope_half_(x, cos, sin, pos0):
+    S, H, D = x.shape
+    c = cos[pos0:pos0 + S].to(x.dtype)[:, None, :]
+    s = sin[pos0:pos0 + S].to(x.dtype)[:, None, :]
+    x1, x2 = x[..., : D // 2].clone(), x[..., D // 2:].clone()
+    x[..., : D // 2] = x1 * c + (-x2) * s
+    x[..., D // 2:] = x2 * c + x1 * s
+    return x
+
+
+def rope_axial_(x, cos, sin, n_rope, n_grid):
+    B, N, C = x.shape
+    if n_rope == 0:
+        return x
+    xr = x[:, :n_rope].float().reshape(B, n_rope, C // 2, 2)
+    reps = n_rope // n_grid
+    c = cos.repeat(reps, 1)[None]
+    s = sin.repeat(reps, 1)[None]
+    a, b = xr[..., 0], xr[..., 1]
+    out = torch.stack([a * c - b * s, a * s + b * c], dim=-1).reshape(B, n_rope, C)
+    x[:, :n_rope] = out.to(x.dtype)
+    return x
+
+
+def embed(ids, table):
+    return table[ids.reshape(-1)]
+
+
+def argmax(x):
+    return torch.argmax(x.float(), dim=-1)
+
+
+def permute5(x, dims, strides):
+    return torch.as_strided(x, dims, strides).contiguous()
+
+
+def im2col(x, kh, kw, stride, pad, kpad):
+    B, H, W, C = x.shape
+    cols = F.unfold(x.float().permute(0, 3, 1, 2), (kh, kw), padding=pad, stride=stride)  # [B, C*kh*kw, L]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    cols = cols.reshape(B, C, kh * kw, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, kh * kw * C)
+    out = torch.zeros(B * Ho * Wo, kpad, dtype=x.dtype, device=x.device)
+    out[:, : kh * kw * C] = cols.to(x.dtype)
+    return out, Ho, Wo
+
+
+def dwconv(x, w, bias, k):
+    B, H, W, C = x.shape
+    wt = w.reshape(k, k, C).permute(2, 0, 1)[:, None]  # [C,1,k,k]
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, padding=k // 2, groups=C)
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def pixel_shuffle2(g, bias, B, H, W, C):
+    y = g.float().reshape(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C)
+    if bias is not None:
+        y = y + bias
+    return y.to(g.dtype)
+
+
+def pool2(x, is_max):
+    xf = x.float().permute(0, 3, 1, 2)
+    y = F.max_pool2d(xf, 2, 2) if is_max else F.avg_pool2d(xf, 2, 2)
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def window_partition(x, ws):
+    B, H, W, C = x.shape
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    x = F.pad(x, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, ws * ws, C)
+
+
+def window_unpartition(win, ws, B, H, W):
+    C = win.shape[-1]
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    x = win.reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    return x[:, :H, :W].contiguous()
+
+
+def bilinear(x, Ho, Wo):
+    return F.interpolate(x[:, None].float(), size=(Ho, Wo), mode="bilinear", align_corners=False)[:, 0]
+
+
+def upsample2_add(lateral, top):
+    up = top.float().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    return (lateral.float() + up).to(lateral.dtype)
+
+
+ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]

@@ -1,0 +1,223 @@
+"""Per-kernel parity: every C-ABI entry point vs the plain-PyTorch fp32 statement in _cpu_ops.py.
+
+fp32 kernels must agree to ~1e-5 relative (MFMA f32 is an exact fp32 FMA chain, only the summation
+order differs); bf16 kernels are compared against the fp32 reference evaluated on the same
+bf16-rounded inputs, with a bf16-sized tolerance.
+"""
+import pytest
+import torch
+
+import _cpu_ops as ref
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, k=1):
+    if dtype == torch.float32:
+        return dict(rtol=2e-4, atol=2e-5 * max(1, k) ** 0.5)
+    return dict(rtol=2e-2, atol=2e-2 * max(1, k / 64) ** 0.5)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(a, b, **kw):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite output"
+    torch.testing.assert_close(a, b, **kw)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (257, 130, 72), (1, 512, 256), (7, 256, 2048), (16, 33, 64),
+                                   (4096, 384, 144), (1025, 1408, 1408), (300, 4, 32), (17, 200, 8), (513, 96, 152)])
+def test_gemm(cuda, dtype, M, N, K):
+    from videoglamm_amd import ops
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
+    bias, gamma = rnd(N, seed=3), rnd(N, seed=4)
+    res = rnd(M, N, dtype=dtype, seed=5)
+    for act in (ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU, ops.ACT_QUICK_GELU):
+        y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act, gamma.to(cuda), res.to(cuda))
+        close(y, ref.linear(x, w, bias, act, gamma, res), **tol(dtype, K))
+    y = ops.linear(x.to(cuda), w.to(cuda))
+    close(y, ref.linear(x, w), **tol(dtype, K))
+    if dtype == torch.bfloat16:
+        y = ops.linear(x.to(cuda), w.to(cuda), out_dtype=torch.float32)
+        close(y, ref.linear(x, w, out_dtype=torch.float32), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_transpose_detect(cuda):
+    """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
+    from videoglamm_amd import ops
+    n = 160
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    y = ops.linear(torch.eye(n).to(cuda), w.to(cuda))
+    close(y, w.t().contiguous(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_strided_views(cuda, dtype):
+    from videoglamm_amd import ops
+    big = rnd(300, 3 * 64, dtype=dtype, seed=7).to(cuda)
+    x = big[:, 64:128]                      # row stride 192, K=64
+    w = rnd(40, 64, dtype=dtype, seed=8)
+    out = torch.zeros(300, 80, dtype=dtype, device=cuda)
+    ops.linear(x, w.to(cuda), out=out[:, 40:])
+    close(out[:, 40:], ref.linear(big.cpu()[:, 64:128], w), **tol(dtype, 64))
+    assert float(out[:, :40].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bmm(cuda, dtype):
+    from videoglamm_amd import ops
+    a, w = rnd(3, 4, 32, dtype=dtype, seed=1), rnd(3, 1000, 32, dtype=dtype, seed=2)
+    close(ops.bmm_nt(a.to(cuda), w.to(cuda), out_dtype=torch.float32), ref.bmm_nt(a, w, torch.float32), **tol(dtype, 32))
+    a, w = rnd(2, 70, 64, dtype=dtype, seed=3), rnd(2, 50, 64, dtype=dtype, seed=4)
+    close(ops.bmm_nt(a.to(cuda), w.to(cuda)), ref.bmm_nt(a, w), **tol(dtype, 64))
+
+
+ATT = [  # B, Hq, Hkv, Sq, Skv, D, causal
+    (1, 2, 2, 64, 64, 72, False),     # Hiera window
+    (2, 4, 4, 16, 64, 72, False),     # Hiera q-pooled window
+    (1, 16, 16, 1025, 1025, 88, False),  # InternVideo2
+    (2, 16, 16, 577, 577, 64, False),    # CLIP
+    (1, 8, 8, 7, 4096, 16, False),    # two-way: tokens -> image
+    (2, 8, 8, 4096, 9, 16, False),    # two-way: image -> tokens
+    (1, 8, 8, 7, 7, 32, False),       # token self-attn
+    (1, 1, 1, 1024, 1024, 256, False),   # memory self-attn
+    (1, 1, 1, 1024, 2100, 256, False),   # memory cross-attn (ragged kv)
+    (1, 8, 2, 333, 333, 128, True),   # Llama GQA prefill
+    (1, 8, 2, 1, 700, 128, True),     # Llama decode step
+    (1, 4, 4, 100, 100, 96, True),    # Phi-3 head dim
+    (1, 4, 4, 33, 160, 64, True),     # causal with offset
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", ATT)
+def test_attention(cuda, dtype, cfg):
+    from videoglamm_amd import ops
+    B, Hq, Hkv, Sq, Skv, D, causal = cfg
+    q, k, v = rnd(B, Sq, Hq, D, dtype=dtype, seed=1), rnd(B, Skv, Hkv, D, dtype=dtype, seed=2), rnd(B, Skv, Hkv, D, dtype=dtype, seed=3)
+    o = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5, causal)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    close(o, ref.attention(q, k, v, D ** -0.5, causal), **t)
+
+
+def test_attention_fused_qkv_strides_and_spike(cuda):
+    """q/k/v as strided slices of one fused projection + a key spike that forces the online-softmax rescale."""
+    from videoglamm_amd import ops
+    B, S, H, D = 2, 200, 4, 72
+    qkv = rnd(B, S, 3, H, D, seed=11)
+    qkv[0, 150, 1] *= 30.0   # late, huge key -> running max jumps at a later tile
+    g = qkv.to(cuda)
+    o = ops.attention(g[:, :, 0], g[:, :, 1], g[:, :, 2], D ** -0.5)
+    close(o, ref.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,C", [(5, 4), (1025, 1408), (64, 256), (3, 4096), (4096, 64)])
+def test_norms(cuda, dtype, rows, C):
+    from videoglamm_amd import ops
+    x = rnd(rows, C, dtype=dtype, seed=1) + 3.0
+    w, b = rnd(C, seed=2), rnd(C, seed=3)
+    close(ops.layernorm(x.to(cuda), w.to(cuda), b.to(cuda), 1e-6), ref.layernorm(x, w, b, 1e-6), **tol(dtype))
+    close(ops.rmsnorm(x.to(cuda), w.to(cuda), 1e-5), ref.rmsnorm(x, w, 1e-5), **tol(dtype))
+    close(ops.layernorm(x.to(cuda), w.to(cuda), b.to(cuda), 1e-6, out_dtype=torch.float32),
+          ref.layernorm(x, w, b, 1e-6, out_dtype=torch.float32), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pointwise(cuda, dtype):
+    from videoglamm_amd import ops
+    a, b = rnd(6, 50, 32, dtype=dtype, seed=1), rnd(50, 32, dtype=dtype, seed=2)
+    close(ops.axpby(a.to(cuda), b.to(cuda), 1.0, 0.1), ref.axpby(a, b, 1.0, 0.1), **tol(dtype))
+    close(ops.add(a.to(cuda), a.to(cuda)), ref.add(a, a), **tol(dtype))
+    close(ops.axpby(a.to(cuda), rnd(32, seed=3).to(cuda), 2.0, 1.0), ref.axpby(a, rnd(32, seed=3), 2.0, 1.0), **tol(dtype))
+    for act in (1, 2, 3, 4, 5):
+        close(ops.activation(a.to(cuda), act), ref.activation(a, act), **tol(dtype))
+    gu = rnd(9, 2 * 48, dtype=dtype, seed=4)
+    close(ops.swiglu(gu.to(cuda)), ref.swiglu(gu), **tol(dtype))
+    close(ops.cast(a.to(cuda), torch.float32), a.float(), rtol=0, atol=0)
+    close(ops.cast(a.float().to(cuda), torch.bfloat16), a.float().to(torch.bfloat16), rtol=0, atol=0)
+    cond = torch.tensor([1.0, -1.0, 0.0, 2.0, -3.0, 5.0])
+    close(ops.where_rows(cond.to(cuda), a.to(cuda), None, -1024.0), ref.where_rows(cond, a, None, -1024.0), rtol=0, atol=0)
+    close(ops.where_rows(cond.to(cuda), a.to(cuda), b[0].to(cuda)), ref.where_rows(cond, a, b[0]), rtol=0, atol=0)
+    x = rnd(3, 40, 40, seed=5) * 4
+    for binz in (0, 1):
+        close(ops.mask_for_mem(x.to(cuda), binz, 20.0, -10.0, dtype), ref.mask_for_mem(x, binz, 20.0, -10.0, dtype), **tol(dtype))
+    assert torch.equal(ops.threshold(x.to(cuda)).cpu(), ref.threshold(x))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_rope_embed_argmax(cuda, dtype):
+    from videoglamm_amd import ops
+    S, H, D = 37, 6, 64
+    big = rnd(S, H + 2, D, dtype=dtype, seed=1)
+    ang = torch.arange(100)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, D, 2).float() / D)))[None]
+    cos, sin = ang.cos(), ang.sin()
+    g = big.to(cuda)
+    ops.rope_half_(g[:, :H], cos.to(cuda), sin.to(cuda), 11)
+    r = big.clone()
+    ref.rope_half_(r[:, :H], cos, sin, 11)
+    close(g, r, **tol(dtype))
+    B, N, C, n_grid = 2, 2 * 64 + 8, 32, 64
+    x = rnd(B, N, C, dtype=dtype, seed=2)
+    c2, s2 = rnd(n_grid, C // 2, seed=3).cos(), rnd(n_grid, C // 2, seed=3).sin()
+    g = x.to(cuda)
+    ops.rope_axial_(g, c2.to(cuda), s2.to(cuda), 2 * 64, n_grid)
+    close(g, ref.rope_axial_(x.clone(), c2, s2, 2 * 64, n_grid), **tol(dtype))
+    table = rnd(50, 24, dtype=dtype, seed=4)
+    ids = torch.tensor([3, 49, 0, 3, 7])
+    close(ops.embed(ids.to(cuda), table.to(cuda)), ref.embed(ids, table), rtol=0, atol=0)
+    lg = rnd(3, 1000, dtype=dtype, seed=5)
+    lg[1, 17] = lg[1, 900] = 50.0   # tie -> lowest index
+    assert torch.equal(ops.argmax(lg.to(cuda)).cpu(), torch.tensor([int(lg[0].float().argmax()), 17, int(lg[2].float().argmax())]))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_spatial(cuda, dtype):
+    from videoglamm_amd import ops
+    x = rnd(2, 12, 20, 8, dtype=dtype, seed=1)
+    g = x.to(cuda)
+    for (kh, st, pad) in ((7, 4, 3), (3, 2, 1), (2, 2, 0), (1, 1, 0)):
+        kp = -(-kh * kh * 8 // 8) * 8 + 8
+        c, Ho, Wo = ops.im2col(g, kh, kh, st, pad, kp)
+        cr, Hr, Wr = ref.im2col(x, kh, kh, st, pad, kp)
+        assert (Ho, Wo) == (Hr, Wr)
+        close(c, cr, rtol=0, atol=0)
+    w, b = rnd(49, 8, seed=2), rnd(8, seed=3)
+    close(ops.dwconv(g, w.to(cuda), b.to(cuda), 7), ref.dwconv(x, w, b, 7), **tol(dtype, 49))
+    gg = rnd(2 * 12 * 20, 4 * 8, dtype=dtype, seed=4)
+    close(ops.pixel_shuffle2(gg.to(cuda), b.to(cuda), 2, 12, 20, 8), ref.pixel_shuffle2(gg, b, 2, 12, 20, 8), **tol(dtype))
+    close(ops.pool2(g, True), ref.pool2(x, True), rtol=0, atol=0)
+    close(ops.pool2(g, False), ref.pool2(x, False), **tol(dtype))
+    fused = rnd(2, 12, 20, 24, dtype=dtype, seed=5)
+    close(ops.pool2(fused.to(cuda)[..., 8:16], True), ref.pool2(fused[..., 8:16], True), rtol=0, atol=0)
+    for ws in (4, 5, 7):
+        wn = ops.window_partition(g, ws)
+        close(wn, ref.window_partition(x, ws), rtol=0, atol=0)
+        close(ops.window_unpartition(wn, ws, 2, 12, 20), x, rtol=0, atol=0)
+    close(ops.upsample2_add(rnd(2, 24, 40, 8, dtype=dtype, seed=6).to(cuda), g), ref.upsample2_add(rnd(2, 24, 40, 8, dtype=dtype, seed=6), x), **tol(dtype))
+    p = ops.permute5(g, (2, 20, 12, 2, 4), (12 * 20 * 8, 8, 20 * 8, 4, 1))
+    close(p, ref.permute5(x, (2, 20, 12, 2, 4), (12 * 20 * 8, 8, 20 * 8, 4, 1)), rtol=0, atol=0)
+
+
+def test_bilinear(cuda):
+    from videoglamm_amd import ops
+    x = rnd(3, 64, 64, seed=1)
+    for (Ho, Wo) in ((256, 256), (100, 37), (32, 32), (64, 64), (224, 400)):
+        close(ops.bilinear(x.to(cuda), Ho, Wo), ref.bilinear(x, Ho, Wo), rtol=1e-5, atol=1e-5)
+
+
+def test_errors_are_loud(cuda):
+    from videoglamm_amd import _lib, ops
+    with pytest.raises(_lib.VGKernelError):
+        ops.linear(torch.zeros(4, 12, device=cuda)[:, :6], torch.zeros(4, 12, device=cuda)[:, :6])  # K=6 not a multiple of 4
+    with pytest.raises(_lib.VGKernelError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(4, 8))  # CPU tensors: no fallback

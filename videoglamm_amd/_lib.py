@@ -1,0 +1,80 @@
+"""ctypes binding of libvgkernels.so (include/vg_kernels.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C videoglamm_amd/csrc``.
+There is NO fallback: if the shared object is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvgkernels.so")
+
+_lib = None
+
+
+class VGKernelError(RuntimeError):
+    pass
+
+
+def _sig(lib):
+    P, I, L, F = c_void_p, c_int, c_int64, c_float
+    S = {
+        "vg_version": ([], c_int),
+        "vg_last_error": ([], c_char_p),
+        "vg_init": ([I], c_int),
+        "vg_gemm": ([P, L, L, P, L, L, P, L, L, P, P, P, L, L, I, I, I, I, I, I, I, P], c_int),
+        "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),
+        "vg_layernorm": ([P, L, P, P, P, L, L, I, F, I, I, P], c_int),
+        "vg_rmsnorm": ([P, L, P, P, L, L, I, F, I, I, P], c_int),
+        "vg_axpby": ([P, P, P, L, F, F, L, I, I, I, P], c_int),
+        "vg_activation": ([P, P, L, I, I, I, P], c_int),
+        "vg_swiglu": ([P, P, L, I, I, P], c_int),
+        "vg_cast": ([P, P, L, I, I, P], c_int),
+        "vg_where_rows": ([P, P, P, P, L, L, L, F, I, P], c_int),
+        "vg_mask_for_mem": ([P, P, L, I, F, F, I, P], c_int),
+        "vg_threshold": ([P, P, L, P], c_int),
+        "vg_rope_half": ([P, L, L, P, P, I, I, I, I, I, P], c_int),
+        "vg_rope_axial": ([P, P, P, I, I, I, I, I, I, P], c_int),
+        "vg_embed": ([P, P, P, L, I, I, P], c_int),
+        "vg_argmax": ([P, L, I, P, I, P], c_int),
+        "vg_permute5": ([P, P, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), I, P], c_int),
+        "vg_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, P], c_int),
+        "vg_dwconv": ([P, P, P, P, I, I, I, I, I, I, P], c_int),
+        "vg_pixel_shuffle2": ([P, P, P, I, I, I, I, I, P], c_int),
+        "vg_pool2": ([P, P, I, I, I, I, L, I, I, P], c_int),
+        "vg_window_partition": ([P, P, I, I, I, I, I, I, P], c_int),
+        "vg_window_unpartition": ([P, P, I, I, I, I, I, I, P], c_int),
+        "vg_bilinear": ([P, P, I, I, I, I, I, P], c_int),
+        "vg_upsample2_add": ([P, P, P, I, I, I, I, I, P], c_int),
+    }
+    for name, (args, res) in S.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.argtypes = args
+        fn.restype = res
+    return list(S)
+
+
+EXPORTS = []
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises VGKernelError when the .so is absent."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VGKernelError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C videoglamm_amd/csrc). "
+                "There is no CPU fallback for the VideoGLaMM hot path."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        EXPORTS = _sig(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vg_last_error()
+        raise VGKernelError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,249 @@
+// vg_attention: flash-style attention for gfx950 (see include/vg_kernels.h).
+//
+// Workgroup = NW waves, each owning 32 query rows; K/V tiles of BKV keys staged in LDS once per
+// workgroup and shared by all waves; Q tile staged once.  Per wave and 32-key sub-tile:
+//   S^T[key,q] = K·Q^T   (MFMA 32x32, "swapped" product: a lane owns ONE query column q = lane&31 and
+//                         16 key rows, so the softmax row statistics are lane-local + one xor-32 shuffle)
+//   online softmax in registers (running max m, running sum l per lane/query)
+//   O^T[d,q]  += V^T·P^T (P^T stays in the accumulator registers it was produced in and is fed to
+//                         the MFMA B operand directly; the key order inside a k-step is the MFMA
+//                         row map, applied identically to the V gather, so no cross-lane traffic)
+// LDS rows are padded by 16 B so the 16-byte fragment reads are bank-conflict free.
+#include "vg_common.h"
+#include <math.h>
+
+struct AttnArgs {
+  const void* Q; const void* K; const void* V; void* O;
+  int B, Hq, Hkv, Sq, Skv, D, causal;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+  float scale;
+};
+
+template <typename T> struct AMma;
+template <> struct AMma<bf16_t> {
+  static __device__ __forceinline__ void qk(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct AMma<float> {
+  static __device__ __forceinline__ void qk(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+// O^T[dt] += V^T P^T for one 32-key sub-tile; vs = LDS pointer to the sub-tile's first key row.
+template <typename T, int RS>
+__device__ __forceinline__ void pv_step(const char* vs, int col, int h, const f32x16_t& p, f32x16_t& o);
+
+template <int RS>
+__device__ __forceinline__ void pv_step_bf16(const char* vs, int col, int h, const f32x16_t& p, f32x16_t& o) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    u32x4_t a, b;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r0 = st * 8 + jj * 2, r1 = r0 + 1;
+      const uint32_t v0 = *(const bf16_t*)(vs + mfma32_row(r0, h) * RS + col * 2);
+      const uint32_t v1 = *(const bf16_t*)(vs + mfma32_row(r1, h) * RS + col * 2);
+      a[jj] = v0 | (v1 << 16);
+      b[jj] = (uint32_t)f2bf(p[r0]) | ((uint32_t)f2bf(p[r1]) << 16);
+    }
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                __builtin_bit_cast(bf16x8_t, b), o, 0, 0, 0);
+  }
+}
+template <int RS>
+__device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, const f32x16_t& p, f32x16_t& o) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float a = *(const float*)(vs + mfma32_row(r, h) * RS + col * 4);
+    o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p[r], o, 0, 0, 0);
+  }
+}
+
+template <typename T, int DP, int BKV, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int KPC = 16 / ES;
+  constexpr int RS = DP * ES + 16;  // LDS row stride in bytes
+  constexpr int CPR = DP * ES / 16; // 16-byte chunks per row
+  constexpr int BQ = NW * 32;
+  constexpr int NT = NW * 64;
+  constexpr int NG = DP * ES / 32;  // k-groups (two 16-byte chunks each) along the head dim
+  constexpr int NDT = DP / 32;
+  constexpr int NKT = BKV / 32;
+  char* Qs = smem;
+  char* Ks = Qs + BQ * RS;
+  char* Vs = Ks + BKV * RS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * BQ, head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (p.Hq / p.Hkv);
+  const int D = p.D, Sq = p.Sq, Skv = p.Skv;
+  const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
+  const T* Kg = (const T*)p.K + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+  for (int idx = tid; idx < BQ * CPR; idx += NT) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    const int q = q0 + row;
+    u32x4_t v = zero4;
+    if (q < Sq && c * KPC < D) v = *(const u32x4_t*)(Qg + (int64_t)q * p.q_ss + c * KPC);
+    *(u32x4_t*)(Qs + row * RS + c * 16) = v;
+  }
+
+  const int off = Skv - Sq;
+  int kv_end = Skv;
+  if (p.causal) {
+    const int lim = q0 + BQ + off;  // keys >= lim are invisible to every query of this block
+    kv_end = lim < Skv ? (lim > 0 ? lim : 0) : Skv;
+  }
+
+  float m_i = -INFINITY, l_i = 0.f;
+  f32x16_t o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  const int q_local = wave * 32 + l31;
+  const int q_idx = q0 + q_local;
+  const char* qrow = Qs + q_local * RS + h * 16;
+
+  for (int kv0 = 0; kv0 < kv_end; kv0 += BKV) {
+    __syncthreads();
+    for (int idx = tid; idx < BKV * CPR; idx += NT) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int key = kv0 + row;
+      u32x4_t kv = zero4, vv = zero4;
+      if (key < Skv && c * KPC < D) {
+        kv = *(const u32x4_t*)(Kg + (int64_t)key * p.k_ss + c * KPC);
+        vv = *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC);
+      }
+      *(u32x4_t*)(Ks + row * RS + c * 16) = kv;
+      *(u32x4_t*)(Vs + row * RS + c * 16) = vv;
+    }
+    __syncthreads();
+
+    f32x16_t s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const char* krow = Ks + (kt * 32 + l31) * RS + h * 16;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const u32x4_t a = *(const u32x4_t*)(krow + g * 32);
+        const u32x4_t bq = *(const u32x4_t*)(qrow + g * 32);
+        AMma<T>::qk(a, bq, s[kt]);
+      }
+    }
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + kt * 32 + mfma32_row(r, h);
+        const bool ok = key < Skv && (!p.causal || key <= q_idx + off);
+        const float v = ok ? s[kt][r] * p.scale : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_i - m_safe);
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(s[kt][r] - m_safe);
+        s[kt][r] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const char* vs = Vs + kt * 32 * RS;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        if constexpr (sizeof(T) == 2) pv_step_bf16<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+        else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+      }
+    }
+  }
+
+  if (q_idx < Sq) {
+    const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+    T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)q_idx * p.o_ss;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + mfma32_row(r, h);
+        if (d < D) vg_elt<T>::st(Og + d, o[dt][r] * inv);
+      }
+  }
+}
+
+template <typename T, int DP, int BKV, int NW>
+static int launch_attn(const AttnArgs& p, hipStream_t st) {
+  constexpr int RS = DP * sizeof(T) + 16;
+  constexpr int lds = (NW * 32 + 2 * BKV) * RS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid((p.Sq + NW * 32 - 1) / (NW * 32), p.Hq, p.B);
+  attn_kernel<T, DP, BKV, NW><<<grid, NW * 64, lds, st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+template <typename T, int BKV, int NW>
+static int dispatch_dp(const AttnArgs& p, hipStream_t st) {
+  const int D = p.D;
+  if (D <= 32) return launch_attn<T, 32, BKV, NW>(p, st);
+  if (D <= 64) return launch_attn<T, 64, BKV, NW>(p, st);
+  if (D <= 96) return launch_attn<T, 96, BKV, NW>(p, st);
+  if (D <= 128) return launch_attn<T, 128, BKV, NW>(p, st);
+  return launch_attn<T, 256, BKV, NW>(p, st);
+}
+
+extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                            int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                            int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                            int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                            int causal, int dtype, vg_stream_t stream) {
+  VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_attention: null pointer");
+  VG_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Sq >= 0 && Skv > 0, VG_ERR_ARG,
+           "vg_attention: bad shape B=%d Hq=%d Hkv=%d Sq=%d Skv=%d", B, Hq, Hkv, Sq, Skv);
+  VG_CHECK(D > 0 && D <= 256 && D % 8 == 0, VG_ERR_ARG, "vg_attention: head dim %d unsupported (multiple of 8, <= 256)", D);
+  VG_CHECK(dtype == VG_F32 || dtype == VG_BF16, VG_ERR_ARG, "vg_attention: bad dtype %d", dtype);
+  const int kpc = dtype == VG_BF16 ? 8 : 4;
+  VG_CHECK(q_ss % kpc == 0 && q_sh % kpc == 0 && q_sb % kpc == 0 && k_ss % kpc == 0 && k_sh % kpc == 0 &&
+               k_sb % kpc == 0 && v_ss % kpc == 0 && v_sh % kpc == 0 && v_sb % kpc == 0,
+           VG_ERR_ARG, "vg_attention: q/k/v strides must keep 16-byte alignment");
+  VG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, VG_ERR_ARG, "vg_attention: q/k/v must be 16-byte aligned");
+  if (Sq == 0) return VG_OK;
+  AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VG_BF16) return dispatch_dp<bf16_t, 64, 4>(p, st);
+  return dispatch_dp<float, 32, 2>(p, st);
+}

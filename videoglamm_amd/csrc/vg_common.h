@@ -1,0 +1,85 @@
+// Shared device/host helpers for the VideoGLaMM MI355X (gfx950) kernel library.
+// wave = 64 lanes, MFMA 32x32 tiles, fp32 accumulate everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/vg_kernels.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+#define VG_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct vg_elt;
+template <> struct vg_elt<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct vg_elt<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// dtype-erased scalar load/store (dt: VG_F32 / VG_BF16), index in elements
+__device__ __forceinline__ float ld_any(const void* p, int64_t i, int dt) {
+  return dt == VG_BF16 ? bf2f(((const bf16_t*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t i, int dt, float v) {
+  if (dt == VG_BF16) ((bf16_t*)p)[i] = f2bf(v); else ((float*)p)[i] = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activation codes (vg_kernels.h): 0 none, 1 gelu(erf), 2 quick_gelu, 3 relu, 4 silu, 5 sigmoid
+__device__ __forceinline__ float vg_act(float x, int act) {
+  switch (act) {
+    case VG_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case VG_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+    case VG_ACT_RELU: return x > 0.f ? x : 0.f;
+    case VG_ACT_SILU: return x / (1.0f + __expf(-x));
+    case VG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    default: return x;
+  }
+}
+
+// row index of accumulator register r for lane-half h in the 32x32 MFMA C/D layout
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// host-side error plumbing (vg_api.cpp)
+extern "C" void vg_set_error(const char* fmt, ...);
+#define VG_CHECK(cond, code, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      vg_set_error(__VA_ARGS__);             \
+      return (code);                         \
+    }                                        \
+  } while (0)
+#define VG_LAUNCH_CHECK()                                              \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) {                                           \
+      vg_set_error("launch failed: %s", hipGetErrorString(e__));       \
+      return VG_ERR_LAUNCH;                                            \
+    }                                                                  \
+  } while (0)

@@ -1,0 +1,222 @@
+// vg_gemm: C = ((act(A @ W^T + bias)) * gamma) + R      (see include/vg_kernels.h)
+//
+// Two kernels:
+//   gemm_tile_kernel   128x128 output tile / 256-thread workgroup (4 waves as 2x2, each 64x64 =
+//                      2x2 MFMA 32x32 tiles), K stepped 128 bytes at a time (64 bf16 / 32 f32),
+//                      global -> registers -> LDS double buffer (one barrier per K step), LDS rows
+//                      padded to 144 B so the ds_read_b128 fragment reads are bank-conflict free.
+//                      bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
+//   gemm_skinny_kernel M <= 16 rows (LLM decode GEMV, mask-decoder token MLPs): one wave per output
+//                      column streams its W row once with 16-byte loads; HBM-bound by construction.
+#include "vg_common.h"
+
+struct GemmArgs {
+  const void* A; const void* W; void* C; const float* bias; const float* gamma; const void* R;
+  int64_t lda, ldw, ldc, ldr, sA, sW, sC, sR;
+  int M, N, K, act;
+};
+
+template <typename T> struct MmaOp;
+template <> struct MmaOp<bf16_t> {
+  static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaOp<float> {
+  static __device__ __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+constexpr int GBM = 128, GBN = 128, GROWB = 144, GTILEB = 128 * GROWB;  // bytes
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = 128 / sizeof(T);   // K elements per step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  u32x4_t ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      const int k = kt * BK + kc * KPC;
+      const int gm = bm * GBM + row, gn = bn * GBN + row;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      ra[i] = (gm < M && k < K) ? *(const u32x4_t*)(A + (int64_t)gm * p.lda + k) : z;
+      rb[i] = (gn < N && k < K) ? *(const u32x4_t*)(W + (int64_t)gn * p.ldw + k) : z;
+    }
+  };
+  auto swrite = [&](int buf) {
+    char* sa = smem + buf * 2 * GTILEB;
+    char* sb = sa + GTILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      *(u32x4_t*)(sa + row * GROWB + kc * 16) = ra[i];
+      *(u32x4_t*)(sb + row * GROWB + kc * 16) = rb[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* sa = smem + buf * 2 * GTILEB + (wm * 64 + l31) * GROWB + h * 16;
+    const char* sb = smem + buf * 2 * GTILEB + GTILEB + (wn * 64 + l31) * GROWB + h * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x4_t a0 = *(const u32x4_t*)(sa + g * 32);
+      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * GROWB + g * 32);
+      u32x4_t b0 = *(const u32x4_t*)(sb + g * 32);
+      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * GROWB + g * 32);
+      MmaOp<T>::run(a0, b0, acc[0][0]);
+      MmaOp<T>::run(a0, b1, acc[0][1]);
+      MmaOp<T>::run(a1, b0, acc[1][0]);
+      MmaOp<T>::run(a1, b1, acc[1][1]);
+    }
+    if (kt + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+  }
+
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = bn * GBN + wn * 64 + j * 32 + l31;
+      if (n >= N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float gv = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm * GBM + wm * 64 + i * 32 + mfma32_row(r, h);
+        if (m >= M) continue;
+        float v = vg_act(acc[i][j][r] + bv, p.act) * gv;
+        if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
+        vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
+      }
+    }
+}
+
+template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& a, const u32x4_t& b);
+template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& a, const u32x4_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(a[e]), __uint_as_float(b[e]), s);
+  return s;
+}
+template <> __device__ __forceinline__ float dot16<bf16_t>(const u32x4_t& a, const u32x4_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), s);
+    s = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), s);
+  }
+  return s;
+}
+
+template <typename T, typename TO, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+  constexpr int KPC = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave, bz = blockIdx.z;
+  if (n >= p.N) return;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* Wr = (const T*)p.W + (int64_t)bz * p.sW + (int64_t)n * p.ldw;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (int k = lane * KPC; k < p.K; k += 64 * KPC) {
+    const u32x4_t wv = *(const u32x4_t*)(Wr + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < p.M) {
+        const u32x4_t av = *(const u32x4_t*)(A + (int64_t)m * p.lda + k);
+        acc[m] += dot16<T>(wv, av);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+  if (lane == 0) {
+    TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+    const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    const float gv = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < p.M) {
+        float v = vg_act(acc[m] + bv, p.act) * gv;
+        if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
+        vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
+      }
+    }
+  }
+}
+
+template <typename T, typename TO>
+static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
+  if (p.M <= 16) {
+    dim3 grid((p.N + 3) / 4, 1, batch);
+    if (p.M <= 1) gemm_skinny_kernel<T, TO, 1><<<grid, 256, 0, st>>>(p);
+    else if (p.M <= 4) gemm_skinny_kernel<T, TO, 4><<<grid, 256, 0, st>>>(p);
+    else if (p.M <= 8) gemm_skinny_kernel<T, TO, 8><<<grid, 256, 0, st>>>(p);
+    else gemm_skinny_kernel<T, TO, 16><<<grid, 256, 0, st>>>(p);
+  } else {
+    static bool attr_set = false;
+    const int lds = 4 * GTILEB;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
+    gemm_tile_kernel<T, TO><<<grid, 256, lds, st>>>(p);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
+                       void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
+                       const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
+                       int in_dtype, int out_dtype, int act, vg_stream_t stream) {
+  VG_CHECK(A && W && C, VG_ERR_ARG, "vg_gemm: null pointer");
+  VG_CHECK(M >= 0 && N > 0 && K > 0 && batch >= 1, VG_ERR_ARG, "vg_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  if (M == 0) return VG_OK;
+  const int kpc = in_dtype == VG_BF16 ? 8 : 4;
+  VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_gemm: bad in_dtype %d", in_dtype);
+  VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && sA % kpc == 0 && sW % kpc == 0, VG_ERR_ARG,
+           "vg_gemm: K/lda/ldw/strides must be multiples of %d (K=%d lda=%lld ldw=%lld)", kpc, K, (long long)lda, (long long)ldw);
+  VG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, VG_ERR_ARG, "vg_gemm: A/W must be 16-byte aligned");
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act};
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
+  if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);
+  if (in_dtype == VG_F32 && out_dtype == VG_F32) return launch_gemm<float, float>(p, batch, st);
+  if (in_dtype == VG_F32 && out_dtype == VG_BF16) return launch_gemm<float, bf16_t>(p, batch, st);
+  vg_set_error("vg_gemm: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
+  return VG_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,198 @@
+// Pointwise / gather kernels (HBM-bound): grid-stride, coalesced, dtype-erased scalar accessors.
+#include "vg_common.h"
+#include <math.h>
+
+static inline dim3 pw_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;  // 256 CUs x 16 resident workgroups, grid-stride the rest
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+#define PW_LOOP(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
+
+__global__ __launch_bounds__(256) void axpby_kernel(const void* a, const void* b, void* out, int64_t n, float alpha,
+                                                    float beta, int64_t bp, int adt, int bdt, int odt) {
+  PW_LOOP(i, n) {
+    const float av = ld_any(a, i, adt);
+    const float bv = b ? ld_any(b, i % bp, bdt) : 1.f;
+    st_any(out, i, odt, alpha * av + beta * bv);
+  }
+}
+extern "C" int vg_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta,
+                        int64_t b_period, int a_dtype, int b_dtype, int out_dtype, vg_stream_t stream) {
+  VG_CHECK(a && out && n >= 0 && (!b || b_period > 0), VG_ERR_ARG, "vg_axpby: bad args");
+  if (n == 0) return VG_OK;
+  axpby_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(a, b, out, n, alpha, beta, b ? b_period : 1, a_dtype, b_dtype, out_dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void act_kernel(const void* x, void* y, int64_t n, int act, int idt, int odt) {
+  PW_LOOP(i, n) st_any(y, i, odt, vg_act(ld_any(x, i, idt), act));
+}
+extern "C" int vg_activation(const void* x, void* y, int64_t n, int act, int in_dtype, int out_dtype, vg_stream_t stream) {
+  VG_CHECK(x && y && n >= 0, VG_ERR_ARG, "vg_activation: bad args");
+  if (n == 0) return VG_OK;
+  act_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(x, y, n, act, in_dtype, out_dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void swiglu_kernel(const void* gu, void* y, int64_t M, int F, int dt) {
+  const int64_t n = M * F;
+  PW_LOOP(i, n) {
+    const int64_t m = i / F;
+    const int f = (int)(i - m * F);
+    float g = ld_any(gu, m * 2 * F + f, dt);
+    const float u = ld_any(gu, m * 2 * F + F + f, dt);
+    g = g / (1.0f + __expf(-g));
+    if (dt == VG_BF16) g = bf2f(f2bf(g));  // HF: act(gate) materialised in bf16 before the product
+    st_any(y, i, dt, g * u);
+  }
+}
+extern "C" int vg_swiglu(const void* gu, void* y, int64_t M, int F, int dtype, vg_stream_t stream) {
+  VG_CHECK(gu && y && M >= 0 && F > 0, VG_ERR_ARG, "vg_swiglu: bad args");
+  if (M == 0) return VG_OK;
+  swiglu_kernel<<<pw_grid(M * F), 256, 0, (hipStream_t)stream>>>(gu, y, M, F, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const void* in, void* out, int64_t n, int idt, int odt) {
+  PW_LOOP(i, n) st_any(out, i, odt, ld_any(in, i, idt));
+}
+extern "C" int vg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, vg_stream_t stream) {
+  VG_CHECK(in && out && n >= 0, VG_ERR_ARG, "vg_cast: bad args");
+  if (n == 0) return VG_OK;
+  cast_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(in, out, n, in_dtype, out_dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void where_rows_kernel(const float* cond, const void* a, const void* b, void* out,
+                                                         int64_t rows, int64_t inner, int64_t bp, float fill, int dt) {
+  const int64_t n = rows * inner;
+  PW_LOOP(i, n) {
+    const int64_t r = i / inner, c = i - r * inner;
+    float v;
+    if (cond[r] > 0.f) v = ld_any(a, i, dt);
+    else v = b ? ld_any(b, c % bp, dt) : fill;
+    st_any(out, i, dt, v);
+  }
+}
+extern "C" int vg_where_rows(const float* cond, const void* a, const void* b, void* out, int64_t rows, int64_t inner,
+                             int64_t b_period, float fill, int dtype, vg_stream_t stream) {
+  VG_CHECK(cond && a && out && rows >= 0 && inner > 0, VG_ERR_ARG, "vg_where_rows: bad args");
+  if (rows == 0) return VG_OK;
+  where_rows_kernel<<<pw_grid(rows * inner), 256, 0, (hipStream_t)stream>>>(cond, a, b, out, rows, inner, b ? b_period : 1, fill, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void mask_for_mem_kernel(const float* x, void* out, int64_t n, int binarize, float scale,
+                                                           float bias, int odt) {
+  PW_LOOP(i, n) {
+    const float v = x[i];
+    // torch.sigmoid in fp32 (sam2_base.py:689) — use the accurate expf here, the value feeds a recurrence
+    const float m = binarize ? (v > 0.f ? 1.f : 0.f) : 1.0f / (1.0f + expf(-v));
+    st_any(out, i, odt, m * scale + bias);
+  }
+}
+extern "C" int vg_mask_for_mem(const float* x, void* out, int64_t n, int binarize, float scale, float bias,
+                               int out_dtype, vg_stream_t stream) {
+  VG_CHECK(x && out && n >= 0, VG_ERR_ARG, "vg_mask_for_mem: bad args");
+  if (n == 0) return VG_OK;
+  mask_for_mem_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(x, out, n, binarize, scale, bias, out_dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void threshold_kernel(const float* x, uint8_t* out, int64_t n) {
+  PW_LOOP(i, n) out[i] = x[i] > 0.f ? 1 : 0;
+}
+extern "C" int vg_threshold(const float* x, uint8_t* out, int64_t n, vg_stream_t stream) {
+  VG_CHECK(x && out && n >= 0, VG_ERR_ARG, "vg_threshold: bad args");
+  if (n == 0) return VG_OK;
+  threshold_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(x, out, n);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void rope_half_kernel(void* x, int64_t x_ss, int64_t x_sh, const float* cs, const float* sn,
+                                                        int S, int H, int D, int pos0, int dt) {
+  const int hd = D / 2;
+  const int64_t n = (int64_t)S * H * hd;
+  PW_LOOP(i, n) {
+    const int d = (int)(i % hd);
+    const int64_t t = i / hd;
+    const int hh = (int)(t % H);
+    const int s = (int)(t / H);
+    const int64_t base = (int64_t)s * x_ss + (int64_t)hh * x_sh;
+    const float c = cs[(int64_t)(pos0 + s) * hd + d], sv = sn[(int64_t)(pos0 + s) * hd + d];
+    const float x1 = ld_any(x, base + d, dt), x2 = ld_any(x, base + d + hd, dt);
+    float o1, o2;
+    if (dt == VG_BF16) {
+      // HF computes q*cos + rotate_half(q)*sin with every product rounded to the tensor dtype
+      const float cb = bf2f(f2bf(c)), sb = bf2f(f2bf(sv));
+      o1 = bf2f(f2bf(x1 * cb)) + bf2f(f2bf(-x2 * sb));
+      o2 = bf2f(f2bf(x2 * cb)) + bf2f(f2bf(x1 * sb));
+    } else {
+      o1 = x1 * c - x2 * sv;
+      o2 = x2 * c + x1 * sv;
+    }
+    st_any(x, base + d, dt, o1);
+    st_any(x, base + d + hd, dt, o2);
+  }
+}
+extern "C" int vg_rope_half(void* x, int64_t x_ss, int64_t x_sh, const float* cos, const float* sin, int S, int H, int D,
+                            int pos0, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && cos && sin && S >= 0 && H > 0 && D > 0 && D % 2 == 0, VG_ERR_ARG, "vg_rope_half: bad args");
+  if (S == 0) return VG_OK;
+  rope_half_kernel<<<pw_grid((int64_t)S * H * D / 2), 256, 0, (hipStream_t)stream>>>(x, x_ss, x_sh, cos, sin, S, H, D, pos0, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void rope_axial_kernel(void* x, const float* cs, const float* sn, int B, int N, int C,
+                                                         int n_rope, int n_grid, int dt) {
+  const int hc = C / 2;
+  const int64_t n = (int64_t)B * n_rope * hc;
+  PW_LOOP(i, n) {
+    const int pr = (int)(i % hc);
+    const int64_t t = i / hc;
+    const int tok = (int)(t % n_rope);
+    const int b = (int)(t / n_rope);
+    const int64_t base = ((int64_t)b * N + tok) * C + 2 * pr;
+    const int g = tok % n_grid;
+    const float c = cs[(int64_t)g * hc + pr], s = sn[(int64_t)g * hc + pr];
+    const float a = ld_any(x, base, dt), bb = ld_any(x, base + 1, dt);
+    st_any(x, base, dt, a * c - bb * s);
+    st_any(x, base + 1, dt, a * s + bb * c);
+  }
+}
+extern "C" int vg_rope_axial(void* x, const float* cos, const float* sin, int B, int N, int C, int n_rope, int n_grid,
+                             int dtype, vg_stream_t stream) {
+  VG_CHECK(x && cos && sin && B > 0 && N > 0 && C % 2 == 0 && n_rope >= 0 && n_rope <= N && n_grid > 0, VG_ERR_ARG,
+           "vg_rope_axial: bad args");
+  if (n_rope == 0) return VG_OK;
+  rope_axial_kernel<<<pw_grid((int64_t)B * n_rope * C / 2), 256, 0, (hipStream_t)stream>>>(x, cos, sin, B, N, C, n_rope, n_grid, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* ids, const void* table, void* out, int64_t n, int D, int dt) {
+  const int64_t tot = n * D;
+  PW_LOOP(i, tot) {
+    const int64_t r = i / D;
+    const int c = (int)(i - r * D);
+    st_any(out, i, dt, ld_any(table, ids[r] * D + c, dt));
+  }
+}
+extern "C" int vg_embed(const int64_t* ids, const void* table, void* out, int64_t n, int D, int dtype, vg_stream_t stream) {
+  VG_CHECK(ids && table && out && n >= 0 && D > 0, VG_ERR_ARG, "vg_embed: bad args");
+  if (n == 0) return VG_OK;
+  embed_kernel<<<pw_grid(n * D), 256, 0, (hipStream_t)stream>>>(ids, table, out, n, D, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

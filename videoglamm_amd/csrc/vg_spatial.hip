@@ -1,0 +1,244 @@
+// Spatial / layout kernels on NHWC tensors (HBM-bound; the channel dim is the coalesced one).
+#include "vg_common.h"
+#include <math.h>
+
+static inline dim3 sp_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+#define SP_LOOP(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (int64_t)gridDim.x * 256)
+
+struct Perm5 { int64_t d[5]; int64_t s[5]; };
+__global__ __launch_bounds__(256) void permute5_kernel(const void* in, void* out, Perm5 p, int dt) {
+  const int64_t n = p.d[0] * p.d[1] * p.d[2] * p.d[3] * p.d[4];
+  SP_LOOP(i, n) {
+    int64_t r = i;
+    const int64_t i4 = r % p.d[4]; r /= p.d[4];
+    const int64_t i3 = r % p.d[3]; r /= p.d[3];
+    const int64_t i2 = r % p.d[2]; r /= p.d[2];
+    const int64_t i1 = r % p.d[1]; r /= p.d[1];
+    const int64_t src = r * p.s[0] + i1 * p.s[1] + i2 * p.s[2] + i3 * p.s[3] + i4 * p.s[4];
+    if (dt == VG_BF16) ((bf16_t*)out)[i] = ((const bf16_t*)in)[src];
+    else ((float*)out)[i] = ((const float*)in)[src];
+  }
+}
+extern "C" int vg_permute5(const void* in, void* out, const int64_t dims[5], const int64_t strides[5], int dtype,
+                           vg_stream_t stream) {
+  VG_CHECK(in && out && dims && strides, VG_ERR_ARG, "vg_permute5: null");
+  Perm5 p;
+  int64_t n = 1;
+  for (int i = 0; i < 5; ++i) { p.d[i] = dims[i]; p.s[i] = strides[i]; n *= dims[i]; VG_CHECK(dims[i] >= 0, VG_ERR_ARG, "vg_permute5: negative dim"); }
+  if (n == 0) return VG_OK;
+  permute5_kernel<<<sp_grid(n), 256, 0, (hipStream_t)stream>>>(in, out, p, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void im2col_kernel(const void* x, void* cols, int B, int H, int W, int C, int kh, int kw,
+                                                     int stride, int pad, int Ho, int Wo, int Kpad, int dt) {
+  const int64_t n = (int64_t)B * Ho * Wo * Kpad;
+  const int Kreal = kh * kw * C;
+  SP_LOOP(i, n) {
+    const int kk = (int)(i % Kpad);
+    int64_t r = i / Kpad;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float v = 0.f;
+    if (kk < Kreal) {
+      const int c = kk % C;
+      const int t = kk / C;
+      const int kx = t % kw, ky = t / kw;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld_any(x, (((int64_t)b * H + iy) * W + ix) * C + c, dt);
+    }
+    st_any(cols, i, dt, v);
+  }
+}
+extern "C" int vg_im2col(const void* x, void* cols, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                         int Kpad, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && Kpad >= kh * kw * C,
+           VG_ERR_ARG, "vg_im2col: bad args");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  im2col_kernel<<<sp_grid((int64_t)B * Ho * Wo * Kpad), 256, 0, (hipStream_t)stream>>>(x, cols, B, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void dwconv_kernel(const void* x, const float* w, const float* bias, void* y, int B, int H,
+                                                     int W, int C, int k, int dt) {
+  const int64_t n = (int64_t)B * H * W * C;
+  const int pad = k / 2;
+  SP_LOOP(i, n) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % W); r /= W;
+    const int oy = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc = bias ? bias[c] : 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy - pad + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox - pad + kx;
+        if (ix < 0 || ix >= W) continue;
+        acc = fmaf(ld_any(x, (((int64_t)b * H + iy) * W + ix) * C + c, dt), w[(ky * k + kx) * C + c], acc);
+      }
+    }
+    st_any(y, i, dt, acc);
+  }
+}
+extern "C" int vg_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+                         int dtype, vg_stream_t stream) {
+  VG_CHECK(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && (k & 1), VG_ERR_ARG, "vg_dwconv: bad args");
+  dwconv_kernel<<<sp_grid((int64_t)B * H * W * C), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, B, H, W, C, k, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const void* g, const float* bias, void* y, int B, int H, int W,
+                                                             int C, int dt) {
+  const int64_t n = (int64_t)B * 2 * H * 2 * W * C;
+  SP_LOOP(i, n) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % (2 * W)); r /= (2 * W);
+    const int oy = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    const int tap = (oy & 1) * 2 + (ox & 1);
+    const int64_t src = ((((int64_t)b * H + (oy >> 1)) * W + (ox >> 1)) * 4 + tap) * C + c;
+    st_any(y, i, dt, ld_any(g, src, dt) + (bias ? bias[c] : 0.f));
+  }
+}
+extern "C" int vg_pixel_shuffle2(const void* g, const float* bias, void* y, int B, int H, int W, int C, int dtype,
+                                 vg_stream_t stream) {
+  VG_CHECK(g && y && B > 0 && H > 0 && W > 0 && C > 0, VG_ERR_ARG, "vg_pixel_shuffle2: bad args");
+  pixel_shuffle2_kernel<<<sp_grid((int64_t)B * 4 * H * W * C), 256, 0, (hipStream_t)stream>>>(g, bias, y, B, H, W, C, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void pool2_kernel(const void* x, void* y, int B, int H, int W, int C, int64_t xps,
+                                                    int is_max, int dt) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  SP_LOOP(i, n) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const int64_t p00 = ((int64_t)b * H + 2 * oy) * W + 2 * ox;
+    const float v0 = ld_any(x, p00 * xps + c, dt), v1 = ld_any(x, (p00 + 1) * xps + c, dt);
+    const float v2 = ld_any(x, (p00 + W) * xps + c, dt), v3 = ld_any(x, (p00 + W + 1) * xps + c, dt);
+    const float o = is_max ? fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) : (v0 + v1 + v2 + v3) * 0.25f;
+    st_any(y, i, dt, o);
+  }
+}
+extern "C" int vg_pool2(const void* x, void* y, int B, int H, int W, int C, int64_t x_pix_stride, int is_max, int dtype,
+                        vg_stream_t stream) {
+  VG_CHECK(x && y && B > 0 && H > 1 && W > 1 && C > 0 && (H % 2 == 0) && (W % 2 == 0) && x_pix_stride >= C, VG_ERR_ARG,
+           "vg_pool2: bad args (H, W must be even)");
+  pool2_kernel<<<sp_grid((int64_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream>>>(x, y, B, H, W, C, x_pix_stride, is_max, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// windows: [B*nH*nW, ws*ws, C], window order (b, wy, wx), token order (r, c) row-major — the layout
+// window_partition(...).view(-1, ws*ws, C) produces (backbones/utils.py:16-38).
+__global__ __launch_bounds__(256) void window_part_kernel(const void* src_, void* dst_, int B, int H, int W, int C, int ws,
+                                                          int nH, int nW, int dt, int reverse) {
+  if (!reverse) {
+    const int64_t n = (int64_t)B * nH * nW * ws * ws * C;
+    SP_LOOP(i, n) {
+      const int c = (int)(i % C);
+      int64_t r = i / C;
+      const int cc = (int)(r % ws); r /= ws;
+      const int rr = (int)(r % ws); r /= ws;
+      const int wx = (int)(r % nW); r /= nW;
+      const int wy = (int)(r % nH);
+      const int b = (int)(r / nH);
+      const int yy = wy * ws + rr, xx = wx * ws + cc;
+      float v = 0.f;
+      if (yy < H && xx < W) v = ld_any(src_, (((int64_t)b * H + yy) * W + xx) * C + c, dt);
+      st_any(dst_, i, dt, v);
+    }
+  } else {
+    const int64_t n = (int64_t)B * H * W * C;
+    SP_LOOP(i, n) {
+      const int c = (int)(i % C);
+      int64_t r = i / C;
+      const int xx = (int)(r % W); r /= W;
+      const int yy = (int)(r % H);
+      const int b = (int)(r / H);
+      const int wy = yy / ws, rr = yy % ws, wx = xx / ws, cc = xx % ws;
+      const int64_t src = (((((int64_t)b * nH + wy) * nW + wx) * ws + rr) * ws + cc) * C + c;
+      st_any(dst_, i, dt, ld_any(src_, src, dt));
+    }
+  }
+}
+extern "C" int vg_window_partition(const void* x, void* win, int B, int H, int W, int C, int ws, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && win && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, VG_ERR_ARG, "vg_window_partition: bad args");
+  const int nH = (H + ws - 1) / ws, nW = (W + ws - 1) / ws;
+  window_part_kernel<<<sp_grid((int64_t)B * nH * nW * ws * ws * C), 256, 0, (hipStream_t)stream>>>(x, win, B, H, W, C, ws, nH, nW, dtype, 0);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+extern "C" int vg_window_unpartition(const void* win, void* x, int B, int H, int W, int C, int ws, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && win && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, VG_ERR_ARG, "vg_window_unpartition: bad args");
+  const int nH = (H + ws - 1) / ws, nW = (W + ws - 1) / ws;
+  window_part_kernel<<<sp_grid((int64_t)B * H * W * C), 256, 0, (hipStream_t)stream>>>(win, x, B, H, W, C, ws, nH, nW, dtype, 1);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// PyTorch upsample_bilinear2d, align_corners=False: src = max((dst+0.5)*scale-0.5, 0), scale = in/out.
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo) {
+  const int64_t n = (int64_t)N * Ho * Wo;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  SP_LOOP(i, n) {
+    const int ox = (int)(i % Wo);
+    int64_t r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float fy = ((float)oy + 0.5f) * sh - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = ((float)ox + 0.5f) * sw - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = in + (int64_t)b * Hi * Wi;
+    out[i] = hy * (hx * p[(int64_t)y0 * Wi + x0] + lx * p[(int64_t)y0 * Wi + x1]) +
+             ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
+  }
+}
+extern "C" int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream) {
+  VG_CHECK(in && out && N >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, VG_ERR_ARG, "vg_bilinear: bad args");
+  if (N == 0) return VG_OK;
+  bilinear_kernel<<<sp_grid((int64_t)N * Ho * Wo), 256, 0, (hipStream_t)stream>>>(in, out, N, Hi, Wi, Ho, Wo);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void upsample2_add_kernel(const void* lat, const void* top, void* y, int B, int H, int W,
+                                                            int C, int dt) {
+  const int64_t n = (int64_t)B * 2 * H * 2 * W * C;
+  SP_LOOP(i, n) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % (2 * W)); r /= (2 * W);
+    const int oy = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    const int64_t src = (((int64_t)b * H + (oy >> 1)) * W + (ox >> 1)) * C + c;
+    st_any(y, i, dt, ld_any(lat, i, dt) + ld_any(top, src, dt));
+  }
+}
+extern "C" int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C, int dtype,
+                                vg_stream_t stream) {
+  VG_CHECK(lateral && top && y && B > 0 && H > 0 && W > 0 && C > 0, VG_ERR_ARG, "vg_upsample2_add: bad args");
+  upsample2_add_kernel<<<sp_grid((int64_t)B * 4 * H * W * C), 256, 0, (hipStream_t)stream>>>(lateral, top, y, B, H, W, C, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

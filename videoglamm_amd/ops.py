@@ -1,0 +1,345 @@
+"""Host-side operator layer: torch tensors in, C-ABI calls (include/vg_kernels.h) out.
+
+PyTorch is used for device memory and streams only; every arithmetic op on the VideoGLaMM hot path
+goes through a hand-written gfx950 kernel in libvgkernels.so.  All tensors are token-major
+(channels last).  There is no CPU fallback: calling any op with a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _tdt(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.VGKernelError("VideoGLaMM ops run on the MI355X HIP kernels only; got a CPU tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous(), "bias/gamma/norm vectors are fp32 contiguous"
+    return t
+
+
+def _rows2d(x):
+    """View x[..., K] as 2-D [M, K] with a single row stride (no copy when possible)."""
+    K = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1:
+        return x, x.shape[0], x.stride(0) if x.shape[0] > 1 else max(x.stride(0), K)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    x2 = x.view(-1, K)
+    return x2, x2.shape[0], K
+
+
+def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None):
+    """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K)."""
+    lib = _lib.load()
+    x2, M, lda = _rows2d(x)
+    N, K = w.shape
+    assert x2.shape[1] == K, (x.shape, w.shape)
+    assert w.stride(1) == 1
+    odt = out_dtype if out_dtype is not None else x.dtype
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
+    o2, Mo, ldc = _rows2d(out)
+    assert Mo == M and out.dtype == odt
+    r2, ldr = None, 0
+    if residual is not None:
+        assert residual.dtype == odt
+        r2, Mr, ldr = _rows2d(residual)
+        assert Mr == M and r2.shape[1] == N
+    assert _dt(w) == _dt(x2)
+    rc = lib.vg_gemm(_p(x2), lda, 0, _p(w), w.stride(0), 0, _p(o2), ldc, 0, _p(_f32(bias)), _p(_f32(gamma)),
+                     _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, _stream())
+    _lib.check(rc, "vg_gemm")
+    return out
+
+
+def bmm_nt(a, w, out_dtype=None):
+    """c[b] = a[b] @ w[b]^T ; a: [B,M,K], w: [B,N,K] (or [N,K] shared) -> [B,M,N]."""
+    lib = _lib.load()
+    a = a.contiguous()
+    w = w.contiguous()
+    B, M, K = a.shape
+    N = w.shape[-2]
+    sW = 0 if w.dim() == 2 else N * K
+    odt = out_dtype if out_dtype is not None else a.dtype
+    out = torch.empty(B, M, N, dtype=odt, device=a.device)
+    rc = lib.vg_gemm(_p(a), K, M * K, _p(w), K, sW, _p(out), N, M * N, None, None, None, 0, 0, M, N, K, B,
+                     _dt(a), _dt(out), ACT_NONE, _stream())
+    _lib.check(rc, "vg_gemm(batched)")
+    return out
+
+
+def attention(q, k, v, scale, causal=False):
+    """q: [B,Sq,Hq,D], k/v: [B,Skv,Hkv,D] (arbitrary batch/token/head strides, D contiguous) -> [B,Sq,Hq,D]."""
+    lib = _lib.load()
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    out = torch.empty(B, Sq, Hq, D, dtype=q.dtype, device=q.device)
+    rc = lib.vg_attention(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
+                          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                          v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                          float(scale), int(bool(causal)), _dt(q), _stream())
+    _lib.check(rc, "vg_attention")
+    return out
+
+
+def layernorm(x, w, b, eps, out_dtype=None):
+    lib = _lib.load()
+    x2, M, ldx = _rows2d(x)
+    C = x2.shape[1]
+    out = torch.empty(*x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    rc = lib.vg_layernorm(_p(x2), ldx, _p(_f32(w)), _p(_f32(b)), _p(out), C, M, C, float(eps), _dt(x2), _dt(out), _stream())
+    _lib.check(rc, "vg_layernorm")
+    return out
+
+
+def rmsnorm(x, w, eps, out_dtype=None):
+    lib = _lib.load()
+    x2, M, ldx = _rows2d(x)
+    C = x2.shape[1]
+    out = torch.empty(*x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    rc = lib.vg_rmsnorm(_p(x2), ldx, _p(_f32(w)), _p(out), C, M, C, float(eps), _dt(x2), _dt(out), _stream())
+    _lib.check(rc, "vg_rmsnorm")
+    return out
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out_dtype=None):
+    """alpha*a + beta*b, b broadcast over the leading dims of a (b.numel() divides a.numel())."""
+    lib = _lib.load()
+    a = a.contiguous()
+    out = torch.empty(a.shape, dtype=out_dtype or a.dtype, device=a.device)
+    if b is None:
+        rc = lib.vg_axpby(_p(a), None, _p(out), a.numel(), float(alpha), float(beta), 1, _dt(a), F32, _dt(out), _stream())
+    else:
+        b = b.contiguous()
+        assert a.numel() % max(b.numel(), 1) == 0, (a.shape, b.shape)
+        rc = lib.vg_axpby(_p(a), _p(b), _p(out), a.numel(), float(alpha), float(beta), b.numel(), _dt(a), _dt(b),
+                          _dt(out), _stream())
+    _lib.check(rc, "vg_axpby")
+    return out
+
+
+def add(a, b):
+    return axpby(a, b, 1.0, 1.0)
+
+
+def activation(x, act, out_dtype=None):
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    _lib.check(lib.vg_activation(_p(x), _p(out), x.numel(), act, _dt(x), _dt(out), _stream()), "vg_activation")
+    return out
+
+
+def swiglu(gu):
+    lib = _lib.load()
+    gu = gu.contiguous()
+    Fh = gu.shape[-1] // 2
+    M = gu.numel() // (2 * Fh)
+    out = torch.empty(*gu.shape[:-1], Fh, dtype=gu.dtype, device=gu.device)
+    _lib.check(lib.vg_swiglu(_p(gu), _p(out), M, Fh, _dt(gu), _stream()), "vg_swiglu")
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(lib.vg_cast(_p(x), _p(out), x.numel(), _dt(x), _dt(out), _stream()), "vg_cast")
+    return out
+
+
+def where_rows(cond, a, b=None, fill=0.0):
+    """out[n,...] = cond[n] > 0 ? a[n,...] : (b broadcast | fill); cond fp32 [rows]."""
+    lib = _lib.load()
+    a = a.contiguous()
+    cond = cond.contiguous().view(-1)
+    rows = cond.numel()
+    inner = a.numel() // rows
+    out = torch.empty_like(a)
+    bp = 1
+    if b is not None:
+        b = b.contiguous()
+        assert b.dtype == a.dtype
+        bp = b.numel()
+    rc = lib.vg_where_rows(_p(_f32(cond)), _p(a), _p(b), _p(out), rows, inner, bp, float(fill), _dt(a), _stream())
+    _lib.check(rc, "vg_where_rows")
+    return out
+
+
+def mask_for_mem(x, binarize, scale, bias, out_dtype):
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rc = lib.vg_mask_for_mem(_p(x), _p(out), x.numel(), int(bool(binarize)), float(scale), float(bias), _dt(out), _stream())
+    _lib.check(rc, "vg_mask_for_mem")
+    return out
+
+
+def threshold(x):
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.vg_threshold(_p(x), _p(out), x.numel(), _stream()), "vg_threshold")
+    return out
+
+
+def rope_half_(x, cos, sin, pos0):
+    """in place; x: [S,H,D] view (head dim contiguous); cos/sin fp32 [max_pos, D/2]."""
+    lib = _lib.load()
+    S, H, D = x.shape
+    assert x.stride(2) == 1
+    rc = lib.vg_rope_half(_p(x), x.stride(0), x.stride(1), _p(_f32(cos)), _p(_f32(sin)), S, H, D, int(pos0), _dt(x), _stream())
+    _lib.check(rc, "vg_rope_half")
+    return x
+
+
+def rope_axial_(x, cos, sin, n_rope, n_grid):
+    """in place; x: [B,N,C] contiguous; cos/sin fp32 [n_grid, C/2]."""
+    lib = _lib.load()
+    assert x.is_contiguous()
+    B, N, C = x.shape
+    rc = lib.vg_rope_axial(_p(x), _p(_f32(cos)), _p(_f32(sin)), B, N, C, int(n_rope), int(n_grid), _dt(x), _stream())
+    _lib.check(rc, "vg_rope_axial")
+    return x
+
+
+def embed(ids, table):
+    lib = _lib.load()
+    ids = ids.contiguous().view(-1)
+    assert ids.dtype == torch.int64 and table.is_contiguous()
+    D = table.shape[1]
+    out = torch.empty(ids.numel(), D, dtype=table.dtype, device=table.device)
+    _lib.check(lib.vg_embed(_p(ids), _p(table), _p(out), ids.numel(), D, _dt(table), _stream()), "vg_embed")
+    return out
+
+
+def argmax(x):
+    lib = _lib.load()
+    x = x.contiguous()
+    n = x.shape[-1]
+    rows = x.numel() // n
+    out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    _lib.check(lib.vg_argmax(_p(x), rows, n, _p(out), _dt(x), _stream()), "vg_argmax")
+    return out
+
+
+def permute5(x, dims, strides):
+    """out (contiguous, shape dims[5]) gathered from x's storage at element strides[5]."""
+    lib = _lib.load()
+    out = torch.empty(*dims, dtype=x.dtype, device=x.device)
+    d = (ctypes.c_int64 * 5)(*dims)
+    s = (ctypes.c_int64 * 5)(*strides)
+    _lib.check(lib.vg_permute5(_p(x), _p(out), d, s, _dt(x), _stream()), "vg_permute5")
+    return out
+
+
+def im2col(x, kh, kw, stride, pad, kpad):
+    lib = _lib.load()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    out = torch.empty(B * Ho * Wo, kpad, dtype=x.dtype, device=x.device)
+    _lib.check(lib.vg_im2col(_p(x), _p(out), B, H, W, C, kh, kw, stride, pad, kpad, _dt(x), _stream()), "vg_im2col")
+    return out, Ho, Wo
+
+
+def dwconv(x, w, bias, k):
+    lib = _lib.load()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty_like(x)
+    _lib.check(lib.vg_dwconv(_p(x), _p(_f32(w)), _p(_f32(bias)), _p(out), B, H, W, C, k, _dt(x), _stream()), "vg_dwconv")
+    return out
+
+
+def pixel_shuffle2(g, bias, B, H, W, C):
+    """g: GEMM output [B*H*W, 4*C] (tap-major) -> [B, 2H, 2W, C] (+bias)."""
+    lib = _lib.load()
+    g = g.contiguous()
+    out = torch.empty(B, 2 * H, 2 * W, C, dtype=g.dtype, device=g.device)
+    _lib.check(lib.vg_pixel_shuffle2(_p(g), _p(_f32(bias)), _p(out), B, H, W, C, _dt(g), _stream()), "vg_pixel_shuffle2")
+    return out
+
+
+def pool2(x, is_max):
+    """x: [B,H,W,C] view whose pixel stride may exceed C (e.g. the q slice of a fused qkv) -> [B,H/2,W/2,C]."""
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * x.stride(1)
+    out = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+    _lib.check(lib.vg_pool2(_p(x), _p(out), B, H, W, C, x.stride(2), int(bool(is_max)), _dt(x), _stream()), "vg_pool2")
+    return out
+
+
+def window_partition(x, ws):
+    lib = _lib.load()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    nH, nW = -(-H // ws), -(-W // ws)
+    out = torch.empty(B * nH * nW, ws * ws, C, dtype=x.dtype, device=x.device)
+    _lib.check(lib.vg_window_partition(_p(x), _p(out), B, H, W, C, ws, _dt(x), _stream()), "vg_window_partition")
+    return out
+
+
+def window_unpartition(win, ws, B, H, W):
+    lib = _lib.load()
+    win = win.contiguous()
+    C = win.shape[-1]
+    out = torch.empty(B, H, W, C, dtype=win.dtype, device=win.device)
+    _lib.check(lib.vg_window_unpartition(_p(win), _p(out), B, H, W, C, ws, _dt(win), _stream()), "vg_window_unpartition")
+    return out
+
+
+def bilinear(x, Ho, Wo):
+    """x: fp32 [N,Hi,Wi] -> [N,Ho,Wo], align_corners=False."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    N, Hi, Wi = x.shape
+    out = torch.empty(N, Ho, Wo, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vg_bilinear(_p(x), _p(out), N, Hi, Wi, Ho, Wo, _stream()), "vg_bilinear")
+    return out
+
+
+def upsample2_add(lateral, top):
+    lib = _lib.load()
+    lateral = lateral.contiguous()
+    top = top.contiguous()
+    B, H, W, C = top.shape
+    out = torch.empty_like(lateral)
+    _lib.check(lib.vg_upsample2_add(_p(lateral), _p(top), _p(out), B, H, W, C, _dt(top), _stream()), "vg_upsample2_add")
+    return out
