@@ -23,7 +23,13 @@ def _mod(name, **attrs):
 
 
 def install():
-    import transformers  # noqa: F401  (must be imported before the stubs shadow anything)
+    # transformers (and its cached *_available() probes) must be fully imported BEFORE the stubs exist
+    import transformers  # noqa: F401
+    import transformers.generation  # noqa: F401
+    import transformers.models.clip.modeling_clip  # noqa: F401
+    import transformers.models.llama.modeling_llama  # noqa: F401
+    import transformers.models.phi3.modeling_phi3  # noqa: F401
+    from transformers import AutoConfig, AutoModelForCausalLM, CLIPImageProcessor  # noqa: F401
     import torch
 
     if "hydra" not in sys.modules:
@@ -58,8 +64,6 @@ def install():
         tvo = _mod("torchvision.ops")
         _mod("torchvision.ops.boxes", batched_nms=None, box_area=None)
         tv.transforms, tvt.functional, tv.ops = tvt, tvf, tvo
-        _mod("decord")
-        _mod("deepspeed")
 
     if R not in sys.path:
         sys.path.insert(0, R)

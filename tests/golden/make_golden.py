@@ -1,0 +1,321 @@
+"""Golden-vector generator.  RUN ONLY IN THE BUILD CONTAINER (needs /root/reference):
+
+    python tests/golden/make_golden.py [sam2|vlm|e2e|all]
+
+Imports the reference (recipe: _ref_import.py), loads the name-seeded synthetic weights of
+oracle/seeded.py into the reference's own nn.Modules, runs them on seeded inputs on CPU/fp32 and
+stores inputs' seeds + outputs as small .npz fixtures, plus the {name: shape} manifests the tests need
+to regenerate the same weights.  Only data is written; no reference source is copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_import as ri  # noqa: E402
+from oracle import seeded  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+# ---- the micro configurations shared with the tests (tests/golden/configs.py) --------------------
+from configs import CLIP_TINY, IV2_TINY, LLAMA_TINY, SAM2_E2E, SAM2_MICRO  # noqa: E402
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().float().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", path, {k: tuple(np.asarray(v).shape) for k, v in arrays.items()}, f"{os.path.getsize(path) / 1e3:.0f} kB")
+
+
+def load_seeded(module, seed, overrides=None, manifest_name=None):
+    sd0 = module.state_dict()
+    manifest = {k: list(v.shape) for k, v in sd0.items()}
+    sd = seeded.seeded_state_dict(manifest, seed, overrides)
+    module.load_state_dict({k: v.to(sd0[k].dtype) for k, v in sd.items()})
+    if manifest_name:
+        with open(os.path.join(HERE, manifest_name), "w") as f:
+            json.dump(manifest, f)
+        print("wrote", manifest_name, len(manifest), "tensors", sum(int(np.prod(s)) for s in manifest.values()), "params")
+    return sd
+
+
+def patch_predictor_device():
+    from model.segment_anything_2.sam2 import sam2_video_predictor as svp
+
+    orig = svp.SAM2VideoPredictor.init_state_from_tensor
+
+    def patched(self, *a, **k):  # hard-coded torch.device("cuda") at sam2_video_predictor.py:143-147
+        real = torch.device
+        try:
+            torch.device = lambda *aa, **kk: real("cpu")
+            return orig(self, *a, **k)
+        finally:
+            torch.device = real
+
+    if not getattr(svp.SAM2VideoPredictor, "_vg_patched", False):
+        svp.SAM2VideoPredictor.init_state_from_tensor = torch.inference_mode()(patched)
+        svp.SAM2VideoPredictor._vg_patched = True
+
+
+def build_ref_sam2(seed=1):
+    ri.install()
+    cfg = ri.sam2_model_cfg("sam2_hiera_l.yaml", True, trunk_override=SAM2_MICRO["trunk"],
+                            neck_channels=SAM2_MICRO["neck_channels"], image_size=SAM2_MICRO["image_size"])
+    m = ri.build_sam2(cfg)
+    patch_predictor_device()
+    load_seeded(m, seed, seeded.sam2_overrides(), "sam2_micro_manifest.json")
+    return m
+
+
+def gen_sam2():
+    m = build_ref_sam2()
+    S = SAM2_MICRO["image_size"]
+    T, N, H, W = 5, 2, 40, 56
+    images = rnd((T, 3, S, S), 11)
+    text = rnd((N, 256), 12, 0.5)
+    out = {}
+    # --- S1: forward_image (Hiera + FPN + conv_s0/s1)
+    bo = m.forward_image(images[0:1])
+    out["fpn0"], out["fpn1"], out["fpn2"] = bo["backbone_fpn"]
+    out["pos2"] = bo["vision_pos_enc"][2]
+    # --- S7/S8 framewise decode exactly as VideoGLaMM.inference_framewise does (R/model/VideoGLaMM.py:689-749)
+    sparse, dense = m.sam_prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.unsqueeze(1))
+    out["dense_pe"] = m.sam_prompt_encoder.get_dense_pe()
+    lows, fw = [], []
+    for t in range(T):
+        bo = m.forward_image(images[t:t + 1])
+        _, emb, _, _ = m._prepare_backbone_features(bo)
+        emb[-1] = emb[-1] + m.no_mem_embed
+        sizes = [(S // 4, S // 4), (S // 8, S // 8), (S // 16, S // 16)]
+        feats = [f.permute(1, 2, 0).view(1, -1, *s) for f, s in zip(emb[::-1], sizes[::-1])][::-1]
+        low, iou, _, _ = m.sam_mask_decoder(image_embeddings=feats[-1], image_pe=m.sam_prompt_encoder.get_dense_pe(),
+                                            sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                            multimask_output=False, repeat_image=True, high_res_features=feats[:-1])
+        lows.append(low)
+        fw.append(torch.nn.functional.interpolate(low.float(), (H, W), mode="bilinear", align_corners=False)[:, 0])
+    out["framewise_low"] = torch.stack(lows)
+    out["framewise_logits"] = torch.stack(fw)
+    # all-4-token decoder output on frame 0 (pre multimask selection)
+    masks4, iou4, tok4, obj = m.sam_mask_decoder.predict_masks(
+        image_embeddings=feats[-1], image_pe=m.sam_prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sparse,
+        dense_prompt_embeddings=dense, repeat_image=True, high_res_features=feats[:-1])
+    out["dec_masks4"], out["dec_iou4"], out["dec_tokens4"], out["dec_obj"] = masks4, iou4, tok4, obj
+    # --- video branch exactly as VideoGLaMM.inference_video_branch does (R/model/VideoGLaMM.py:844-877)
+    state = m.init_state_from_tensor(images, H, W)
+    m.reset_state(state)
+    feat = text.unsqueeze(1)
+    for k in range(N):
+        m.add_new_text(inference_state=state, frame_idx=0, obj_id=k, text=feat[k].unsqueeze(0))
+    vid = []
+    for fidx, obj_ids, logits in m.propagate_in_video(state):
+        vid.append(logits.clone())
+    out["video_logits"] = torch.stack(vid)
+    od = state["output_dict"]
+    out["video_low_res"] = torch.stack([od["cond_frame_outputs"][0]["pred_masks"]] + [od["non_cond_frame_outputs"][t]["pred_masks"] for t in range(1, T)])
+    out["video_obj_ptr"] = torch.stack([od["cond_frame_outputs"][0]["obj_ptr"]] + [od["non_cond_frame_outputs"][t]["obj_ptr"] for t in range(1, T)])
+    out["video_maskmem0"] = od["cond_frame_outputs"][0]["maskmem_features"].float()
+    out["video_maskmem1"] = od["non_cond_frame_outputs"][1]["maskmem_features"].float()
+    # --- S5 / S9 modules in isolation
+    hw = (S // 16) ** 2
+    curr, cpos = rnd((hw, N, 256), 21), rnd((hw, N, 256), 22)
+    mem, mpos = rnd((2 * hw + 8, N, 64), 23), rnd((2 * hw + 8, N, 64), 24)
+    out["memattn_out"] = m.memory_attention(curr=[curr], curr_pos=[cpos], memory=mem, memory_pos=mpos, num_obj_ptr_tokens=8)
+    pix, msk = rnd((N, 256, S // 16, S // 16), 25), rnd((N, 1, S, S), 26, 3.0)
+    mo = m.memory_encoder(pix, torch.sigmoid(msk) * 20 - 10, skip_mask_sigmoid=True)
+    out["memenc_feat"], out["memenc_pos"] = mo["vision_features"], mo["vision_pos_enc"][0]
+    save("sam2_micro.npz", meta=np.array([T, N, H, W]), **out)
+
+
+def gen_vlm():
+    ri.install()
+    from model.videogpt_plus.model.internvideo.internvideo2 import PretrainInternVideo2
+    from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaModel
+
+    out = {}
+    c = IV2_TINY
+    iv2 = PretrainInternVideo2(in_chans=3, img_size=c["img_size"], patch_size=c["patch_size"], embed_dim=c["embed_dim"], depth=c["depth"],
+                               num_heads=c["num_heads"], mlp_ratio=c["mlp_ratio"], clip_embed_dim=32, attn_pool_num_heads=4, qkv_bias=False,
+                               drop_path_rate=0.0, init_values=1e-5, qk_normalization=True, use_flash_attn=False, use_fused_rmsnorm=False,
+                               use_fused_mlp=False, num_frames=4, tubelet_size=1, sep_image_video_pos_embed=True, clip_teacher_embed_dim=32,
+                               clip_teacher_final_dim=16, clip_return_layer=1, clip_student_return_interval=1).eval()
+    load_seeded(iv2, 2, None, "iv2_tiny_manifest.json")
+    vid = rnd((2, 4, 3, c["img_size"], c["img_size"]), 31)
+    # InternVideo2_Stage2V.forward (internvideo/utils.py:229-238)
+    out["iv2_out"] = iv2(vid.permute(0, 2, 1, 3, 4), None, False, x_vis_return_idx=-2, x_vis_only=True)
+
+    c = CLIP_TINY
+    clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=c["hidden"], intermediate_size=c["mlp"], num_hidden_layers=c["num_layers"],
+                                            num_attention_heads=c["num_heads"], image_size=c["img_size"], patch_size=c["patch_size"],
+                                            hidden_act="quick_gelu", attn_implementation="eager")).eval()
+    load_seeded(clip, 3, None, "clip_tiny_manifest.json")
+    img = rnd((3, 3, c["img_size"], c["img_size"]), 32)
+    # CLIPVisionTower.forward/feature_select (clip_encoder.py:34-72)
+    out["clip_out"] = clip(img, output_hidden_states=True).hidden_states[-2][:, 1:]
+
+    c = LLAMA_TINY
+    llm = LlamaModel(LlamaConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["ffn"], num_hidden_layers=c["num_layers"],
+                                 num_attention_heads=c["num_heads"], num_key_value_heads=c["num_kv_heads"], rms_norm_eps=c["rms_eps"],
+                                 rope_theta=c["rope_theta"], max_position_embeddings=4096, attn_implementation="eager")).eval()
+    load_seeded(llm, 4, None, "llama_tiny_manifest.json")
+    emb = rnd((1, 45, c["hidden"]), 33)
+    out["llama_out"] = llm(inputs_embeds=emb).last_hidden_state[0]
+    save("vlm_tiny.npz", **out)
+
+
+def build_ref_e2e(use_video_branch):
+    """Compose VideoGLaMM_SAM2 with the Llama wrapper exactly the way R/model/VideoGLaMM.py:155-173,882-903
+    composes it with Phi-3 (the reference ships no Llama composition — SURVEY headline 3)."""
+    ri.install()
+    os.chdir(ri.R)
+    import model.VideoGLaMM as vg
+    from model.videogpt_plus.model.language_model.llama3_1 import (VideoGPTPlusLlamaConfig, VideoGPTPlusLlamaForCausalLM,
+                                                                    VideoGPTPlusLlamaModel)
+    from model.videogpt_plus.model.internvideo.internvideo2 import PretrainInternVideo2
+    from model.videogpt_plus.model.internvideo.utils import InternVideo2_Stage2V
+    from model.videogpt_plus.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from model.videogpt_plus.model.multimodal_projector.builder import build_vision_projector
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from configs import E2E
+
+    def micro_sam(*a, **k):
+        cfg = ri.sam2_model_cfg("sam2_hiera_l.yaml", use_video_branch, trunk_override=SAM2_E2E["trunk"],
+                                neck_channels=SAM2_E2E["neck_channels"], image_size=SAM2_E2E["image_size"])
+        if not use_video_branch:
+            cfg["_target_"] = "model.segment_anything_2.sam2.modeling.sam2_base.SAM2Base"
+        return ri.build_sam2(cfg)
+
+    patch_predictor_device()
+    vg.build_sam2 = micro_sam
+    vg.build_sam2_video_predictor = micro_sam
+
+    class VideoGLaMMLlamaModel(vg.VideoGLaMMMetaModel, VideoGPTPlusLlamaModel):
+        def __init__(self, config, **kwargs):
+            super().__init__(config, **kwargs)
+            self.config.use_cache = False
+            self.config.mm_vision_select_feature = "patch"
+
+    class VideoGLaMMLlamaForCausalLM(VideoGPTPlusLlamaForCausalLM, vg.VideoGLaMM_SAM2):
+        def __init__(self, config, **kwargs):
+            super(VideoGPTPlusLlamaForCausalLM, self).__init__(config)
+            self.model = VideoGLaMMLlamaModel(config, **kwargs)
+            self.lm_head = torch.nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+            self.post_init()
+
+        def forward(self, **kwargs):
+            if "past_key_values" in kwargs:
+                return VideoGPTPlusLlamaForCausalLM.forward(self, **kwargs)
+            return vg.VideoGLaMM_SAM2.model_forward(self, **kwargs)
+
+        def super_forward(self, **kwargs):
+            return VideoGPTPlusLlamaForCausalLM.forward(self, **kwargs)
+
+    c = E2E["llm"]
+    config = VideoGPTPlusLlamaConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["ffn"], num_hidden_layers=c["num_layers"],
+                                     num_attention_heads=c["num_heads"], num_key_value_heads=c["num_kv_heads"], rms_norm_eps=c["rms_eps"],
+                                     rope_theta=c["rope_theta"], max_position_embeddings=8192, attn_implementation="eager",
+                                     bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    config.mm_projector_type = "mlp2x_gelu"
+    config.image_mm_projector_type = "mlp2x_gelu"
+    m = VideoGLaMMLlamaForCausalLM(config, train_mask_decoder=False, out_dim=256, mask_decoder_itm=False, use_sam2=True,
+                                   use_sam2_video_branch=use_video_branch)
+    m.config.seg_token_idx = E2E["seg_token_idx"]
+    iv = E2E["iv2"]
+
+    class _IV2(torch.nn.Module):
+        forward = InternVideo2_Stage2V.forward
+        dtype = property(lambda self: self.vision_encoder.patch_embed.proj.weight.dtype)
+
+    tower = _IV2()
+    tower.vision_encoder = PretrainInternVideo2(in_chans=3, img_size=iv["img_size"], patch_size=iv["patch_size"], embed_dim=iv["embed_dim"],
+                                                depth=iv["depth"], num_heads=iv["num_heads"], mlp_ratio=iv["mlp_ratio"], clip_embed_dim=32,
+                                                attn_pool_num_heads=4, qkv_bias=False, drop_path_rate=0.0, init_values=1e-5, qk_normalization=True,
+                                                use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False, num_frames=4, tubelet_size=1,
+                                                sep_image_video_pos_embed=True, clip_teacher_embed_dim=32, clip_teacher_final_dim=16,
+                                                clip_return_layer=1, clip_student_return_interval=1)
+    cl = E2E["clip"]
+    ctower = CLIPVisionTower.__new__(CLIPVisionTower)
+    torch.nn.Module.__init__(ctower)
+    ctower.is_loaded, ctower.select_layer, ctower.select_feature = True, -2, "patch"
+    ctower.vision_tower = CLIPVisionModel(CLIPVisionConfig(hidden_size=cl["hidden"], intermediate_size=cl["mlp"], num_hidden_layers=cl["num_layers"],
+                                                           num_attention_heads=cl["num_heads"], image_size=cl["img_size"], patch_size=cl["patch_size"],
+                                                           hidden_act="quick_gelu", attn_implementation="eager"))
+    m.model.vision_tower = tower
+    m.model.image_vision_tower = ctower
+    m.model.mm_projector = build_vision_projector(config, image_mm_projector=False)
+    m.model.image_mm_projector = build_vision_projector(config, image_mm_projector=True)
+    m.eval()
+    return m
+
+
+def gen_e2e():
+    from configs import E2E
+
+    fixtures = {}
+    manifest_done = False
+    for branch in (False, True):
+        m = build_ref_e2e(branch)
+        sd0 = m.state_dict()
+        # drop the towers' unused heads from the manifest? keep everything: names are the checkpoint contract
+        ov = seeded.sam2_overrides("model.visual_model.")
+        load_seeded(m, 5, ov, None if manifest_done else "e2e_manifest.json")
+        manifest_done = True
+        # make the random LM emit [SEG] deterministically: large lm_head row norm for the seg token
+        te, S = E2E["te"], SAM2_E2E["image_size"]
+        T, H, W = E2E["t_sam"], 40, 56
+        images = rnd((te, 3, 224, 224), 41)
+        context = rnd((te, 3, 336, 336), 42)
+        sam = rnd((T, 3, S, S), 43)
+        g = torch.Generator().manual_seed(44)
+        ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, E2E["llm"]["vocab"], (12,), generator=g)])[None]
+        # Version-skew guard (transformers 5.x here vs the reference's pinned 4.41): after the first outer
+        # forward with output_hidden_states=True, 5.x records every CLIP layer output twice, so
+        # hidden_states[-2] silently becomes the LAST layer.  Evaluate the reference's CLIPVisionTower once
+        # while the 4.41 semantics still hold (3 entries for 2 layers) and pin its forward to that result.
+        ctower = m.get_model().get_image_vision_tower()
+        assert len(ctower.vision_tower(context[:1], output_hidden_states=True).hidden_states) == E2E["clip"]["num_layers"] + 1
+        clip_feats = ctower(context, select_feature="patch")
+        ctower.forward = lambda imgs, select_feature="patch", batch_size=128: clip_feats if imgs.shape == context.shape else (_ for _ in ()).throw(RuntimeError("unexpected CLIP input"))
+        with torch.no_grad():
+            # a random LM never emits token 300: pick as [SEG] a token it DOES emit (SURVEY §8c gotcha);
+            # the choice is recorded in the fixture so the tests use the same index
+            probe = m.generate(images=[images], context_images=[context], input_ids=ids, max_new_tokens=E2E["max_new_tokens"],
+                               num_beams=1, use_cache=False)
+            gen = probe[0, ids.shape[1]:].tolist()
+            seg_idx = gen[1]
+            m.config.seg_token_idx = seg_idx
+            fixtures["seg_token_idx"] = np.array(seg_idx)
+            print("generated", gen, "-> seg_token_idx", seg_idx)
+            out_ids, segs = m.inference(images=[images], context_images=[context], images_for_sam=[sam], input_ids=ids,
+                                        resize_list=[(S, S)], original_size_list=[(H, W)], max_new_tokens=E2E["max_new_tokens"],
+                                        use_sam2_video_branch=branch)
+        key = "video" if branch else "framewise"
+        fixtures[f"{key}_output_ids"] = out_ids[0].numpy()
+        seg = segs[0]
+        frames = sorted(seg.keys())
+        objs = sorted(seg[frames[0]].keys()) if frames else []
+        fixtures[f"{key}_masks"] = np.stack([np.stack([seg[t][k] for k in objs]) for t in frames]) if frames else np.zeros((0,))
+        print(key, "output_ids", out_ids[0].tolist(), "n_seg", len(objs), "mask px", [int(seg[t][k].sum()) for t in frames for k in objs][:8])
+        fixtures["input_ids"] = ids[0].numpy()
+    save("e2e_tiny.npz", **fixtures)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("sam2", "all"):
+        gen_sam2()
+    if what in ("vlm", "all"):
+        gen_vlm()
+    if what in ("e2e", "all"):
+        gen_e2e()

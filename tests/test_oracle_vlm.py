@@ -1,0 +1,36 @@
+"""The LLM-side oracle (oracle/vlm.py) vs outputs of the reference's InternVideo2 and of HF
+CLIPVisionModel / LlamaModel (the third-party arithmetic the reference calls), tests/golden/vlm_tiny.npz."""
+import torch
+
+import _golden as G
+from oracle import vlm as O
+
+torch.set_grad_enabled(False)
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def setup_module(m):
+    m.fx = G.fixture("vlm_tiny.npz")
+
+
+def test_internvideo2():
+    c = G.configs.IV2_TINY
+    sd = G.weights("iv2_tiny_manifest.json", 2)
+    cfg = dict(depth=c["depth"], num_heads=c["num_heads"], patch_size=c["patch_size"])
+    out = O.iv2_forward(sd, "", cfg, G.rnd((2, 4, 3, c["img_size"], c["img_size"]), 31))
+    torch.testing.assert_close(out, fx["iv2_out"], **TOL)
+
+
+def test_clip():
+    c = G.configs.CLIP_TINY
+    sd = G.weights("clip_tiny_manifest.json", 3)
+    cfg = dict(num_heads=c["num_heads"], num_layers=c["num_layers"], patch_size=c["patch_size"])
+    out = O.clip_forward(sd, "", cfg, G.rnd((3, 3, c["img_size"], c["img_size"]), 32))
+    torch.testing.assert_close(out, fx["clip_out"], **TOL)
+
+
+def test_llama():
+    c = G.configs.LLAMA_TINY
+    sd = G.weights("llama_tiny_manifest.json", 4)
+    out = O.llama_forward(sd, "", c | dict(num_layers=c["num_layers"]), G.rnd((1, 45, c["hidden"]), 33)[0])
+    torch.testing.assert_close(out, fx["llama_out"], **TOL)
