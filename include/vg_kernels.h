@@ -126,6 +126,14 @@ int vg_embed(const int64_t* ids, const void* table, void* out, int64_t n, int D,
 /* out[r] = first index of the row maximum (torch.argmax)  x:[rows,n] */
 int vg_argmax(const void* x, int64_t rows, int n, int64_t* out, int dtype, vg_stream_t stream);
 
+/* SAM2 mask selection, one call per decoder batch: masks fp32 [N,4,HW], ious fp32 [N,4], tokens [N,4,C].
+ * mode 0: dynamic multimask via stability (R/.../sam/mask_decoder.py:247-295), token 0 returned;
+ * mode 1: best predicted IoU among tokens 1..3 (R/.../sam2_base.py:376-386), that token returned.
+ * out_mask [N,HW] fp32, out_iou [N] fp32, out_token [N,C] (may be NULL), out_idx [N] int32 (may be NULL). */
+int vg_multimask_select(const float* masks, const float* ious, const void* tokens, float* out_mask,
+                        float* out_iou, void* out_token, int* out_idx, int N, int64_t HW, int C, float delta,
+                        float thresh, int mode, int token_dtype, vg_stream_t stream);
+
 /* ---- spatial / layout (all NHWC) ---------------------------------------------------------------- */
 /* 5-D gather copy: out (contiguous, dims n0..n4) = in at element strides s0..s4 */
 int vg_permute5(const void* in, void* out, const int64_t dims[5], const int64_t strides[5], int dtype,

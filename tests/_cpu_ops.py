@@ -152,6 +152,22 @@ def argmax(x):
     return torch.argmax(x.float(), dim=-1)
 
 
+def multimask_select(masks, ious, tokens, mode, delta=0.05, thresh=0.98):
+    N = masks.shape[0]
+    bi = torch.arange(N)
+    best = torch.argmax(ious[:, 1:], dim=-1) + 1
+    if mode == 0:
+        fl = masks[:, 0].flatten(1)
+        ai, au = (fl > delta).sum(-1).float(), (fl > -delta).sum(-1).float()
+        stab = torch.where(au > 0, ai / au, torch.ones_like(au))
+        sel = torch.where(stab >= thresh, torch.zeros_like(best), best)
+        tok = tokens[:, 0]
+    else:
+        sel = best
+        tok = tokens[bi, sel]
+    return masks[bi, sel].unsqueeze(1).contiguous(), ious[bi, sel], tok.contiguous(), sel.to(torch.int32)
+
+
 def permute5(x, dims, strides):
     return torch.as_strided(x, dims, strides).contiguous()
 

@@ -25,3 +25,16 @@ def cuda():
     ncu = lib.vg_init(0)
     assert ncu > 0, lib.vg_last_error()
     return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def cpu_ops(monkeypatch):
+    """Swap the HIP operator layer for the plain-PyTorch statements (tests/_cpu_ops.py) so the host-side graph
+    code can be exercised without a GPU.  Test-only: the product never falls back."""
+    import _cpu_ops
+    from videoglamm_amd import ops
+
+    for name in _cpu_ops.ALL:
+        if hasattr(ops, name):
+            monkeypatch.setattr(ops, name, getattr(_cpu_ops, name))
+    return ops

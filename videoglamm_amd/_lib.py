@@ -38,6 +38,7 @@ def _sig(lib):
         "vg_rope_axial": ([P, P, P, I, I, I, I, I, I, P], c_int),
         "vg_embed": ([P, P, P, L, I, I, P], c_int),
         "vg_argmax": ([P, L, I, P, I, P], c_int),
+        "vg_multimask_select": ([P, P, P, P, P, P, P, I, L, I, F, F, I, I, P], c_int),
         "vg_permute5": ([P, P, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), I, P], c_int),
         "vg_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, P], c_int),
         "vg_dwconv": ([P, P, P, P, I, I, I, I, I, I, P], c_int),

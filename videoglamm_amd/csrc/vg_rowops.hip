@@ -105,3 +105,62 @@ extern "C" int vg_argmax(const void* x, int64_t rows, int n, int64_t* out, int d
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// Mask selection after the SAM2 mask decoder (one 256-thread workgroup per object).
+//   mode 0 (multimask_output=False): dynamic multimask via stability — keep mask 0 when its stability
+//          score |{m>delta}| / |{m>-delta}| >= thresh, else the best-IoU mask of tokens 1..3
+//          (sam/mask_decoder.py:247-295); token out = token 0.
+//   mode 1 (multimask_output=True): best-IoU of tokens 1..3 (sam2_base.py:376-386); token out = that token.
+__global__ __launch_bounds__(256) void multimask_select_kernel(const float* __restrict__ masks, const float* __restrict__ ious,
+                                                               const void* __restrict__ tokens, float* __restrict__ out_mask,
+                                                               float* __restrict__ out_iou, void* __restrict__ out_token,
+                                                               int* __restrict__ out_idx, int64_t HW, int C, float delta,
+                                                               float thresh, int mode, int tok_dt) {
+  __shared__ float s_i[4], s_u[4];
+  __shared__ int s_sel;
+  const int n = blockIdx.x;
+  const float* m = masks + (int64_t)n * 4 * HW;
+  const float* io = ious + n * 4;
+  int best = 1;
+  for (int k = 2; k < 4; ++k) if (io[k] > io[best]) best = k;  // argmax, first max wins
+  int sel = best;
+  if (mode == 0) {
+    float ai = 0.f, au = 0.f;
+    for (int64_t i = threadIdx.x; i < HW; i += 256) {
+      const float v = m[i];
+      ai += v > delta ? 1.f : 0.f;
+      au += v > -delta ? 1.f : 0.f;
+    }
+    ai = wave_sum(ai); au = wave_sum(au);
+    if ((threadIdx.x & 63) == 0) { s_i[threadIdx.x >> 6] = ai; s_u[threadIdx.x >> 6] = au; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float ti = s_i[0] + s_i[1] + s_i[2] + s_i[3], tu = s_u[0] + s_u[1] + s_u[2] + s_u[3];
+      const float stab = tu > 0.f ? ti / tu : 1.0f;
+      s_sel = stab >= thresh ? 0 : best;
+    }
+    __syncthreads();
+    sel = s_sel;
+  }
+  const float* src = m + (int64_t)sel * HW;
+  for (int64_t i = threadIdx.x; i < HW; i += 256) out_mask[(int64_t)n * HW + i] = src[i];
+  const int tsel = mode == 0 ? 0 : sel;
+  if (tokens && out_token)
+    for (int c = threadIdx.x; c < C; c += 256)
+      st_any(out_token, (int64_t)n * C + c, tok_dt, ld_any(tokens, ((int64_t)n * 4 + tsel) * C + c, tok_dt));
+  if (threadIdx.x == 0) {
+    out_iou[n] = io[sel];
+    if (out_idx) out_idx[n] = sel;
+  }
+}
+
+extern "C" int vg_multimask_select(const float* masks, const float* ious, const void* tokens, float* out_mask,
+                                   float* out_iou, void* out_token, int* out_idx, int N, int64_t HW, int C, float delta,
+                                   float thresh, int mode, int token_dtype, vg_stream_t stream) {
+  VG_CHECK(masks && ious && out_mask && out_iou && N >= 0 && HW > 0, VG_ERR_ARG, "vg_multimask_select: bad args");
+  if (N == 0) return VG_OK;
+  multimask_select_kernel<<<dim3(N), 256, 0, (hipStream_t)stream>>>(masks, ious, tokens, out_mask, out_iou, out_token, out_idx,
+                                                                     HW, C, delta, thresh, mode, token_dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -256,6 +256,23 @@ def argmax(x):
     return out
 
 
+def multimask_select(masks, ious, tokens, mode, delta=0.05, thresh=0.98):
+    """masks fp32 [N,4,h,w], ious fp32 [N,4], tokens [N,4,C] -> (mask [N,1,h,w] fp32, iou [N], token [N,C], idx [N] int32)."""
+    lib = _lib.load()
+    masks, ious, tokens = masks.contiguous(), ious.contiguous(), tokens.contiguous()
+    assert masks.dtype == torch.float32 and ious.dtype == torch.float32
+    N, _, h, w = masks.shape
+    C = tokens.shape[-1]
+    om = torch.empty(N, 1, h, w, dtype=torch.float32, device=masks.device)
+    oi = torch.empty(N, dtype=torch.float32, device=masks.device)
+    ot = torch.empty(N, C, dtype=tokens.dtype, device=masks.device)
+    ox = torch.empty(N, dtype=torch.int32, device=masks.device)
+    rc = lib.vg_multimask_select(_p(masks), _p(ious), _p(tokens), _p(om), _p(oi), _p(ot), _p(ox), N, h * w, C,
+                                 float(delta), float(thresh), int(mode), _dt(tokens), _stream())
+    _lib.check(rc, "vg_multimask_select")
+    return om, oi, ot, ox
+
+
 def permute5(x, dims, strides):
     """out (contiguous, shape dims[5]) gathered from x's storage at element strides[5]."""
     lib = _lib.load()

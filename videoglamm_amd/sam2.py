@@ -1,0 +1,404 @@
+"""SAM2 promptable pixel decoder on the MI355X kernel library (rows S1–S11 of SURVEY.md §8a).
+
+Host-side graph only: every arithmetic step is a C-ABI kernel call through ``ops``; torch is used for
+device allocation, views, concatenation and indexing.  Layout is channels-last everywhere
+([B,H,W,C] == [B, tokens, C]), so 1x1 convs / LayerNorm2d / FPN laterals are plain row GEMMs / row norms
+and the reference's NCHW<->(HW)NC permutes (R/.../sam2/modeling/sam2_base.py:479-493) disappear.
+R/ = /root/reference/VideoGLaMM/model/segment_anything_2/sam2/.
+"""
+import math
+
+import torch
+
+from . import ops
+
+NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
+
+
+def hiera_layout(cfg):
+    """(dim, dim_out, heads, window, q_stride) per block — R/modeling/backbones/hieradet.py:196-259."""
+    stages, window_spec = cfg["stages"], cfg["window_spec"]
+    stage_ends = [sum(stages[:i]) - 1 for i in range(1, len(stages) + 1)]
+    q_pool_blocks = [x + 1 for x in stage_ends[:-1]][: cfg.get("q_pool", 3)]
+    dim, heads, cur = cfg["embed_dim"], cfg["num_heads"], 1
+    blocks = []
+    for i in range(sum(stages)):
+        dim_out, window = dim, window_spec[cur - 1]
+        if i in cfg["global_att_blocks"]:
+            window = 0
+        if i - 1 in stage_ends:
+            dim_out, heads, cur = dim * 2, heads * 2, cur + 1
+        blocks.append(dict(dim=dim, dim_out=dim_out, heads=heads, window=window, q_stride=2 if i in q_pool_blocks else 0))
+        dim = dim_out
+    return blocks, stage_ends
+
+
+def _sine_pos(num_pos_feats, h, w, temperature=10000.0):
+    """PositionEmbeddingSine (normalize=True) as an [h*w, C] table — R/modeling/position_encoding.py:78-111."""
+    npf = num_pos_feats // 2
+    y = torch.arange(1, h + 1, dtype=torch.float32).view(-1, 1).repeat(1, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32).view(1, -1).repeat(h, 1)
+    y = y / (y[-1:, :] + 1e-6) * (2 * math.pi)
+    x = x / (x[:, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = temperature ** (2 * (torch.arange(npf, dtype=torch.float32) // 2) / npf)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, num_pos_feats)
+
+
+def _axial_cos_sin(dim, side, theta=10000.0):
+    """compute_axial_cis as cos/sin tables [side*side, dim/2] — R/modeling/position_encoding.py:174-191."""
+    fx = 1.0 / (theta ** (torch.arange(0, dim, 4)[: dim // 4].float() / dim))
+    t = torch.arange(side * side, dtype=torch.float32)
+    tx, ty = (t % side).float(), torch.div(t, side, rounding_mode="floor").float()
+    ang = torch.cat([torch.outer(tx, fx), torch.outer(ty, fx)], dim=-1)
+    return ang.cos(), ang.sin()
+
+
+class SAM2:
+    def __init__(self, params, prefix, cfg):
+        """params: Params over the checkpoint; prefix: e.g. "model.visual_model."; cfg: {image_size, trunk{...}}."""
+        self.P, self.p, self.cfg = params, prefix, cfg
+        self.dtype, self.device = params.dtype, params.device
+        self.S = cfg["image_size"]
+        self.es = self.S // 16
+        self.blocks, self.stage_ends = hiera_layout(cfg["trunk"])
+
+    # ------------------------------------------------------------------ small helpers
+    def lin(self, name, x, **kw):
+        return ops.linear(x, self.P.w(self.p + name), self.P.b(self.p + name), **kw)
+
+    def ln(self, name, x, eps=1e-5, **kw):
+        return ops.layernorm(x, self.P.f32(self.p + name + ".weight"), self.P.f32(self.p + name + ".bias"), eps, **kw)
+
+    def mlp(self, name, x, n, act=ops.ACT_RELU, sigmoid_output=False, out_dtype=None):
+        """R/modeling/sam2_utils.py:108-132."""
+        for i in range(n):
+            last = i == n - 1
+            x = self.lin(f"{name}.layers.{i}", x, act=(ops.ACT_SIGMOID if (last and sigmoid_output) else (ops.ACT_NONE if last else act)),
+                         out_dtype=out_dtype if last else None)
+        return x
+
+    # ------------------------------------------------------------------ S1 Hiera + FPN
+    def _hiera_pos(self, h, w):
+        def make():
+            sd, p = self.P.sd, self.p + "image_encoder.trunk."
+            pe = torch.nn.functional.interpolate(sd[p + "pos_embed"].float(), size=(h, w), mode="bicubic")
+            we = sd[p + "pos_embed_window"].float()
+            pe = pe + we.tile([x // y for x, y in zip(pe.shape, we.shape)])
+            return pe.permute(0, 2, 3, 1).reshape(h * w, -1)
+        return self.P.const(("hiera_pos", h, w), make)
+
+    def _hiera_block(self, i, blk, x):
+        """MultiScaleBlock — R/modeling/backbones/hieradet.py:37-168.  x: [B,H,W,C]."""
+        p = f"image_encoder.trunk.blocks.{i}."
+        B, H, W, _ = x.shape
+        do, nh = blk["dim_out"], blk["heads"]
+        hd = do // nh
+        xn = self.ln(p + "norm1", x, 1e-6)
+        shortcut = x
+        if blk["dim"] != do:
+            shortcut = self.lin(p + "proj", xn)
+            if blk["q_stride"]:
+                shortcut = ops.pool2(shortcut, True)
+        ws = blk["window"]
+        if ws > 0:
+            xw = ops.window_partition(xn, ws)           # [Bw, ws*ws, C]
+            h = w = ws
+        else:
+            xw, h, w = xn.view(B, H * W, -1), H, W
+        Bw = xw.shape[0]
+        qkv = self.lin(p + "attn.qkv", xw).view(Bw, h * w, 3, nh, hd)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        if blk["q_stride"]:
+            q = ops.pool2(q.reshape(Bw, h, w, do) if q.is_contiguous() else qkv.view(Bw, h, w, 3 * do)[..., :do], True)
+            h, w = h // 2, w // 2
+            q = q.view(Bw, h * w, nh, hd)
+        o = ops.attention(q, k, v, hd ** -0.5).view(Bw, h * w, do)
+        Hs, Ws = shortcut.shape[1:3]
+        if ws > 0:
+            o = self.lin(p + "attn.proj", o)
+            wse = ws // 2 if blk["q_stride"] else ws
+            x = ops.add(shortcut, ops.window_unpartition(o, wse, B, Hs, Ws))
+        else:
+            x = self.lin(p + "attn.proj", o, residual=shortcut.view(B, Hs * Ws, do)).view(B, Hs, Ws, do)
+        hmid = self.lin(p + "mlp.layers.0", self.ln(p + "norm2", x, 1e-6), act=ops.ACT_GELU)
+        return self.lin(p + "mlp.layers.1", hmid, residual=x)
+
+    def forward_image(self, img):
+        """SAM2Base.forward_image (Hiera + FpnNeck scalp=1 + conv_s0/s1) — R/modeling/sam2_base.py:465-477,
+        backbones/image_encoder.py:29-42,101-133.  img: [B,3,S,S] (any float dtype, NCHW like the reference's
+        preprocessing emits) -> fpn = [[B,S/4,S/4,32], [B,S/8,S/8,64], [B,S/16,S/16,256]] channels-last."""
+        B, _, H, W = img.shape
+        x = ops.permute5(img.contiguous(), (B, H, W, 3, 1), (3 * H * W, W, 1, H * W, 0)).view(B, H, W, 3)
+        x = ops.cast(x, self.dtype)
+        t = self.p + "image_encoder.trunk."
+        C0 = self.cfg["trunk"]["embed_dim"]
+        wpe = self.P.conv_w(t + "patch_embed.proj")
+        cols, Ho, Wo = ops.im2col(x, 7, 7, 4, 3, wpe.shape[1])
+        x = ops.linear(cols, wpe, self.P.b(t + "patch_embed.proj")).view(B, Ho, Wo, C0)
+        x = ops.add(x, self._hiera_pos(Ho, Wo))
+        feats = []
+        for i, blk in enumerate(self.blocks):
+            x = self._hiera_block(i, blk, x)
+            if i in self.stage_ends:
+                feats.append(x)
+        n = len(feats) - 1
+        out, prev = [None] * len(feats), None
+        for i in range(n, -1, -1):
+            lat = self.lin(f"image_encoder.neck.convs.{n - i}.conv", feats[i])
+            prev = ops.upsample2_add(lat, prev) if (i in (2, 3) and prev is not None) else lat
+            out[i] = prev
+        out = out[:-1]
+        out[0] = self.lin("sam_mask_decoder.conv_s0", out[0])
+        out[1] = self.lin("sam_mask_decoder.conv_s1", out[1])
+        return out
+
+    def vision_pos(self):
+        """vision_pos_enc of the top level as [es*es, 256] (constant)."""
+        return self.P.const(("vision_pos", self.es), lambda: _sine_pos(256, self.es, self.es))
+
+    # ------------------------------------------------------------------ S3 prompt encoder
+    def dense_pe(self):
+        """PromptEncoder.get_dense_pe as [es*es, 256] — R/modeling/sam/prompt_encoder.py:68-77,216-228 (constant)."""
+        def make():
+            g = self.P.sd[self.p + "sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
+            grid = torch.ones((self.es, self.es))
+            y, x = (grid.cumsum(0) - 0.5) / self.es, (grid.cumsum(1) - 0.5) / self.es
+            c = 2 * math.pi * ((2 * torch.stack([x, y], dim=-1) - 1) @ g)
+            return torch.cat([c.sin(), c.cos()], dim=-1).reshape(self.es * self.es, 256)
+        return self.P.const("dense_pe", make)
+
+    def sparse_prompt(self, n, text_embeds, with_empty_point):
+        """PromptEncoder.forward sparse part — prompt_encoder.py:143-189 (+ sam2_base.py:310-313 padding points)."""
+        parts = []
+        if with_empty_point:
+            nap = self.P.t(self.p + "sam_prompt_encoder.not_a_point_embed.weight")
+            parts.append(nap.view(1, 1, 256).expand(n, 2, 256))
+        if text_embeds is not None:
+            parts.append(ops.cast(text_embeds, self.dtype))
+        return torch.cat(parts, dim=1).contiguous()
+
+    # ------------------------------------------------------------------ S7/S8 mask decoder
+    def _attn(self, name, q, k, v, heads, residual=None):
+        """sam/transformer.py Attention.forward :236-260 (+ the caller's residual add fused into out_proj)."""
+        q, k, v = self.lin(name + ".q_proj", q), self.lin(name + ".k_proj", k), self.lin(name + ".v_proj", v)
+        B, nq, c = q.shape
+        hd = c // heads
+        o = ops.attention(q.view(B, nq, heads, hd), k.view(B, -1, heads, hd), v.view(B, -1, heads, hd), hd ** -0.5)
+        return self.lin(name + ".out_proj", o.view(B, nq, c), residual=residual)
+
+    def _two_way(self, src, tokens):
+        """TwoWayTransformer — R/modeling/sam/transformer.py:69-115,160-193.  src [N,HW,256], tokens [N,nt,256]."""
+        t = "sam_mask_decoder.transformer."
+        key_pe = self.dense_pe()
+        queries, keys, query_pe = tokens, src, tokens
+        for i in range(2):
+            l = f"{t}layers.{i}."
+            if i == 0:
+                queries = self._attn(l + "self_attn", queries, queries, queries, 8)
+            else:
+                q = ops.add(queries, query_pe)
+                queries = self._attn(l + "self_attn", q, q, queries, 8, residual=queries)
+            queries = self.ln(l + "norm1", queries)
+            q, k = ops.add(queries, query_pe), ops.add(keys, key_pe)
+            queries = self.ln(l + "norm2", self._attn(l + "cross_attn_token_to_image", q, k, keys, 8, residual=queries))
+            h = self.lin(l + "mlp.layers.0", queries, act=ops.ACT_RELU)
+            queries = self.ln(l + "norm3", self.lin(l + "mlp.layers.1", h, residual=queries))
+            q = ops.add(queries, query_pe)
+            keys = self.ln(l + "norm4", self._attn(l + "cross_attn_image_to_token", k, q, queries, 8, residual=keys))
+        q, k = ops.add(queries, query_pe), ops.add(keys, key_pe)
+        queries = self.ln(t + "norm_final_attn", self._attn(t + "final_attn_token_to_image", q, k, keys, 8, residual=queries))
+        return queries, keys
+
+    def mask_decoder(self, image_embed, sparse, high_res, repeat_image):
+        """MaskDecoder.predict_masks — R/modeling/sam/mask_decoder.py:168-245.
+        image_embed [Bi,HW,256] (Bi = 1 when repeat_image else N), sparse [N,ns,256],
+        high_res = (s0 [Bi,(4es)^2,32], s1 [Bi,(2es)^2,64]).
+        -> masks fp32 [N,4,4es,4es], iou fp32 [N,4], mask tokens [N,4,256], object score logits fp32 [N,1]."""
+        d = "sam_mask_decoder."
+        N, es = sparse.shape[0], self.es
+        out_tokens = torch.cat([self.P.t(self.p + d + "obj_score_token.weight"), self.P.t(self.p + d + "iou_token.weight"),
+                                self.P.t(self.p + d + "mask_tokens.weight")], dim=0)
+        tokens = torch.cat([out_tokens.unsqueeze(0).expand(N, -1, -1), sparse], dim=1).contiguous()
+        no_mask = self.P.t(self.p + "sam_prompt_encoder.no_mask_embed.weight").view(-1)
+        src = ops.add(image_embed, no_mask)  # dense prompt = no_mask_embed broadcast (prompt_encoder.py:183-187)
+        if repeat_image and N > 1:
+            src = ops.permute5(src, (N, es * es, 256, 1, 1), (0, 256, 1, 0, 0)).view(N, es * es, 256)
+        hs, src = self._two_way(src.view(N, es * es, 256), tokens)
+        iou_tok, mask_toks = hs[:, 1, :], hs[:, 2:6, :]
+        s0, s1 = high_res
+        g = ops.linear(src, self.P.convT_w(self.p + d + "output_upscaling.0"))
+        up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.0"), N, es, es, 64)
+        up = ops.add(up, s1)
+        up = ops.activation(self.ln(d + "output_upscaling.1", up, 1e-6), ops.ACT_GELU)
+        g = ops.linear(up, self.P.convT_w(self.p + d + "output_upscaling.3"))
+        up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.3"), N, 2 * es, 2 * es, 32)
+        up = ops.activation(ops.add(up, s0), ops.ACT_GELU)                       # [N,4es,4es,32]
+        hyper = torch.stack([self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :].contiguous(), 3) for i in range(4)], dim=1)
+        masks = ops.bmm_nt(hyper, up.view(N, 16 * es * es, 32), out_dtype=torch.float32).view(N, 4, 4 * es, 4 * es)
+        iou = self.mlp(d + "iou_prediction_head", iou_tok.contiguous(), 3, sigmoid_output=True, out_dtype=torch.float32)
+        obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :].contiguous(), 3, out_dtype=torch.float32)
+        return masks, iou, mask_toks.contiguous(), obj
+
+    # ------------------------------------------------------------------ S5 memory attention
+    def _rope_attn(self, name, q_in, k_in, v_in, n_exclude, residual):
+        """RoPEAttention.forward (1 head) — R/modeling/sam/transformer.py:289-327."""
+        q, k, v = self.lin(name + ".q_proj", q_in), self.lin(name + ".k_proj", k_in), self.lin(name + ".v_proj", v_in)
+        B, nq, c = q.shape
+        cos, sin = self.P.const(("axial_cos", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[0], torch.float32), \
+            self.P.const(("axial_sin", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[1], torch.float32)
+        ops.rope_axial_(q, cos, sin, nq, nq)
+        ops.rope_axial_(k, cos, sin, k.shape[1] - n_exclude, nq)
+        o = ops.attention(q.view(B, nq, 1, c), k.view(B, -1, 1, c), v.view(B, -1, 1, c), c ** -0.5)
+        return self.lin(name + ".out_proj", o.view(B, nq, c), residual=residual)
+
+    def memory_attention(self, curr, memory, memory_pos, num_obj_ptr_tokens):
+        """MemoryAttention.forward — R/modeling/memory_attention.py:119-169,60-99 (batch-first throughout).
+        curr [N,HW,256]; memory, memory_pos [N,M,64] -> [N,HW,256]."""
+        m = "memory_attention."
+        out = ops.axpby(curr, self.vision_pos(), 1.0, 0.1)
+        mem_k = ops.add(memory, memory_pos)
+        for i in range(4):
+            l = f"{m}layers.{i}."
+            t2 = self.ln(l + "norm1", out)
+            out = self._rope_attn(l + "self_attn", t2, t2, t2, 0, out)
+            t2 = self.ln(l + "norm2", out)
+            out = self._rope_attn(l + "cross_attn_image", t2, mem_k, memory, num_obj_ptr_tokens, out)
+            t2 = self.ln(l + "norm3", out)
+            out = self.lin(l + "linear2", self.lin(l + "linear1", t2, act=ops.ACT_RELU), residual=out)
+        return self.ln(m + "norm", out)
+
+    # ------------------------------------------------------------------ S9 memory encoder
+    def memory_encoder(self, pix_feat, mask):
+        """MemoryEncoder.forward(skip_mask_sigmoid=True) — R/modeling/memory_encoder.py:159-182,17-118.
+        pix_feat [N,es,es,256]; mask [N,S,S,1] (already scaled) -> features [N,es*es,64]."""
+        e = "memory_encoder."
+        N = pix_feat.shape[0]
+        x, H = mask, self.S
+        for i in range(4):
+            w = self.P.conv_w(f"{self.p}{e}mask_downsampler.encoder.{3 * i}")
+            cols, Ho, Wo = ops.im2col(x, 3, 3, 2, 1, w.shape[1])
+            x = ops.linear(cols, w, self.P.b(f"{self.p}{e}mask_downsampler.encoder.{3 * i}"))
+            x = ops.activation(self.ln(f"{e}mask_downsampler.encoder.{3 * i + 1}", x, 1e-6), ops.ACT_GELU).view(N, Ho, Wo, -1)
+        x = self.lin(e + "mask_downsampler.encoder.12", x)
+        x = self.lin(e + "pix_feat_proj", pix_feat, residual=x)
+        for i in range(2):
+            l = f"{e}fuser.layers.{i}."
+            h = ops.dwconv(x, self.P.dw_w(self.p + l + "dwconv"), self.P.b(self.p + l + "dwconv"), 7)
+            h = self.lin(l + "pwconv1", self.ln(l + "norm", h, 1e-6), act=ops.ACT_GELU)
+            x = ops.linear(h, self.P.w(self.p + l + "pwconv2"), self.P.b(self.p + l + "pwconv2"), gamma=self.P.f32(self.p + l + "weight"), residual=x)
+        return self.lin(e + "out_proj", x).view(N, self.es * self.es, 64)
+
+    def maskmem_pos(self):
+        return self.P.const(("maskmem_pos", self.es), lambda: _sine_pos(64, self.es, self.es))
+
+    # ------------------------------------------------------------------ S6 SAM heads
+    def forward_sam_heads(self, pix_feat, high_res, text_inputs, multimask_output=True):
+        """SAM2Base._forward_sam_heads (points=None, masks=None) — R/modeling/sam2_base.py:251-411.
+        pix_feat [N,HW,256]; returns low-res best mask fp32 [N,1,4es,4es] (NO_OBJ-filled), high-res [N,1,S,S],
+        obj_ptr [N,256], object score logits [N,1]."""
+        N = pix_feat.shape[0]
+        sparse = self.sparse_prompt(N, text_inputs, with_empty_point=True)
+        masks, iou, toks, obj = self.mask_decoder(pix_feat, sparse, high_res, repeat_image=False)
+        low, _, tok, _ = ops.multimask_select(masks, iou, toks, 1 if multimask_output else 0)
+        low = ops.where_rows(obj, low, None, NO_OBJ_SCORE)
+        high = ops.bilinear(low.view(N, 4 * self.es, 4 * self.es), self.S, self.S).view(N, 1, self.S, self.S)
+        ptr = self.mlp("obj_ptr_proj", tok, 3)
+        ptr = ops.where_rows(obj, ptr, self.P.t(self.p + "no_obj_ptr").view(-1))
+        return dict(low=low, high=high, obj_ptr=ptr, obj_logits=obj, low_multi_pre_where=masks[:, 1:], ious=iou[:, 1:])
+
+    def encode_new_memory(self, feat_top, high_res_masks, is_mask_from_pts):
+        """SAM2Base._encode_new_memory — R/modeling/sam2_base.py:666-704; features come back bf16-rounded the way
+        the predictor stores them (sam2_video_predictor.py:967,1011)."""
+        N = high_res_masks.shape[0]
+        m = ops.mask_for_mem(high_res_masks.view(N, self.S, self.S, 1), is_mask_from_pts, 20.0, -10.0, self.dtype)
+        mem = self.memory_encoder(feat_top.view(N, self.es, self.es, 256), m)
+        return ops.cast(ops.cast(mem, torch.bfloat16), self.dtype)
+
+    # ------------------------------------------------------------------ S10 video branch / S11 framewise
+    def video_branch(self, images, text_embeds, video_hw, trace=None, frame_feats=None):
+        """init_state_from_tensor -> add_new_text per object -> propagate_in_video for one clip
+        (R/model/VideoGLaMM.py:834-877; R/sam2_video_predictor.py:108-180,415-495,520-636,674-827,921-1017;
+        R/modeling/sam2_base.py:495-664,706-803).  images [T,3,S,S]; text_embeds [N,256].
+        frame_feats: optional precomputed forward_image outputs per frame (frame-sharded Hiera).
+        -> video-res logits fp32 [T,N,H,W]."""
+        T, N = images.shape[0], text_embeds.shape[0]
+        es, hw = self.es, self.es * self.es
+        H, W = video_hw
+
+        def feats(t, bs):
+            fpn = frame_feats[t] if frame_feats is not None else self.forward_image(images[t:t + 1])
+            if bs > 1:
+                fpn = [f.expand(bs, -1, -1, -1).contiguous() for f in fpn]
+            return fpn
+
+        no_mem = self.P.t(self.p + "no_mem_embed").view(-1)
+        # frame 0: objects added one at a time (batch 1 each), no memory encoder yet
+        fpn0 = feats(0, 1)
+        pix0 = ops.add(fpn0[2].view(1, hw, 256), no_mem)          # directly_add_no_mem_embed
+        outs0 = [self.forward_sam_heads(pix0, (fpn0[0], fpn0[1]), text_embeds[k:k + 1].unsqueeze(1)) for k in range(N)]
+        low0 = torch.cat([o["low"] for o in outs0])
+        ptr0 = torch.cat([o["obj_ptr"] for o in outs0])
+        if trace is not None:
+            trace["frame0_low_multi_pre_where"] = torch.cat([o["low_multi_pre_where"] for o in outs0])
+            trace["frame0_obj_logits"] = torch.cat([o["obj_logits"] for o in outs0])
+        # preflight: consolidate + memory-encode frame 0 (binarised mask, is_mask_from_pts=True)
+        high0 = ops.bilinear(low0.view(N, 4 * es, 4 * es), self.S, self.S).view(N, 1, self.S, self.S)
+        top0 = fpn0[2].view(1, hw, 256).expand(N, -1, -1).contiguous()
+        cond = dict(mem=self.encode_new_memory(top0, high0, True), ptr=ptr0)
+        non_cond = {}
+        lows = [low0]
+        tpos = self.P.t(self.p + "maskmem_tpos_enc").view(7, 64)
+        mpos = self.maskmem_pos()
+        for t in range(1, T):
+            fpn = feats(t, N)
+            mems, mposs = [], []
+            for t_pos in range(0, 7):
+                prev = cond if t_pos == 0 else non_cond.get(t - (7 - t_pos))
+                if prev is None:
+                    continue
+                mems.append(prev["mem"])
+                mposs.append(ops.add(mpos, tpos[7 - t_pos - 1]).unsqueeze(0).expand(N, -1, -1))
+            ptrs = [cond["ptr"]]
+            for t_diff in range(1, min(T, 16)):
+                if t - t_diff < 0:
+                    break
+                if (t - t_diff) in non_cond:
+                    ptrs.append(non_cond[t - t_diff]["ptr"])
+            obj_ptrs = torch.stack(ptrs, dim=1).reshape(N, len(ptrs) * 4, 64)   # each 256-d pointer = 4 tokens of 64
+            memory = torch.cat(mems + [obj_ptrs], dim=1).contiguous()
+            memory_pos = torch.cat(mposs + [torch.zeros_like(obj_ptrs)], dim=1).contiguous()
+            top = fpn[2].view(N, hw, 256)
+            pix = self.memory_attention(top, memory, memory_pos, obj_ptrs.shape[1])
+            o = self.forward_sam_heads(pix, (fpn[0], fpn[1]), None)
+            non_cond[t] = dict(mem=self.encode_new_memory(top, o["high"], False), ptr=o["obj_ptr"])
+            non_cond.pop(t - 16, None)
+            lows.append(o["low"])
+            if trace is not None and t == 1:
+                trace["frame1_pix_feat_with_mem"] = pix
+                trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
+        low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
+        if trace is not None:
+            trace["low_res"] = low
+        return ops.bilinear(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
+
+    def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None):
+        """VideoGLaMM framewise decode — R/model/VideoGLaMM.py:205-241,676-766.  One mask-decoder batch per frame
+        (N objects, repeat_image), multimask_output=False with the stability fallback.  -> logits fp32 [T,N,H,W]."""
+        N = text_embeds.shape[0]
+        es, hw = self.es, self.es * self.es
+        H, W = video_hw
+        frames = list(range(images.shape[0])) if frames is None else frames
+        sparse = self.sparse_prompt(N, text_embeds.unsqueeze(1), with_empty_point=False)
+        no_mem = self.P.t(self.p + "no_mem_embed").view(-1)
+        lows = []
+        for t in frames:
+            fpn = frame_feats[t] if frame_feats is not None else self.forward_image(images[t:t + 1])
+            emb = ops.add(fpn[2].view(1, hw, 256), no_mem)
+            masks, iou, toks, _ = self.mask_decoder(emb, sparse, (fpn[0], fpn[1]), repeat_image=True)
+            low, _, _, _ = ops.multimask_select(masks, iou, toks, 0)
+            lows.append(low)
+        low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
+        return ops.bilinear(low.view(len(frames) * N, 4 * es, 4 * es), H, W).view(len(frames), N, H, W), low
