@@ -1,0 +1,85 @@
+"""Host-side LLM-side graph (videoglamm_amd/vlm.py, model.py) vs reference outputs (golden fixtures).
+CPU variant runs on tests/_cpu_ops.py; the -m gpu variant runs the same graph on the HIP kernels (fp32 parity mode)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from oracle import seeded
+
+torch.set_grad_enabled(False)
+
+
+def towers(device, sd, cfg):
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import VisionTowers
+
+    return VisionTowers(Params(sd, device, torch.float32), cfg)
+
+
+def check_modules(device, tol):
+    fx = G.fixture("vlm_tiny.npz")
+    c = G.configs.IV2_TINY
+    sd = {"model.vision_tower.vision_encoder." + k: v for k, v in G.weights("iv2_tiny_manifest.json", 2).items()}
+    t = towers(device, sd, dict(iv2=dict(depth=c["depth"], num_heads=c["num_heads"], patch_size=c["patch_size"])))
+    out = t.iv2(G.rnd((2, 4, 3, c["img_size"], c["img_size"]), 31).to(device))
+    torch.testing.assert_close(out.float().cpu(), fx["iv2_out"][:, 1:], **tol)
+
+    c = G.configs.CLIP_TINY
+    sd = {"model.image_vision_tower.vision_tower." + k: v for k, v in G.weights("clip_tiny_manifest.json", 3).items()}
+    t = towers(device, sd, dict(clip=dict(num_layers=c["num_layers"], num_heads=c["num_heads"], patch_size=c["patch_size"])))
+    out = t.clip(G.rnd((3, 3, c["img_size"], c["img_size"]), 32).to(device))
+    torch.testing.assert_close(out.float().cpu(), fx["clip_out"], **tol)
+
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    c = G.configs.LLAMA_TINY
+    sd = {"model." + k: v for k, v in G.weights("llama_tiny_manifest.json", 4).items()}
+    x = G.rnd((1, 45, c["hidden"]), 33)[0].to(device)
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    torch.testing.assert_close(dec.forward(x).cpu(), fx["llama_out"], **tol)
+    # prefill + token-by-token decode through the KV cache must give the same rows
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    rows = [dec.forward(x[:40])] + [dec.forward(x[i:i + 1]) for i in range(40, 45)]
+    torch.testing.assert_close(torch.cat(rows).cpu(), fx["llama_out"], **tol)
+
+
+def check_e2e(device, branch):
+    from test_oracle_e2e import e2e_setup
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    fx, sd, cfg, inp = e2e_setup()
+    m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device)
+    out_ids, segs = m.inference([inp["images"]], [inp["context_images"]], [inp["images_for_sam"]], inp["input_ids"][None],
+                                [(1024, 1024)], [inp["original_size"]], max_new_tokens=inp["max_new_tokens"],
+                                use_sam2_video_branch=branch)
+    key = "video" if branch else "framewise"
+    assert out_ids[0].tolist() == fx[f"{key}_output_ids"].long().tolist()        # token ids bit-exact
+    seg = segs[0]
+    got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
+    ref = fx[f"{key}_masks"].numpy() > 0.5
+    assert got.shape == ref.shape
+    iou = (got & ref).sum() / (got | ref).sum()
+    assert iou > 0.999, iou
+
+
+def test_modules_cpu(cpu_ops):
+    check_modules(torch.device("cpu"), dict(rtol=1e-4, atol=1e-4))
+
+
+@pytest.mark.parametrize("branch", [False, True])
+def test_e2e_cpu(cpu_ops, branch, monkeypatch):
+    from videoglamm_amd import _lib
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    check_e2e(torch.device("cpu"), branch)
+
+
+@pytest.mark.gpu
+def test_modules_hip_fp32(cuda):
+    check_modules(cuda, dict(rtol=1e-3, atol=1e-3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("branch", [False, True])
+def test_e2e_hip_fp32(cuda, branch):
+    check_e2e(cuda, branch)

@@ -1,0 +1,141 @@
+"""Drop-in façade for the reference's ``VideoGLaMMForCausalLM`` inference surface
+(R/model/VideoGLaMM.py:560-596 inference, :598-768 inference_framewise, :770-879 inference_video_branch,
+:325-508 model_forward(inference=True), :897-900 forward) on the MI355X kernel library.
+
+Same argument meaning, return structure and error behaviour as the reference for this path; batch size 1 is
+asserted exactly like R/model/VideoGLaMM.py:252-253.
+"""
+import torch
+
+from . import ops
+from .params import Params
+from .sam2 import SAM2
+from .vlm import VisionTowers, generate
+
+
+class _Cfg:
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+
+class VideoGLaMMForCausalLM:
+    def __init__(self, state_dict, config, torch_dtype=torch.bfloat16, device="cuda", use_sam2_video_branch=False,
+                 comm=None, **kwargs):
+        """state_dict: the merged checkpoint ({name: tensor}, reference naming); config: dict with keys
+        seg_token_idx, iv2{depth,num_heads,patch_size}, clip{num_layers,num_heads,patch_size},
+        llm{hidden,num_layers,num_heads,num_kv_heads,rms_eps,rope_theta}, sam2{image_size,trunk{...}},
+        optional eos_token_id.  comm: optional videoglamm_amd.dist.FrameSharder for multi-GPU runs."""
+        from . import _lib
+
+        _lib.load()  # fail loudly if the HIP extension is missing: there is no fallback path
+        self.cfg = dict(config)
+        self.config = _Cfg(dict(seg_token_idx=config["seg_token_idx"], use_sam2=True))
+        self.dtype = torch_dtype
+        self.device = torch.device(device)
+        self.use_sam2_video_branch = use_sam2_video_branch
+        self.P = Params(state_dict, self.device, torch_dtype)
+        self.towers = VisionTowers(self.P, self.cfg)
+        self.sam2 = SAM2(self.P, "model.visual_model.", self.cfg["sam2"])
+        self.comm = comm
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kwargs):
+        """HF directory with *.safetensors shards (+ config.json carrying the keys above under "videoglamm_amd")."""
+        import glob
+        import json
+        import os
+
+        from safetensors.torch import load_file
+
+        sd = {}
+        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            sd.update(load_file(f))
+        if not sd:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        if config is None:
+            with open(os.path.join(path, "config.json")) as fh:
+                config = json.load(fh)["videoglamm_amd"]
+        return cls(sd, config, **kwargs)
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ forward surface
+    def forward(self, **kwargs):
+        """R/model/VideoGLaMM.py:897-900: LM forward when past_key_values is passed (not part of this path),
+        otherwise model_forward."""
+        if "past_key_values" in kwargs:
+            raise NotImplementedError("the bare LM forward is outside the accelerated path (SURVEY §8)")
+        return self.model_forward(**kwargs)
+
+    __call__ = forward
+
+    def model_forward(self, images_for_sam, images, context_images, input_ids, labels=None, attention_masks=None,
+                      offset=None, masks_list=None, label_list=None, resize_list=None, inference=False, **kwargs):
+        """inference=True branch of R/model/VideoGLaMM.py:325-508: teacher-forced ids -> [SEG] rows -> framewise
+        decode; returns {"pred_masks": B x T x [N,H,W] logits, "gt_masks": masks_list}."""
+        if not inference:
+            raise NotImplementedError("training losses are out of scope (SURVEY §2 rows 10-11)")
+        assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
+        hw = tuple(label_list[0].shape[-2:])
+        ids = input_ids[0].cpu()
+        _, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), context_images[0].to(self.device), ids, 0)
+        if emb.shape[0] == 0:
+            return {"pred_masks": [[torch.zeros(0, *hw, device=self.device) for _ in range(len(images_for_sam[0]))]], "gt_masks": masks_list}
+        logits, _ = self.sam2.framewise_branch(images_for_sam[0].to(self.device), emb, hw)
+        return {"pred_masks": [[logits[t] for t in range(logits.shape[0])]], "gt_masks": masks_list}
+
+    # ------------------------------------------------------------------ inference surface
+    def inference(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
+                  max_new_tokens=32, use_sam2_video_branch=False):
+        """R/model/VideoGLaMM.py:560-596."""
+        if use_sam2_video_branch:
+            if self.config.use_sam2:
+                return self.inference_video_branch(images, context_images, images_for_sam, input_ids, resize_list,
+                                                   original_size_list, max_new_tokens)
+            raise ValueError("use_sam2_video_branch is True, but model is not configured to use SAM2")
+        return self.inference_framewise(images, context_images, images_for_sam, input_ids, resize_list,
+                                        original_size_list, max_new_tokens)
+
+    def _text_side(self, images, context_images, input_ids, max_new_tokens):
+        assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
+        ctx = context_images[0] if context_images is not None else None
+        if ctx is None:
+            raise NotImplementedError("single-image prompts (context_images=None) are outside the video hot path")
+        out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), ctx.to(self.device),
+                                input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"))
+        return out_ids.unsqueeze(0), emb
+
+    @staticmethod
+    def _segments(mask_u8):
+        """[T,N,H,W] uint8 on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875)."""
+        m = mask_u8.numpy().astype(bool)
+        return {t: {k: m[t, k] for k in range(m.shape[1])} for t in range(m.shape[0])}
+
+    def inference_framewise(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
+                            max_new_tokens=32):
+        """R/model/VideoGLaMM.py:598-768 -> (output_ids [1,L+G], [ {frame: {obj: mask}} ])."""
+        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+        if emb.shape[0] == 0:
+            # the reference dereferences `.shape` of a tuple here (VideoGLaMM.py:732): same exception type
+            raise AttributeError("'tuple' object has no attribute 'shape'")
+        hw = tuple(original_size_list[0])
+        sam = images_for_sam[0].to(self.device)
+        if self.comm is not None:
+            masks = self.comm.framewise(self.sam2, sam, emb, hw)
+        else:
+            logits, _ = self.sam2.framewise_branch(sam, emb, hw)
+            masks = ops.threshold(logits).cpu()
+        return out_ids, [self._segments(masks)]
+
+    def inference_video_branch(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
+                               max_new_tokens=32):
+        """R/model/VideoGLaMM.py:770-879; empty dict when no [SEG] was emitted (:840-842)."""
+        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+        if emb.shape[0] == 0:
+            return out_ids, [{}]
+        hw = tuple(original_size_list[0])
+        sam = images_for_sam[0].to(self.device)
+        feats = self.comm.hiera_all_frames(self.sam2, sam) if self.comm is not None else None
+        logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
+        return out_ids, [self._segments(ops.threshold(logits).cpu())]

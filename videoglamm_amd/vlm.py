@@ -1,0 +1,203 @@
+"""LLM side of the VideoGLaMM hot path on the MI355X kernel library (rows L1–L6 of SURVEY.md §8a):
+InternVideo2 video tower, CLIP ViT image tower, V-L adapters + 2x2 pooling, embedding splice, Llama
+decoder with a KV cache, greedy decode with [SEG] hidden capture, L-V adapter.
+
+Scheduling differs from the reference on purpose (results are identical): the towers run ONCE per clip and
+the LLM keeps a KV cache, where the reference re-encodes the clip and re-runs the full sequence for every
+generated token (generate(use_cache=False), R/model/VideoGLaMM.py:617-626,790-799;
+R/model/videogpt_plus/model/language_model/llama3_1.py:110-134).
+"""
+import torch
+
+from . import ops
+
+IMAGE_TOKEN_INDEX = -200  # R/model/videogpt_plus/constants.py
+
+
+class VisionTowers:
+    def __init__(self, params, cfg):
+        self.P, self.cfg = params, cfg
+        self.dtype = params.dtype
+
+    # ------------------------------------------------------------------ shared
+    def _patches(self, imgs, ps, wname, bias):
+        """non-overlapping patch embedding as im2col + GEMM. imgs [B,3,H,W] NCHW -> [B, L, C]."""
+        B, _, H, W = imgs.shape
+        x = ops.permute5(imgs.contiguous(), (B, H, W, 3, 1), (3 * H * W, W, 1, H * W, 0)).view(B, H, W, 3)
+        x = ops.cast(x, self.dtype)
+        w = self.P.conv_w(wname)
+        cols, Ho, Wo = ops.im2col(x, ps, ps, ps, 0, w.shape[1])
+        return ops.linear(cols, w, bias).view(B, Ho * Wo, -1)
+
+    # ------------------------------------------------------------------ L1 InternVideo2
+    def iv2(self, video):
+        """InternVideo2_Stage2V.forward / PretrainInternVideo2.forward(x_vis_return_idx=-2, x_vis_only=True)
+        R/.../internvideo/utils.py:229-238; internvideo2.py:585-651,190-209,265-316.
+        video [nc,4,3,H,W] -> [nc, 4*L, C] (CLS already dropped, arch.py:145)."""
+        p, c = "model.vision_tower.vision_encoder.", self.cfg["iv2"]
+        nc, T = video.shape[:2]
+        heads = c["num_heads"]
+        x = self._patches(video.reshape(nc * T, *video.shape[2:]), c["patch_size"], p + "patch_embed.proj", self.P.b(p + "patch_embed.proj"))
+        C = x.shape[-1]
+        x = x.view(nc, -1, C)
+        cls = self.P.t(p + "cls_token").view(1, 1, C).expand(nc, 1, C)
+        x = ops.add(torch.cat([cls, x], dim=1).contiguous(), self.P.t(p + "pos_embed").view(-1))
+        n, hd = x.shape[1], C // heads
+        for i in range(c["depth"] - 1):  # the loop breaks after block depth-2 (internvideo2.py:640-642)
+            b = f"{p}blocks.{i}."
+            h = ops.rmsnorm(x, self.P.f32(b + "norm1.weight"), 1e-6)
+            qkv = ops.linear(h, self.P.w(b + "attn.qkv")).view(nc * n, 3 * C)
+            q = ops.rmsnorm(qkv[:, :C], self.P.f32(b + "attn.q_norm.weight"), 1e-6).view(nc, n, heads, hd)
+            k = ops.rmsnorm(qkv[:, C:2 * C], self.P.f32(b + "attn.k_norm.weight"), 1e-6).view(nc, n, heads, hd)
+            v = qkv.view(nc, n, 3, heads, hd)[:, :, 2]
+            o = ops.attention(q, k, v, hd ** -0.5).view(nc, n, C)
+            x = ops.linear(o, self.P.w(b + "attn.proj"), self.P.b(b + "attn.proj"), gamma=self.P.f32(b + "ls1.gamma"), residual=x)
+            h = ops.rmsnorm(x, self.P.f32(b + "norm2.weight"), 1e-6)
+            h = ops.linear(h, self.P.w(b + "mlp.fc1"), self.P.b(b + "mlp.fc1"), act=ops.ACT_GELU)
+            x = ops.linear(h, self.P.w(b + "mlp.fc2"), self.P.b(b + "mlp.fc2"), gamma=self.P.f32(b + "ls2.gamma"), residual=x)
+        return x[:, 1:]
+
+    # ------------------------------------------------------------------ L2 CLIP
+    def clip(self, images):
+        """CLIPVisionTower.forward('patch'): HF CLIPVisionModel hidden_states[-2] minus CLS —
+        R/.../multimodal_encoder/clip_encoder.py:34-72.  images [T,3,H,W] -> [T, L, C]."""
+        c = self.cfg["clip"]
+        p = "model.image_vision_tower.vision_tower."
+        v = p + "vision_model." if self.P.has(p + "vision_model.embeddings.class_embedding") else p
+        heads = c["num_heads"]
+        x = self._patches(images, c["patch_size"], v + "embeddings.patch_embedding", None)
+        T, L, C = x.shape
+        cls = self.P.t(v + "embeddings.class_embedding").view(1, 1, C).expand(T, 1, C)
+        x = ops.add(torch.cat([cls, x], dim=1).contiguous(), self.P.t(v + "embeddings.position_embedding.weight").view(-1))
+        x = ops.layernorm(x, self.P.f32(v + "pre_layrnorm.weight"), self.P.f32(v + "pre_layrnorm.bias"), 1e-5)
+        n, hd = L + 1, C // heads
+        for i in range(c["num_layers"] - 1):  # select_layer=-2: the last layer's output is never read
+            b = f"{v}encoder.layers.{i}."
+            h = ops.layernorm(x, self.P.f32(b + "layer_norm1.weight"), self.P.f32(b + "layer_norm1.bias"), 1e-5)
+            wqkv, bqkv = self.P.fused([b + "self_attn.q_proj", b + "self_attn.k_proj", b + "self_attn.v_proj"])
+            qkv = ops.linear(h, wqkv, bqkv).view(T, n, 3, heads, hd)
+            o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], hd ** -0.5).view(T, n, C)
+            x = ops.linear(o, self.P.w(b + "self_attn.out_proj"), self.P.b(b + "self_attn.out_proj"), residual=x)
+            h = ops.layernorm(x, self.P.f32(b + "layer_norm2.weight"), self.P.f32(b + "layer_norm2.bias"), 1e-5)
+            h = ops.linear(h, self.P.w(b + "mlp.fc1"), self.P.b(b + "mlp.fc1"), act=ops.ACT_QUICK_GELU)
+            x = ops.linear(h, self.P.w(b + "mlp.fc2"), self.P.b(b + "mlp.fc2"), residual=x)
+        return x[:, 1:]
+
+    # ------------------------------------------------------------------ L3 adapters + pooling
+    def _projector(self, name, x):
+        """'linear' or 'mlpNx_gelu' — R/.../multimodal_projector/builder.py:17-54."""
+        if self.P.has(name + ".weight"):
+            return ops.linear(x, self.P.w(name), self.P.b(name))
+        i = 0
+        while self.P.has(f"{name}.{i + 2}.weight"):
+            x = ops.linear(x, self.P.w(f"{name}.{i}"), self.P.b(f"{name}.{i}"), act=ops.ACT_GELU)
+            i += 2
+        return ops.linear(x, self.P.w(f"{name}.{i}"), self.P.b(f"{name}.{i}"))
+
+    def encode(self, images, context_images):
+        """encode_videos + project(input_type='video') — R/model/videogpt_plus/model/arch.py:121-151,164-191.
+        images [Te,3,224,224], context [Te,3,336,336] -> visual tokens [Te*144 + Te*64, D] (context first)."""
+        te = images.shape[0]
+        assert te % 4 == 0, "the video encoder consumes 4-frame chunks (arch.py:133)"
+        vf = self.iv2(images.view(te // 4, 4, *images.shape[1:]))            # [nc, 4*L, Dv]
+        cf = self.clip(context_images)                                        # [Te, Lc, Dc]
+        vf = self._projector("model.mm_projector", vf.contiguous())
+        D = vf.shape[-1]
+        g = int(round((vf.shape[1] // 4) ** 0.5))
+        vf = ops.pool2(vf.view(te, g, g, D), False).view(-1, D)               # 16x16 -> 8x8 per frame
+        cf = self._projector("model.image_mm_projector", cf.contiguous())
+        g = int(round(cf.shape[1] ** 0.5))
+        cf = ops.pool2(cf.view(te, g, g, D), False).view(-1, D)               # 24x24 -> 12x12 per frame
+        return torch.cat([cf, vf], dim=0)
+
+
+class LlamaDecoder:
+    """HF LlamaModel arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache."""
+
+    def __init__(self, params, cfg, max_len):
+        self.P, self.c = params, cfg
+        c = cfg
+        self.D, self.H, self.Hkv = c["hidden"], c["num_heads"], c["num_kv_heads"]
+        self.hd = self.D // self.H
+        dev, dt = params.device, params.dtype
+        self.kc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
+        self.vc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
+        inv = 1.0 / (c["rope_theta"] ** (torch.arange(0, self.hd, 2, dtype=torch.int64).float() / self.hd))
+        fr = torch.arange(max_len).float()[:, None] * inv[None]
+        self.cos = fr.cos().to(dev).contiguous()
+        self.sin = fr.sin().to(dev).contiguous()
+        self.pos = 0
+
+    def forward(self, x):
+        """x [S,D] new tokens appended at self.pos -> final-normed hidden [S,D]."""
+        P, c = self.P, self.c
+        S, pos = x.shape[0], self.pos
+        for i in range(c["num_layers"]):
+            l = f"model.layers.{i}."
+            h = ops.rmsnorm(x, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
+            q = ops.linear(h, P.w(l + "self_attn.q_proj")).view(S, self.H, self.hd)
+            k = self.kc[i][pos:pos + S]
+            v = self.vc[i][pos:pos + S]
+            ops.linear(h, P.w(l + "self_attn.k_proj"), out=k.view(S, self.Hkv * self.hd))
+            ops.linear(h, P.w(l + "self_attn.v_proj"), out=v.view(S, self.Hkv * self.hd))
+            ops.rope_half_(q, self.cos, self.sin, pos)
+            ops.rope_half_(k, self.cos, self.sin, pos)
+            o = ops.attention(q.unsqueeze(0), self.kc[i][:pos + S].unsqueeze(0), self.vc[i][:pos + S].unsqueeze(0),
+                              self.hd ** -0.5, causal=True).view(S, self.D)
+            x = ops.linear(o, P.w(l + "self_attn.o_proj"), residual=x)
+            h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
+            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
+            x = ops.linear(ops.swiglu(ops.linear(h, wgu)), P.w(l + "mlp.down_proj"), residual=x)
+        self.pos = pos + S
+        return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
+
+
+def splice(params, input_ids, visual):
+    """prepare_inputs_labels_for_multimodal for one sample with one run of <image> placeholders —
+    R/model/videogpt_plus/model/arch.py:271-371,453-467.  input_ids [L] (host, with -200) -> embeds [S,D]."""
+    ids = input_ids
+    pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten()
+    table = params.t("model.embed_tokens.weight")
+    dev = params.device
+    if pos.numel() == 0:
+        return ops.embed(ids.to(dev), table)
+    s, e = int(pos[0]), int(pos[-1])
+    parts = [ops.embed(ids[:s].to(dev), table), visual]
+    if e + 1 < ids.numel():
+        parts.append(ops.embed(ids[e + 1:].to(dev), table))
+    return torch.cat(parts, dim=0).contiguous()
+
+
+def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None):
+    """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
+    KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
+    final-norm state of position p-1 = the row that produced the token, captured here as it is
+    emitted.  input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
+    seg_idx = cfg["seg_token_idx"]
+    if visual is None:
+        visual = towers.encode(images, context_images)
+    x = splice(params, input_ids, visual)
+    dec = LlamaDecoder(params, cfg["llm"], x.shape[0] + max_new_tokens + 1)
+    lm_head = params.w("lm_head")
+    table = params.t("model.embed_tokens.weight")
+    hiddens = [dec.forward(x)]                 # rows 0..S-1: final-norm states of the spliced prompt
+    hidden = hiddens[0][-1:]
+    added = x.shape[0] - input_ids.numel()      # "num_newly_added_tokens" (VideoGLaMM.py:613,786)
+    ids = input_ids.tolist()
+    for step in range(max_new_tokens):
+        nxt = int(ops.argmax(ops.linear(hidden, lm_head, out_dtype=torch.float32))[0])
+        ids.append(nxt)
+        if (eos_token_id is not None and nxt == eos_token_id) or step == max_new_tokens - 1:
+            break
+        hidden = dec.forward(ops.embed(torch.tensor([nxt], device=params.device), table))
+        hiddens.append(hidden)
+    out_ids = torch.tensor(ids, dtype=torch.int64)
+    # seg_token_mask = (output_ids[:,1:] == seg) left-padded by `added` (VideoGLaMM.py:630-633,803-806):
+    # the row picked for a [SEG] at output position j is j-1+added, i.e. the state that emitted it
+    rows = [j - 1 + added for j in range(1, len(ids)) if ids[j] == seg_idx]
+    if not rows:
+        return out_ids, torch.empty(0, 256, dtype=params.dtype, device=params.device)
+    h = torch.cat(hiddens, dim=0)[torch.tensor(rows, device=params.device)]
+    fc = "model.text_hidden_fcs.0."
+    h = ops.linear(h, params.w(fc + "0"), params.b(fc + "0"), act=ops.ACT_RELU)
+    return out_ids, ops.linear(h, params.w(fc + "2"), params.b(fc + "2"))
