@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec end-to-end (text + masks) of the VideoGLaMM hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--branch framewise|video] [--no-cpu-baseline]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of VideoGLaMMForCausalLM.inference() over one synthetic clip, from
+device-resident preprocessed tensors + input_ids to (token ids on host, thresholded masks on host):
+dual vision encoders -> V-L adapters -> Llama-3-8B prefill + 32 greedy decode steps with one [SEG]
+-> L-V adapter -> SAM2-L (Hiera + FPN + mask decoder) over every frame.
+Workload at N=1 = BASELINE config C1 (8-frame 512^2-source clip -> 8 x 1024^2 SAM frames, Te=8 encoder
+frames, Llama-3-8B bf16, SAM2-L, one [SEG] object).  N>1: weak scaling, 8 SAM frames per rank (clip of
+8N frames, frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding and of the masks).
+Weights are random-init of the exact architectures (no network / no public Llama VideoGLaMM checkpoint).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--branch", default="framewise", choices=["framewise", "video"],
+                    help="framewise = the reference's default path (chat.py without --use_sam2_video_branch)")
+    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--te", type=int, default=8, help="encoder frames (NUM_FRAMES)")
+    ap.add_argument("--src", type=int, default=512, help="source (output mask) resolution")
+    ap.add_argument("--max-new-tokens", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
+    return ap.parse_args()
+
+
+def make_inputs(cfg, args, world, device):
+    g = torch.Generator().manual_seed(1234)
+    te, T = args.te, args.frames_per_gpu * world
+    S = cfg["sam2"]["image_size"]
+    iv, cl = cfg["iv2"]["img_size"], cfg["clip"]["img_size"]
+    images = torch.randn(te, 3, iv, iv, generator=g).to(device)
+    context = torch.randn(te, 3, cl, cl, generator=g).to(device)
+    sam = torch.randn(T, 3, S, S, generator=g).to(device)
+    ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, cfg["llm"]["vocab"] - 2, (30,), generator=g)])[None]
+    return images, context, sam, ids
+
+
+class GemmMeter:
+    """Per-launch HIP-event timing of the dominant kernel (gemm_tile_kernel, bf16) on torch's current stream —
+    the stream every vg_* kernel is launched on (videoglamm_amd/ops.py:_stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.linear, []
+
+    def __enter__(self):
+        def timed(x, w, *a, **k):
+            M = x.numel() // x.shape[-1]
+            if M <= 16:
+                return self.orig(x, w, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig(x, w, *a, **k)
+            e1.record()
+            self.rec.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1))
+            return y
+        self.ops.linear = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.linear = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
+        return flops, ms, len(self.rec)
+
+
+def cpu_baseline(cfg, args):
+    """Reference algorithm (oracle/, CPU fp32 restatement pinned to the reference) on the host cores, bounded
+    sample of the same workload: ONE frame through every per-frame stage at full architecture size
+    (Hiera-L+FPN+mask decoder, CLIP-L/336, 1/4 of an InternVideo2-1B 4-frame chunk).  The LLM is excluded
+    (8B fp32 parameters = 32 GB of host RAM), so the figure is an UPPER bound of the CPU path's frames/sec."""
+    from oracle import sam2 as osam, seeded, vlm as ovlm
+    from videoglamm_amd import synth
+
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    t_total = 0.0
+    man = synth.sam2_manifest(cfg["sam2"])
+    sd = seeded.seeded_state_dict(man, 0, seeded.sam2_overrides())
+    S = cfg["sam2"]["image_size"]
+    img = torch.randn(1, 3, S, S, generator=torch.Generator().manual_seed(1))
+    text = torch.randn(1, 256, generator=torch.Generator().manual_seed(2)) * 0.5
+    t0 = time.time()
+    osam.framewise_branch(sd, "", cfg["sam2"], img, text, (args.src, args.src))
+    t_sam = time.time() - t0
+    t_total += t_sam
+    del sd
+    vman = synth.vlm_manifest(cfg)
+    pc = "model.image_vision_tower.vision_tower."
+    sdc = seeded.seeded_state_dict({k: v for k, v in vman.items() if k.startswith(pc)}, 0)
+    t0 = time.time()
+    ovlm.clip_forward(sdc, pc, dict(num_heads=cfg["clip"]["num_heads"], num_layers=cfg["clip"]["num_layers"], patch_size=cfg["clip"]["patch_size"]),
+                      torch.randn(1, 3, cfg["clip"]["img_size"], cfg["clip"]["img_size"]))
+    t_clip = time.time() - t0
+    t_total += t_clip
+    del sdc
+    pi = "model.vision_tower.vision_encoder."
+    sdi = seeded.seeded_state_dict({k: v for k, v in vman.items() if k.startswith(pi)}, 0)
+    t0 = time.time()
+    ovlm.iv2_forward(sdi, pi, dict(depth=cfg["iv2"]["depth"], num_heads=cfg["iv2"]["num_heads"], patch_size=cfg["iv2"]["patch_size"]),
+                     torch.randn(1, 4, 3, cfg["iv2"]["img_size"], cfg["iv2"]["img_size"]))
+    t_iv2 = (time.time() - t0) / 4.0
+    t_total += t_iv2
+    return dict(value=round(1.0 / t_total, 4), unit="frames/sec", cores=cores, kind="port",
+                sample=f"1 frame through Hiera-L+FPN+mask decoder ({t_sam:.1f}s), CLIP-L/336 ({t_clip:.1f}s), InternVideo2-1B chunk/4 "
+                       f"({t_iv2:.1f}s), fp32 oracle; LLM (Llama-3-8B) excluded -> upper bound of the CPU path")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+        from videoglamm_amd.dist import FrameSharder
+        comm = FrameSharder()
+
+    from videoglamm_amd import ops, synth
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    torch.set_grad_enabled(False)
+    cfg = synth.videoglamm_llama3_8b()
+    if args.tiny:
+        cfg = dict(seg_token_idx=319, projector_depth=2,
+                   iv2=dict(img_size=224, patch_size=14, embed_dim=128, depth=3, num_heads=4, mlp_hidden=256),
+                   clip=dict(img_size=336, patch_size=14, hidden=128, mlp=256, num_layers=3, num_heads=4),
+                   llm=dict(vocab=320, hidden=128, ffn=256, num_layers=2, num_heads=4, num_kv_heads=2, rms_eps=1e-5, rope_theta=10000.0),
+                   sam2=dict(image_size=1024, trunk=dict(embed_dim=16, num_heads=1, stages=[1, 2, 3, 1], global_att_blocks=[4, 5],
+                                                         window_spec=[8, 4, 8, 4], window_pos_embed_bkg_spatial_size=[7, 7])))
+    cfg["forced_tokens"] = {8: cfg["seg_token_idx"]}          # exactly one [SEG] object (config C1)
+    t0 = time.time()
+    sd = synth.device_state_dict(synth.manifest(cfg), device, torch.bfloat16)
+    model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=device, comm=comm)
+    images, context, sam, ids = make_inputs(cfg, args, world, device)
+    T = sam.shape[0]
+    use_video = args.branch == "video"
+
+    def step():
+        return model.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)],
+                               max_new_tokens=args.max_new_tokens, use_sam2_video_branch=use_video)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 0)):
+        out = step()
+    del sd
+    t_load = time.time() - t0
+    barrier()
+    t1 = time.time()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.time() - t1
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt[0])
+    out_ids, segs = out
+    n_obj = len(segs[0][0]) if segs[0] else 0
+    res = {
+        "metric": "frames/sec end-to-end (text+masks)", "value": round(T * args.steps / dt, 3), "unit": "frames/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"C1: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
+                               f"Te={args.te}, Llama-3-8B bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
+                               f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),
+                   "frames": T, "encoder_frames": args.te, "generated_tokens": int(out_ids.shape[1] - ids.shape[1]),
+                   "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": f"frames sharded x{world}, LLM replicated",
+                   "weights": "random-init (synthetic)"},
+        "load_s": round(t_load, 1),
+    }
+    if rank == 0 and not args.no_roofline:
+        # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream
+        with GemmMeter(ops) as gm:
+            step()
+        flops, ms, n = gm.summary()
+        peak = 2500.0
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                           "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2), "kernel_ms_per_step": round(ms, 2)}
+    if rank == 0 and not args.no_cpu_baseline and not args.tiny:
+        res["cpu_baseline"] = cpu_baseline(cfg, args)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the path: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+What shards naturally and what does not:
+  * Hiera + FPN (dominant FLOPs) and the framewise mask decode are independent per frame -> contiguous
+    blocks of frames per rank, NO communication inside.
+  * The LLM side is a single sequence with no tensor parallelism in the reference -> replicated on every
+    rank (identical greedy ids by construction).  The only exchange the decode needs is the tiny
+    [N,256] [SEG] embedding: one all-gather, rank 0's copy is used everywhere so all ranks decode with
+    bit-identical prompts (<= 8 KB: latency-bound, one-shot, never a ring of buckets).
+  * Results: uint8 masks of the local frames, all-gathered so that rank 0 (and everyone) holds the clip.
+  * Video-branch propagation is a recurrence over frames (memory of t-1..t-6): only the per-frame Hiera
+    features shard; they are all-gathered (8.4 MB bf16 per frame at SAM2-L) and the recurrence runs replicated.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FrameSharder:
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "init torch.distributed first (torchrun: one process per GPU)"
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def my_frames(self, T):
+        """contiguous block split; T must divide evenly so every collective is regular."""
+        assert T % self.world == 0, f"T={T} frames must be a multiple of world_size={self.world}"
+        per = T // self.world
+        return list(range(self.rank * per, (self.rank + 1) * per))
+
+    def _all_gather(self, t):
+        bufs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(bufs, t.contiguous(), group=self.group)
+        return bufs
+
+    def sync_seg_embeddings(self, emb):
+        """all-gather of the [N,256] [SEG] embeddings; every rank adopts rank 0's copy."""
+        return self._all_gather(emb)[0]
+
+    def framewise(self, sam2, images_for_sam, emb, hw):
+        """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W]."""
+        emb = self.sync_seg_embeddings(emb)
+        frames = self.my_frames(images_for_sam.shape[0])
+        logits, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames)
+        local = ops.threshold(logits)                      # [T/world, N, H, W] uint8, on device
+        return torch.cat(self._all_gather(local), dim=0).cpu()
+
+    def hiera_all_frames(self, sam2, images_for_sam):
+        """frame-sharded Hiera + FPN, features all-gathered level by level -> list over frames of fpn lists."""
+        T = images_for_sam.shape[0]
+        frames = self.my_frames(T)
+        local = [sam2.forward_image(images_for_sam[t:t + 1]) for t in frames]
+        levels = []
+        for lv in range(3):
+            stacked = torch.cat([f[lv] for f in local], dim=0)      # [T/world, h, w, c]
+            levels.append(torch.cat(self._all_gather(stacked), dim=0))
+        return [[levels[lv][t:t + 1] for lv in range(3)] for t in range(T)]

@@ -103,7 +103,8 @@ class VideoGLaMMForCausalLM:
         if ctx is None:
             raise NotImplementedError("single-image prompts (context_images=None) are outside the video hot path")
         out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), ctx.to(self.device),
-                                input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"))
+                                input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
+                                forced_tokens=self.cfg.get("forced_tokens"))
         return out_ids.unsqueeze(0), emb
 
     @staticmethod
@@ -136,6 +137,9 @@ class VideoGLaMMForCausalLM:
             return out_ids, [{}]
         hw = tuple(original_size_list[0])
         sam = images_for_sam[0].to(self.device)
-        feats = self.comm.hiera_all_frames(self.sam2, sam) if self.comm is not None else None
+        feats = None
+        if self.comm is not None:
+            emb = self.comm.sync_seg_embeddings(emb)
+            feats = self.comm.hiera_all_frames(self.sam2, sam)
         logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
         return out_ids, [self._segments(ops.threshold(logits).cpu())]

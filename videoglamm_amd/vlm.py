@@ -104,6 +104,9 @@ class VisionTowers:
         vf = self._projector("model.mm_projector", vf.contiguous())
         D = vf.shape[-1]
         g = int(round((vf.shape[1] // 4) ** 0.5))
+        # arch.py:173,177-178 hard-code 8x8 / 12x12 outputs; with the 16x16 / 24x24 token grids of the shipped
+        # towers adaptive_avg_pool2d is exactly a 2x2 mean
+        assert g == 16 and int(round(cf.shape[1] ** 0.5)) == 24, "token grids must be 16x16 (video) and 24x24 (context)"
         vf = ops.pool2(vf.view(te, g, g, D), False).view(-1, D)               # 16x16 -> 8x8 per frame
         cf = self._projector("model.image_mm_projector", cf.contiguous())
         g = int(round(cf.shape[1] ** 0.5))
@@ -168,11 +171,14 @@ def splice(params, input_ids, visual):
     return torch.cat(parts, dim=0).contiguous()
 
 
-def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None):
+def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
+             forced_tokens=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
-    emitted.  input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
+    emitted.  forced_tokens {step: id} overrides the emitted token at given steps AFTER the full lm_head+argmax
+    has been computed (synthetic-weight benchmarks need a [SEG] at a known position; no work is skipped).
+    input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
     seg_idx = cfg["seg_token_idx"]
     if visual is None:
         visual = towers.encode(images, context_images)
@@ -186,6 +192,8 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     ids = input_ids.tolist()
     for step in range(max_new_tokens):
         nxt = int(ops.argmax(ops.linear(hidden, lm_head, out_dtype=torch.float32))[0])
+        if forced_tokens and step in forced_tokens:
+            nxt = int(forced_tokens[step])
         ids.append(nxt)
         if (eos_token_id is not None and nxt == eos_token_id) or step == max_new_tokens - 1:
             break
