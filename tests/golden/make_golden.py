@@ -319,3 +319,53 @@ if __name__ == "__main__":
         gen_vlm()
     if what in ("e2e", "all"):
         gen_e2e()
+
+
+# ---- host rows (H1/H2): run the reference's own helper functions on toy inputs --------------------------
+class ToyTokenizer:
+    """whitespace tokenizer with a BOS id, enough for tokenizer_image_token / templates."""
+    bos_token_id = 1
+
+    def __init__(self):
+        self.vocab = {}
+
+    def __call__(self, text):
+        ids = [self.bos_token_id]
+        for w in text.replace("\n", " \n ").split(" "):
+            if w == "":
+                continue
+            ids.append(self.vocab.setdefault(w, 10 + len(self.vocab)))
+        return type("Enc", (), {"input_ids": ids})()
+
+
+def gen_host():
+    ri.install()
+    from PIL import Image
+    import torchvision.transforms.functional as tvf
+
+    tvf.to_pil_image = Image.fromarray
+    tvf.resize = lambda img, size: img.resize((size[1], size[0]), Image.BILINEAR)  # torchvision default for PIL inputs
+    import model.segment_anything.utils.transforms as tr
+    tr.resize, tr.to_pil_image = tvf.resize, tvf.to_pil_image
+    from utils.sam_transforms import sam_preprocess
+    from model.videogpt_plus.mm_utils import tokenizer_image_token
+    from model.videogpt_plus import conversation as conv
+
+    out = {}
+    g = np.random.RandomState(7)
+    frame = g.randint(0, 256, size=(60, 80, 3)).astype(np.uint8)
+    x, shape = sam_preprocess(frame, model_type="sam2")
+    out["sam_pre_sub"], out["sam_pre_shape"] = x[:, ::16, ::16], np.array(shape)
+    out["sam_pre_mean"] = x.mean(dim=(1, 2))
+    tok = ToyTokenizer()
+    for name, key in (("phi3_instruct", "phi3"), ("llama3_1", "llama3_1")):
+        c = conv.conv_templates[name].copy()
+        c.messages = []
+        c.append_message(c.roles[0], "<image>" * 4 + "\n" + "Please segment the red car .")
+        c.append_message(c.roles[1], "")
+        out[f"ids_{key}"] = tokenizer_image_token(c.get_prompt(), tok, return_tensors="pt").numpy()
+    save("host_rows.npz", **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("host", "all")):
+    gen_host()

@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 gloo processes running the frame-sharded SAM2 decode (videoglamm_amd/dist.py)
+must reproduce the single-process result bit for bit (operators swapped for tests/_cpu_ops.py)."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    import _cpu_ops
+    import _golden as G
+    from oracle import seeded
+    from videoglamm_amd import ops
+    from videoglamm_amd.dist import FrameSharder
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(2)
+    for name in _cpu_ops.ALL:
+        if hasattr(ops, name):
+            setattr(ops, name, getattr(_cpu_ops, name))
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_overrides())
+    m = SAM2(Params(sd, "cpu", torch.float32), "", G.sam2_cfg())
+    T, N, hw = 4, 2, (40, 56)
+    images = G.rnd((T, 3, 256, 256), 11)
+    text = G.rnd((N, 256), 12, 0.5)
+    comm = FrameSharder()
+    assert comm.my_frames(T) == [2 * rank, 2 * rank + 1]
+    # a rank-dependent perturbation must be overwritten by rank 0's copy
+    emb = comm.sync_seg_embeddings(text + 0.01 * rank)
+    assert torch.equal(emb, text)
+    masks = comm.framewise(m, images, text + 0.01 * rank, hw)
+    feats = comm.hiera_all_frames(m, images)
+    vid = m.video_branch(images, emb, hw, frame_feats=feats)
+    if rank == 0:
+        ref_logits, _ = m.framewise_branch(images, text, hw)
+        ref_vid = m.video_branch(images, text, hw)
+        q.put((bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))), bool(torch.equal(vid, ref_vid)), tuple(masks.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_fw, ok_vid, shape = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert shape == (4, 2, 40, 56)
+    assert ok_fw, "frame-sharded framewise masks differ from the single-process result"
+    assert ok_vid, "video branch on all-gathered Hiera features differs from the single-process result"

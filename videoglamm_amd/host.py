@@ -1,0 +1,173 @@
+"""Host-side callers of the hot path (rows H1, H2, H4 of SURVEY.md §8a): frame sub-sampling and the three
+preprocessed tensor streams, chat-prompt templating + <image> tokenisation, id post-processing and mask
+writing.  CPU / numpy / PIL code, outside the timed region (the benchmark starts from device tensors);
+the resizing backends the reference uses (cv2, torchvision, the CLIP processor from the HF hub) are not
+installable here, so resizes go through PIL's bilinear/bicubic filters (see DESIGN.md "host rows").
+"""
+import os
+
+import numpy as np
+import torch
+
+IMAGE_TOKEN_INDEX = -200
+DEFAULT_IMAGE_TOKEN, DEFAULT_VIDEO_TOKEN = "<image>", "<video>"
+
+# ----------------------------------------------------------------------------------------------- H1
+SAM_MEAN = torch.tensor([123.675, 116.28, 103.53]).view(-1, 1, 1)
+SAM_STD = torch.tensor([58.395, 57.12, 57.375]).view(-1, 1, 1)
+IV2_MEAN, IV2_STD = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+CLIP_MEAN, CLIP_STD = np.array([0.48145466, 0.4578275, 0.40821073]), np.array([0.26862954, 0.26130258, 0.27577711])
+
+
+def subsample_frames(frames, num_frames):
+    """np.linspace sub-sampling to NUM_FRAMES — R/chat.py:422-427."""
+    if len(frames) > num_frames:
+        idx = np.linspace(0, len(frames) - 1, num_frames, dtype=int)
+        return [frames[i] for i in idx]
+    return list(frames)
+
+
+def pad_or_truncate(frames, num_frames):
+    """R/utils/enc_preprocessors.py:145-149: truncate, or repeat the last frame."""
+    frames = list(frames[:num_frames])
+    while len(frames) < num_frames:
+        frames.append(frames[-1])
+    return frames
+
+
+def get_preprocess_shape(oldh, oldw, long_side):
+    """ResizeLongestSide.get_preprocess_shape — R/model/segment_anything/utils/transforms.py."""
+    scale = long_side * 1.0 / max(oldh, oldw)
+    return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
+
+
+def _pil_resize(img_u8, hw, resample):
+    from PIL import Image
+
+    return np.array(Image.fromarray(img_u8).resize((hw[1], hw[0]), resample))
+
+
+def sam_preprocess(frame_u8, img_size=1024):
+    """sam_preprocess(model_type='sam2') — R/utils/sam_transforms.py:26-65: resize longest side to 1024
+    (torchvision resize of a PIL image = PIL bilinear), normalise, bilinear stretch to 1024^2.
+    -> (tensor [3,1024,1024] fp32, resize_shape)."""
+    from PIL import Image
+
+    th, tw = get_preprocess_shape(frame_u8.shape[0], frame_u8.shape[1], img_size)
+    x = _pil_resize(frame_u8, (th, tw), Image.BILINEAR)
+    x = torch.from_numpy(x).permute(2, 0, 1).contiguous()
+    x = (x - SAM_MEAN) / SAM_STD
+    x = torch.nn.functional.interpolate(x.unsqueeze(0), (img_size, img_size), mode="bilinear").squeeze(0)
+    return x, (th, tw)
+
+
+def iv2_preprocess(frame_u8, size=224):
+    """VideoTrainProcessor.frames2tensor — R/.../internvideo/utils.py:105-143 (cv2.resize bilinear + ImageNet norm)."""
+    from PIL import Image
+
+    x = _pil_resize(frame_u8, (size, size), Image.BILINEAR).astype(np.float64)
+    x = (x / 255.0 - IV2_MEAN.reshape(1, 1, 3)) / IV2_STD.reshape(1, 1, 3)
+    return torch.from_numpy(np.transpose(x, (2, 0, 1))).float()
+
+
+def clip_preprocess(frame_u8, size=336):
+    """CLIPImageProcessor(openai/clip-vit-large-patch14-336): bicubic resize of the short side to 336, centre crop,
+    /255, CLIP mean/std — R/utils/enc_preprocessors.py:120-166."""
+    from PIL import Image
+
+    h, w = frame_u8.shape[:2]
+    s = size / min(h, w)
+    nh, nw = max(size, int(round(h * s))), max(size, int(round(w * s)))
+    x = _pil_resize(frame_u8, (nh, nw), Image.BICUBIC)
+    t, l = (nh - size) // 2, (nw - size) // 2
+    x = x[t:t + size, l:l + size].astype(np.float64) / 255.0
+    x = (x - CLIP_MEAN.reshape(1, 1, 3)) / CLIP_STD.reshape(1, 1, 3)
+    return torch.from_numpy(np.transpose(x, (2, 0, 1))).float()
+
+
+def preprocess_vision(np_frames, num_frames=16):
+    """preprocess_vision(type='video') — R/chat.py:402-456: returns the reference's five inputs
+    (images, context_images, images_for_sam, resize_list, original_size_list), batch of one."""
+    enc_frames = pad_or_truncate(subsample_frames(np_frames, num_frames), num_frames)
+    images = torch.stack([iv2_preprocess(f) for f in enc_frames])
+    context = torch.stack([clip_preprocess(f) for f in enc_frames])
+    sam, shapes = zip(*[sam_preprocess(f) for f in np_frames])
+    return [images], [context], [torch.stack(sam)], [shapes[0]], [tuple(np_frames[0].shape[:2])]
+
+
+# ----------------------------------------------------------------------------------------------- H2
+TEMPLATES = {  # R/model/videogpt_plus/conversation.py:124-144
+    "phi3": dict(system="<|system|>\nYou are a helpful AI assistant.", roles=("\n<|user|>\n", "\n<|assistant|>\n"), style="mpt", sep="<|end|>", sep2=None),
+    "llama3_1": dict(system="A chat between a curious user and an artificial intelligence assistant. "
+                            "The assistant gives helpful, detailed, and polite answers to the user's questions.",
+                     roles=("USER", "ASSISTANT"), style="two", sep=" ", sep2="<|end_of_text|>"),
+}
+
+
+def get_prompt(template, messages):
+    """Conversation.get_prompt for the MPT and TWO separator styles — conversation.py:27-75."""
+    t = TEMPLATES[template]
+    if t["style"] == "mpt":
+        ret = t["system"] + t["sep"]
+        for role, msg in messages:
+            ret += role + msg + t["sep"] if msg else role
+        return ret
+    seps = [t["sep"], t["sep2"]]
+    ret = t["system"] + seps[0]
+    for i, (role, msg) in enumerate(messages):
+        ret += role + ": " + msg + seps[i % 2] if msg else role + ":"
+    return ret
+
+
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX):
+    """R/model/videogpt_plus/mm_utils.py:17-37: tokenise around '<image>' and splice -200 placeholders."""
+    chunks = [tokenizer(c).input_ids for c in prompt.split(DEFAULT_IMAGE_TOKEN)]
+    ids, offset = [], 0
+    if len(chunks) > 0 and len(chunks[0]) > 0 and chunks[0][0] == tokenizer.bos_token_id:
+        offset = 1
+        ids.append(chunks[0][0])
+    sep = [image_token_index] * (offset + 1)
+    inter = [e for pair in zip(chunks, [sep] * len(chunks)) for e in pair][:-1]
+    for x in inter:
+        ids.extend(x[offset:])
+    return torch.tensor(ids, dtype=torch.long)
+
+
+def apply_for_chat(prompt_text, tokenizer, num_frames=16, base_type="llama3_1"):
+    """ConvGenerator_VideoGPTPlus.apply_for_chat(type='video') — R/utils/conv_generator.py:86-111 -> input_ids [1,L]."""
+    prompt = DEFAULT_VIDEO_TOKEN + "\n" + prompt_text
+    prompt = prompt.replace(DEFAULT_VIDEO_TOKEN, DEFAULT_IMAGE_TOKEN * num_frames)
+    roles = TEMPLATES[base_type]["roles"]
+    prompt = get_prompt(base_type, [(roles[0], prompt), (roles[1], "")])
+    return tokenizer_image_token(prompt, tokenizer).unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------------------------- H4
+def decode_text(output_ids, tokenizer):
+    """R/chat.py:572-577: drop the -200 placeholders, decode."""
+    ids = output_ids[0]
+    ids = ids[ids != IMAGE_TOKEN_INDEX]
+    return tokenizer.decode(ids, skip_special_tokens=False).replace("\n", "").replace("  ", " ")
+
+
+def write_masks(video_segments, video_frames_np, save_dir):
+    """write_masks — R/chat.py:26-64 (frames as JPG, masks as PNG, red overlay at 0.5 alpha), PIL instead of cv2."""
+    from PIL import Image
+
+    for t, pred in video_segments.items():
+        os.makedirs(os.path.join(save_dir, "img_frames"), exist_ok=True)
+        Image.fromarray(video_frames_np[t]).save(os.path.join(save_dir, "img_frames", f"frame_{t}.jpg"))
+        for obj_id, m in pred.items():
+            m = m > 0
+            os.makedirs(os.path.join(save_dir, f"pred_masks_{obj_id}"), exist_ok=True)
+            Image.fromarray((m * 255).astype(np.uint8)).save(os.path.join(save_dir, f"pred_masks_{obj_id}", f"mask_{t}.png"))
+            os.makedirs(os.path.join(save_dir, "masked_images"), exist_ok=True)
+            img = video_frames_np[t].copy()
+            img[m] = (video_frames_np[t] * 0.5 + m[:, :, None].astype(np.uint8) * np.array([255, 0, 0]) * 0.5)[m]
+            Image.fromarray(img).save(os.path.join(save_dir, "masked_images", f"masked_img_{t}_{obj_id}.jpg"))
+
+
+def mask_iou(pred, ref):
+    """IoU = sum(and) / sum(or) — R/eval_gcg_metrics.py:26-35 ('mask mIoU vs ref' of BASELINE.md)."""
+    inter, union = np.logical_and(pred, ref).sum(), np.logical_or(pred, ref).sum()
+    return float(inter) / float(union) if union > 0 else 1.0
