@@ -59,7 +59,9 @@ class Params:
             bs = [self.sd.get(n + ".bias") for n in names]
             bias = None
             if any(x is not None for x in bs):
-                bias = torch.cat([x if x is not None else torch.zeros(self.sd[n + ".weight"].shape[0]) for x, n in zip(bs, names)])
+                ref = next(x for x in bs if x is not None)
+                bias = torch.cat([x if x is not None else torch.zeros(self.sd[n + ".weight"].shape[0], dtype=ref.dtype, device=ref.device)
+                                  for x, n in zip(bs, names)])
                 bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
             return self._padk(w), bias
         return self._get(("fused",) + tuple(names), make)

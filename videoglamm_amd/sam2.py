@@ -84,8 +84,8 @@ class SAM2:
     def _hiera_pos(self, h, w):
         def make():
             sd, p = self.P.sd, self.p + "image_encoder.trunk."
-            pe = torch.nn.functional.interpolate(sd[p + "pos_embed"].float(), size=(h, w), mode="bicubic")
-            we = sd[p + "pos_embed_window"].float()
+            pe = torch.nn.functional.interpolate(sd[p + "pos_embed"].float().cpu(), size=(h, w), mode="bicubic")
+            we = sd[p + "pos_embed_window"].float().cpu()
             pe = pe + we.tile([x // y for x, y in zip(pe.shape, we.shape)])
             return pe.permute(0, 2, 3, 1).reshape(h * w, -1)
         return self.P.const(("hiera_pos", h, w), make)
@@ -163,7 +163,7 @@ class SAM2:
     def dense_pe(self):
         """PromptEncoder.get_dense_pe as [es*es, 256] — R/modeling/sam/prompt_encoder.py:68-77,216-228 (constant)."""
         def make():
-            g = self.P.sd[self.p + "sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
+            g = self.P.sd[self.p + "sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float().cpu()
             grid = torch.ones((self.es, self.es))
             y, x = (grid.cumsum(0) - 0.5) / self.es, (grid.cumsum(1) - 0.5) / self.es
             c = 2 * math.pi * ((2 * torch.stack([x, y], dim=-1) - 1) @ g)
