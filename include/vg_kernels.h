@@ -79,6 +79,15 @@ int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, in
                  int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
                  int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, vg_stream_t stream);
 
+/* Same contraction with the KV range split over `nsplit` workgroups per (query tile, head) and a merge pass —
+ * the decode-step shape (Sq = 1, Skv = thousands: one workgroup per head would walk the whole KV cache
+ * serially).  workspace: fp32, >= B*Hq*nsplit*Sq*(D+2) floats, caller-owned.  nsplit = 1 == vg_attention. */
+int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                         int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                         int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                         int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, float* workspace,
+                         int64_t ws_floats, int nsplit, vg_stream_t stream);
+
 /* ---- row normalisation -------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, two-pass fp32): nn.LayerNorm and LayerNorm2d
  * (R/model/segment_anything_2/sam2/modeling/sam2_utils.py:137-149 — channels-last makes them identical).

@@ -1,0 +1,45 @@
+"""GEMM / attention micro-benchmarks on the shapes of the C1 workload (run on the GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from videoglamm_amd import ops
+
+def t(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+shapes = [("llm qkv/o", 1697, 4096, 4096), ("llm gate|up", 1697, 28672, 4096), ("llm down", 1697, 4096, 14336),
+          ("iv2 qkv", 2050, 4224, 1408), ("iv2 fc1", 2050, 6144, 1408), ("iv2 fc2", 2050, 1408, 6144),
+          ("clip qkv", 4616, 3072, 1024), ("clip fc1", 4616, 4096, 1024), ("clip fc2", 4616, 1024, 4096),
+          ("hiera s1 qkv", 524288, 432, 144), ("hiera s1 fc1", 524288, 576, 144), ("hiera s2 qkv", 131072, 864, 288),
+          ("hiera s3 qkv", 32768, 1728, 576), ("hiera s3 fc1", 32768, 2304, 576), ("hiera s3 fc2", 32768, 576, 2304),
+          ("hiera s4 fc1", 8192, 4608, 1152), ("square 4k", 4096, 4096, 4096), ("square 8k", 8192, 8192, 8192)]
+for name, M, N, K in shapes:
+    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ms = t(lambda: ops.linear(a, w, out=out))
+    print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s")
+for name, B, H, Hkv, Sq, Skv, D, causal in [("llm prefill", 1, 32, 8, 1697, 1697, 128, True), ("llm decode", 1, 32, 8, 1, 1730, 128, True),
+                                            ("iv2", 2, 16, 16, 1025, 1025, 88, False), ("clip", 8, 16, 16, 577, 577, 64, False),
+                                            ("hiera win8", 8192, 2, 2, 64, 64, 72, False), ("hiera glob", 8, 8, 8, 4096, 4096, 72, False),
+                                            ("memattn cross", 1, 1, 1, 4096, 28736, 256, False), ("dec tok->img", 8, 8, 8, 7, 4096, 16, False),
+                                            ("dec img->tok", 8, 8, 8, 4096, 7, 16, False)]:
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, Skv, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, Skv, Hkv, D, device="cuda", dtype=torch.bfloat16)
+    ms = t(lambda: ops.attention(q, k, v, D ** -0.5, causal))
+    fl = 4.0 * B * H * Sq * Skv * D * (0.5 if causal and Sq == Skv else 1.0)
+    print(f"attn {name:14s} B={B} H={H} Sq={Sq} Skv={Skv} D={D}  {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TF/s")
+for rows, C in [(1, 4096), (1697, 4096), (2050, 1408), (524288, 144)]:
+    x = torch.randn(rows, C, device="cuda", dtype=torch.bfloat16); w = torch.ones(C, device="cuda")
+    ms = t(lambda: ops.rmsnorm(x, w, 1e-5))
+    print(f"rmsnorm rows={rows} C={C} {ms*1e3:8.1f} us  {rows*C*4/ms/1e6:8.1f} GB/s")
+for N, K in [(4096, 4096), (28672, 4096), (4096, 14336), (128257, 4096)]:
+    a = torch.randn(1, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
+    ms = t(lambda: ops.linear(a, w), 20)
+    print(f"gemv N={N} K={K} {ms*1e3:8.1f} us  {N*K*2/ms/1e6:8.1f} GB/s")

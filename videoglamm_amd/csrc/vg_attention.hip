@@ -17,6 +17,8 @@ struct AttnArgs {
   int B, Hq, Hkv, Sq, Skv, D, causal;
   int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
   float scale;
+  int nsplit, split_len;   // split-KV: blockIdx.x = q_tile * nsplit + split; partials go to `part`
+  float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
 };
 
 template <typename T> struct AMma;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   char* Vs = Ks + BKV * RS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.x * BQ, head = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x % p.nsplit;
+  const int q0 = (blockIdx.x / p.nsplit) * BQ, head = blockIdx.y, b = blockIdx.z;
   const int kvh = head / (p.Hq / p.Hkv);
   const int D = p.D, Sq = p.Sq, Skv = p.Skv;
   const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
@@ -115,7 +118,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   const int q_idx = q0 + q_local;
   const char* qrow = Qs + q_local * RS + h * 16;
 
-  for (int kv0 = 0; kv0 < kv_end; kv0 += BKV) {
+  int kv_begin = 0;
+  if (p.nsplit > 1) {
+    kv_begin = split * p.split_len;
+    const int e = kv_begin + p.split_len;
+    kv_end = e < kv_end ? e : kv_end;
+  }
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
     __syncthreads();
     for (int idx = tid; idx < BKV * CPR; idx += NT) {
       const int row = idx / CPR, c = idx - row * CPR;
@@ -187,6 +196,20 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     }
   }
 
+  if (p.nsplit > 1) {
+    if (q_idx < Sq) {
+      float* pp = p.part + ((((int64_t)b * p.Hq + head) * p.nsplit + split) * Sq + q_idx) * (D + 2);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = dt * 32 + mfma32_row(r, h);
+          if (d < D) pp[d] = o[dt][r];
+        }
+      if (h == 0) { pp[D] = m_i; pp[D + 1] = l_i; }
+    }
+    return;
+  }
   if (q_idx < Sq) {
     const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
     T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)q_idx * p.o_ss;
@@ -209,10 +232,30 @@ static int launch_attn(const AttnArgs& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  dim3 grid((p.Sq + NW * 32 - 1) / (NW * 32), p.Hq, p.B);
+  dim3 grid(((p.Sq + NW * 32 - 1) / (NW * 32)) * p.nsplit, p.Hq, p.B);
   attn_kernel<T, DP, BKV, NW><<<grid, NW * 64, lds, st>>>(p);
   VG_LAUNCH_CHECK();
   return VG_OK;
+}
+
+// merge the split-KV partials: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p) {
+  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, D = p.D;
+  const float* base = p.part + (((int64_t)b * p.Hq + head) * p.nsplit * p.Sq + q) * (D + 2);
+  const int64_t sstride = (int64_t)p.Sq * (D + 2);
+  float m = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, base[s * sstride + D]);
+  const float ms = (m == -INFINITY) ? 0.f : m;
+  float l = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) l += base[s * sstride + D + 1] * __expf(base[s * sstride + D] - ms);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)q * p.o_ss;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) acc += base[s * sstride + d] * __expf(base[s * sstride + D] - ms);
+    vg_elt<T>::st(Og + d, acc * inv);
+  }
 }
 
 template <typename T, int BKV, int NW>
@@ -225,11 +268,12 @@ static int dispatch_dp(const AttnArgs& p, hipStream_t st) {
   return launch_attn<T, 256, BKV, NW>(p, st);
 }
 
-extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
-                            int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
-                            int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
-                            int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
-                            int causal, int dtype, vg_stream_t stream) {
+extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                                    int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                                    int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                                    int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                                    int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
+                                    vg_stream_t stream) {
   VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_attention: null pointer");
   VG_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Sq >= 0 && Skv > 0, VG_ERR_ARG,
            "vg_attention: bad shape B=%d Hq=%d Hkv=%d Sq=%d Skv=%d", B, Hq, Hkv, Sq, Skv);
@@ -241,9 +285,30 @@ extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O
            VG_ERR_ARG, "vg_attention: q/k/v strides must keep 16-byte alignment");
   VG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, VG_ERR_ARG, "vg_attention: q/k/v must be 16-byte aligned");
   if (Sq == 0) return VG_OK;
+  VG_CHECK(nsplit >= 1, VG_ERR_ARG, "vg_attention: nsplit must be >= 1");
+  int split_len = 0;
+  if (nsplit > 1) {
+    split_len = (((Skv + nsplit - 1) / nsplit) + 63) / 64 * 64;   // whole KV tiles per split
+    VG_CHECK(workspace && ws_floats >= (int64_t)B * Hq * nsplit * Sq * (D + 2), VG_ERR_ARG,
+             "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(D+2) floats)");
+  }
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
-             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace};
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VG_BF16) return dispatch_dp<bf16_t, 64, 4>(p, st);
-  return dispatch_dp<float, 32, 2>(p, st);
+  int rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
+  if (rc != VG_OK || nsplit == 1) return rc;
+  dim3 grid(Sq, Hq, B);
+  if (dtype == VG_BF16) attn_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(p);
+  else attn_combine_kernel<float><<<grid, 256, 0, st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                            int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                            int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                            int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                            int causal, int dtype, vg_stream_t stream) {
+  return vg_attention_splitkv(Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh,
+                              o_sb, o_ss, o_sh, scale, causal, dtype, nullptr, 0, 1, stream);
 }

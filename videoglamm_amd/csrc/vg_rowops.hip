@@ -3,39 +3,118 @@
 #include "vg_common.h"
 #include <math.h>
 
-template <typename TI, typename TO, bool RMS>
+template <typename T> struct RowVec;
+template <> struct RowVec<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const u32x4_t r = *(const u32x4_t*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+  }
+};
+template <> struct RowVec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4_t r = *(const f32x4_t*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r[e];
+  }
+};
+template <typename TO, int N> __device__ __forceinline__ void row_store(TO* p, const float (&v)[N]) {
+  if constexpr (sizeof(TO) == 2 && N == 8) {
+    u32x4_t r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+    *(u32x4_t*)p = r;
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) vg_elt<TO>::st(p + e, v[e]);
+  }
+}
+
+// TPR threads cooperate on one row: 64 (one wave per row, 4 rows per workgroup) for tall inputs, 256 (whole
+// workgroup per row) when there are few rows (LLM decode: 1 x 4096).  16-byte loads when VEC, scalar otherwise.
+template <typename TI, typename TO, bool RMS, int TPR, bool VEC>
 __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                    const float* __restrict__ b, TO* __restrict__ y, int64_t ldy,
                                                    int64_t rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  __shared__ float red[4];
+  constexpr int RPB = 256 / TPR;
+  constexpr int NV = RowVec<TI>::N;
+  const int t = threadIdx.x % TPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+  if (row >= rows) return;  // TPR == 256: block-uniform; TPR == 64: wave-uniform and no block barrier is used
   const TI* xr = x + row * ldx;
   TO* yr = y + row * ldy;
+  auto reduce = [&](float v) {
+    v = wave_sum(v);
+    if constexpr (TPR == 256) {
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      v = red[0] + red[1] + red[2] + red[3];
+      __syncthreads();
+    }
+    return v;
+  };
   float mean = 0.f;
   if (!RMS) {
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += vg_elt<TI>::ld(xr + c);
-    mean = wave_sum(s) / (float)C;
+    if constexpr (VEC) {
+      for (int c = t * NV; c < C; c += TPR * NV) { float v[NV]; RowVec<TI>::ld(xr + c, v);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) s += v[e]; }
+    } else {
+      for (int c = t; c < C; c += TPR) s += vg_elt<TI>::ld(xr + c);
+    }
+    mean = reduce(s) / (float)C;
   }
-  float v = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float d = vg_elt<TI>::ld(xr + c) - mean;
-    v += d * d;
+  float q = 0.f;
+  if constexpr (VEC) {
+    for (int c = t * NV; c < C; c += TPR * NV) { float v[NV]; RowVec<TI>::ld(xr + c, v);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) { const float d = v[e] - mean; q += d * d; } }
+  } else {
+    for (int c = t; c < C; c += TPR) { const float d = vg_elt<TI>::ld(xr + c) - mean; q += d * d; }
   }
-  v = wave_sum(v) / (float)C;
-  const float rstd = rsqrtf(v + eps);
-  for (int c = lane; c < C; c += 64) {
-    float o = (vg_elt<TI>::ld(xr + c) - mean) * rstd;
+  const float rstd = rsqrtf(reduce(q) / (float)C + eps);
+  auto fin = [&](float xv, int c) {
+    float o = (xv - mean) * rstd;
     if (RMS) {
       // reference casts the normalised value back to the input dtype before the weight multiply
       // (internvideo2.py:140-145, HF LlamaRMSNorm)
       if (sizeof(TI) == 2) o = bf2f(f2bf(o));
-      o = w ? o * w[c] : o;
-    } else {
-      o = o * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
+      return w ? o * w[c] : o;
     }
-    vg_elt<TO>::st(yr + c, o);
+    return o * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
+  };
+  if constexpr (VEC) {
+    for (int c = t * NV; c < C; c += TPR * NV) {
+      float v[NV];
+      RowVec<TI>::ld(xr + c, v);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) v[e] = fin(v[e], c + e);
+      row_store<TO, NV>(yr + c, v);
+    }
+  } else {
+    for (int c = t; c < C; c += TPR) vg_elt<TO>::st(yr + c, fin(vg_elt<TI>::ld(xr + c), c));
+  }
+}
+
+template <typename TI, typename TO, bool RMS>
+static void launch_norm_t(const void* x, int64_t ldx, const float* w, const float* b, void* y, int64_t ldy, int64_t rows,
+                          int C, float eps, hipStream_t st) {
+  constexpr int NV = RowVec<TI>::N;
+  const bool vec = (C % NV == 0) && (ldx % NV == 0) && (ldy % NV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  const TI* xi = (const TI*)x;
+  TO* yo = (TO*)y;
+  if (rows < 1024) {
+    dim3 grid((unsigned)rows);
+    if (vec) norm_kernel<TI, TO, RMS, 256, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
+    else norm_kernel<TI, TO, RMS, 256, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
+  } else {
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (vec) norm_kernel<TI, TO, RMS, 64, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
+    else norm_kernel<TI, TO, RMS, 64, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   }
 }
 
@@ -43,15 +122,10 @@ template <bool RMS>
 static int launch_norm(const void* x, int64_t ldx, const float* w, const float* b, void* y, int64_t ldy,
                        int64_t rows, int C, float eps, int in_dtype, int out_dtype, hipStream_t st) {
   if (rows == 0) return VG_OK;
-  dim3 grid((unsigned)((rows + 3) / 4));
-  if (in_dtype == VG_F32 && out_dtype == VG_F32)
-    norm_kernel<float, float, RMS><<<grid, 256, 0, st>>>((const float*)x, ldx, w, b, (float*)y, ldy, rows, C, eps);
-  else if (in_dtype == VG_BF16 && out_dtype == VG_BF16)
-    norm_kernel<bf16_t, bf16_t, RMS><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, w, b, (bf16_t*)y, ldy, rows, C, eps);
-  else if (in_dtype == VG_BF16 && out_dtype == VG_F32)
-    norm_kernel<bf16_t, float, RMS><<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, w, b, (float*)y, ldy, rows, C, eps);
-  else if (in_dtype == VG_F32 && out_dtype == VG_BF16)
-    norm_kernel<float, bf16_t, RMS><<<grid, 256, 0, st>>>((const float*)x, ldx, w, b, (bf16_t*)y, ldy, rows, C, eps);
+  if (in_dtype == VG_F32 && out_dtype == VG_F32) launch_norm_t<float, float, RMS>(x, ldx, w, b, y, ldy, rows, C, eps, st);
+  else if (in_dtype == VG_BF16 && out_dtype == VG_BF16) launch_norm_t<bf16_t, bf16_t, RMS>(x, ldx, w, b, y, ldy, rows, C, eps, st);
+  else if (in_dtype == VG_BF16 && out_dtype == VG_F32) launch_norm_t<bf16_t, float, RMS>(x, ldx, w, b, y, ldy, rows, C, eps, st);
+  else if (in_dtype == VG_F32 && out_dtype == VG_BF16) launch_norm_t<float, bf16_t, RMS>(x, ldx, w, b, y, ldy, rows, C, eps, st);
   else {
     vg_set_error("norm: bad dtypes %d -> %d", in_dtype, out_dtype);
     return VG_ERR_ARG;
@@ -71,37 +145,52 @@ extern "C" int vg_rmsnorm(const void* x, int64_t ldx, const float* w, void* y, i
   return launch_norm<true>(x, ldx, w, nullptr, y, ldy, rows, C, eps, in_dtype, out_dtype, (hipStream_t)stream);
 }
 
-// argmax: one 256-thread workgroup per row; ties resolve to the lowest index (torch.argmax on CPU).
-__global__ __launch_bounds__(256) void argmax_kernel(const void* __restrict__ x, int n, int64_t* __restrict__ out, int dt) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  const int64_t row = blockIdx.x;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = ld_any(x, row * n + i, dt);
-    if (v > best || (v == best && i < bi) || bi == 0x7fffffff) { best = v; bi = i; }
+// argmax over long rows (lm_head logits, 128k entries): up to 64 workgroups per row atomicMax a packed
+// (order-preserving value bits, ~index) key into out[row] (zeroed first), then the key is decoded in place.
+// Ties -> lowest index, NaN-free inputs assumed (torch.argmax semantics on finite logits).
+__device__ __forceinline__ uint64_t amax_key(float v, int i) {
+  uint32_t u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map of float order onto unsigned order
+  return ((uint64_t)u << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+}
+__global__ __launch_bounds__(256) void argmax_stage1(const void* __restrict__ x, int n, unsigned long long* __restrict__ acc, int nb, int dt) {
+  __shared__ uint64_t sk[4];
+  const int64_t row = blockIdx.y;
+  uint64_t best = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += nb * 256) {
+    const uint64_t k = amax_key(ld_any(x, row * n + i, dt), i);
+    best = k > best ? k : best;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    const uint64_t ok = __shfl_xor(best, o, 64);
+    best = ok > best ? ok : best;
   }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sv[wave] = best; si[wave] = bi; }
+  if ((threadIdx.x & 63) == 0) sk[threadIdx.x >> 6] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-    out[row] = bi;
+    for (int w = 1; w < 4; ++w) best = sk[w] > best ? sk[w] : best;
+    atomicMax(acc + row, (unsigned long long)best);   // out[] doubles as the per-row key accumulator
   }
+}
+__global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ out, int64_t rows) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) out[r] = (int64_t)(0xffffffffu - (uint32_t)(((uint64_t)out[r]) & 0xffffffffu));
 }
 
 extern "C" int vg_argmax(const void* x, int64_t rows, int n, int64_t* out, int dtype, vg_stream_t stream) {
   VG_CHECK(x && out && rows >= 0 && n > 0, VG_ERR_ARG, "vg_argmax: bad args");
   if (rows == 0) return VG_OK;
-  argmax_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, n, out, dtype);
+  int nb = (n + 2047) / 2048;
+  if (nb > 64) nb = 64;
+  if (nb < 1) nb = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)rows * sizeof(int64_t), st) != hipSuccess) {
+    vg_set_error("vg_argmax: memset failed");
+    return VG_ERR_LAUNCH;
+  }
+  argmax_stage1<<<dim3(nb, (unsigned)rows), 256, 0, st>>>(x, n, (unsigned long long*)out, nb, dtype);
+  argmax_stage2<<<dim3((unsigned)((rows + 255) / 256)), 256, 0, st>>>(out, rows);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

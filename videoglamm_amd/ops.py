@@ -103,10 +103,17 @@ def attention(q, k, v, scale, causal=False):
     Skv, Hkv = k.shape[1], k.shape[2]
     assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
     out = torch.empty(B, Sq, Hq, D, dtype=q.dtype, device=q.device)
-    rc = lib.vg_attention(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
-                          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                          v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
-                          float(scale), int(bool(causal)), _dt(q), _stream())
+    # few query rows against a long KV range (LLM decode, mask-decoder tokens -> image): split the KV range over
+    # workgroups so the chip is filled, merge the partial softmaxes afterwards
+    nsplit, ws = 1, None
+    if Sq <= 64 and Skv >= 1024:
+        nsplit = min(64, -(-Skv // 256))
+        ws = torch.empty(B * Hq * nsplit * Sq * (D + 2), dtype=torch.float32, device=q.device)
+    rc = lib.vg_attention_splitkv(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
+                                  q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                  v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                                  float(scale), int(bool(causal)), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit,
+                                  _stream())
     _lib.check(rc, "vg_attention")
     return out
 

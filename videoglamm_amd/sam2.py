@@ -64,6 +64,18 @@ class SAM2:
         self.S = cfg["image_size"]
         self.es = self.S // 16
         self.blocks, self.stage_ends = hiera_layout(cfg["trunk"])
+        self.frame_chunk = 8  # frames batched per Hiera / framewise-decode launch group
+
+    def hiera_frames(self, images, frames=None):
+        """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
+        frames = list(range(images.shape[0])) if frames is None else frames
+        out = {}
+        for c0 in range(0, len(frames), self.frame_chunk):
+            fr = frames[c0:c0 + self.frame_chunk]
+            fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr])
+            for j, t in enumerate(fr):
+                out[t] = [f[j:j + 1] for f in fpn]
+        return out
 
     # ------------------------------------------------------------------ small helpers
     def lin(self, name, x, **kw):
@@ -328,8 +340,11 @@ class SAM2:
         es, hw = self.es, self.es * self.es
         H, W = video_hw
 
+        if frame_feats is None:  # Hiera is frame-independent: batch it up front (the recurrence below only reads it)
+            frame_feats = self.hiera_frames(images)
+
         def feats(t, bs):
-            fpn = frame_feats[t] if frame_feats is not None else self.forward_image(images[t:t + 1])
+            fpn = frame_feats[t]
             if bs > 1:
                 fpn = [f.expand(bs, -1, -1, -1).contiguous() for f in fpn]
             return fpn
@@ -392,13 +407,28 @@ class SAM2:
         H, W = video_hw
         frames = list(range(images.shape[0])) if frames is None else frames
         sparse = self.sparse_prompt(N, text_embeds.unsqueeze(1), with_empty_point=False)
+        ns = sparse.shape[1]
         no_mem = self.P.t(self.p + "no_mem_embed").view(-1)
         lows = []
-        for t in frames:
-            fpn = frame_feats[t] if frame_feats is not None else self.forward_image(images[t:t + 1])
-            emb = ops.add(fpn[2].view(1, hw, 256), no_mem)
-            masks, iou, toks, _ = self.mask_decoder(emb, sparse, (fpn[0], fpn[1]), repeat_image=True)
+        # frames are independent here: a chunk of frames x all objects goes through Hiera and the mask decoder as
+        # ONE batch (identical per-item arithmetic to the reference's frame-serial loop, far fewer/larger launches)
+        for c0 in range(0, len(frames), self.frame_chunk):
+            fr = frames[c0:c0 + self.frame_chunk]
+            Tc = len(fr)
+            if frame_feats is not None:
+                fpn = [torch.cat([frame_feats[t][lv] for t in fr], dim=0) for lv in range(3)]
+            else:
+                fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr])
+            emb = ops.add(fpn[2].view(Tc, hw, 256), no_mem)
+            s0, s1, sp = fpn[0], fpn[1], sparse
+            if N > 1:  # (frame, object) pairs: repeat each frame's features per object, tile the prompts per frame
+                rep = lambda x: ops.permute5(x.contiguous(), (Tc, N, x[0].numel(), 1, 1), (x[0].numel(), 0, 1, 0, 0))  # noqa: E731
+                emb = rep(emb).view(Tc * N, hw, 256)
+                s0, s1 = rep(s0).view(Tc * N, 16 * hw, 32), rep(s1).view(Tc * N, 4 * hw, 64)
+            if Tc > 1:
+                sp = ops.permute5(sparse, (Tc, N, ns * 256, 1, 1), (0, ns * 256, 1, 0, 0)).view(Tc * N, ns, 256)
+            masks, iou, toks, _ = self.mask_decoder(emb, sp, (s0, s1), repeat_image=False)
             low, _, _, _ = ops.multimask_select(masks, iou, toks, 0)
-            lows.append(low)
-        low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
+            lows.append(low.view(Tc, N, 1, 4 * es, 4 * es))
+        low = torch.cat(lows, dim=0)                                             # [T,N,1,4es,4es]
         return ops.bilinear(low.view(len(frames) * N, 4 * es, 4 * es), H, W).view(len(frames), N, H, W), low
