@@ -86,7 +86,18 @@ int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, i
                          int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
                          int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
                          int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, float* workspace,
-                         int64_t ws_floats, int nsplit, vg_stream_t stream);
+                         int64_t ws_floats, int nsplit, const int* skv_dev, vg_stream_t stream);
+/* skv_dev (may be NULL): when given, the kernel uses Skv = *skv_dev + Sq read from device memory instead of the
+ * host value, so one captured decode step can be replayed from a HIP graph as the KV cache grows. */
+
+/* Fused HF rotate-half RoPE + KV-cache append for one decoder layer (HF LlamaAttention.forward: apply_rotary_pos_emb
+ * then cache update).  qkv: fused projection output [S, (H+2*Hkv)*D], row stride ld; q rotated in place, rotated k
+ * and plain v written to k_cache/v_cache[pos+s] ([max_len,Hkv,D]).  pos = pos_dev ? *pos_dev : pos0. */
+int vg_rope_kv_append(void* qkv, int64_t ld, void* k_cache, void* v_cache, const float* cos, const float* sin,
+                      int S, int H, int Hkv, int D, int pos0, const int* pos_dev, int dtype, vg_stream_t stream);
+/* dst[(*idx_dev + idx_off)*n + i] = src[i]; *p += v — device-indexed bookkeeping for graph-replayed decode. */
+int vg_store_row(const void* src, void* dst, int64_t n, const int* idx_dev, int idx_off, int dtype, vg_stream_t stream);
+int vg_add_int(int* p, int v, vg_stream_t stream);
 
 /* ---- row normalisation -------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, two-pass fp32): nn.LayerNorm and LayerNorm2d

@@ -148,8 +148,39 @@ def embed(ids, table):
     return table[ids.reshape(-1)]
 
 
-def argmax(x):
-    return torch.argmax(x.float(), dim=-1)
+def argmax(x, out=None):
+    r = torch.argmax(x.float(), dim=-1)
+    if out is not None:
+        out.copy_(r.reshape(out.shape))
+        return out
+    return r
+
+
+def attention_decode(q, k_cache, v_cache, pos_dev, scale):
+    n = int(pos_dev[0]) + q.shape[1]
+    return attention(q, k_cache[:n].unsqueeze(0), v_cache[:n].unsqueeze(0), scale, causal=True)
+
+
+def rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos0=0, pos_dev=None):
+    pos = int(pos_dev[0]) if pos_dev is not None else pos0
+    S = qkv.shape[0]
+    q = qkv[:, : H * D].view(S, H, D)
+    k = qkv[:, H * D:(H + Hkv) * D].reshape(S, Hkv, D).clone()
+    rope_half_(q, cos, sin, pos)
+    rope_half_(k, cos, sin, pos)
+    k_cache[pos:pos + S] = k
+    v_cache[pos:pos + S] = qkv[:, (H + Hkv) * D:].reshape(S, Hkv, D)
+    return qkv
+
+
+def store_row_(src, dst, idx_dev, idx_off=0):
+    dst.view(-1, src.numel())[int(idx_dev[0]) + idx_off] = src.reshape(-1)
+    return dst
+
+
+def add_int_(p, v):
+    p += v
+    return p
 
 
 def multimask_select(masks, ious, tokens, mode, delta=0.05, thresh=0.98):

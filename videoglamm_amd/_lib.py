@@ -25,7 +25,10 @@ def _sig(lib):
         "vg_init": ([I], c_int),
         "vg_gemm": ([P, L, L, P, L, L, P, L, L, P, P, P, L, L, I, I, I, I, I, I, I, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),
-        "vg_attention_splitkv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P, L, I, P], c_int),
+        "vg_attention_splitkv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P, L, I, P, P], c_int),
+        "vg_rope_kv_append": ([P, L, P, P, P, P, I, I, I, I, I, P, I, P], c_int),
+        "vg_store_row": ([P, P, L, P, I, I, P], c_int),
+        "vg_add_int": ([P, I, P], c_int),
         "vg_layernorm": ([P, L, P, P, P, L, L, I, F, I, I, P], c_int),
         "vg_rmsnorm": ([P, L, P, P, L, L, I, F, I, I, P], c_int),
         "vg_axpby": ([P, P, P, L, F, F, L, I, I, I, P], c_int),

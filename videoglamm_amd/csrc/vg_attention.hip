@@ -19,6 +19,7 @@ struct AttnArgs {
   float scale;
   int nsplit, split_len;   // split-KV: blockIdx.x = q_tile * nsplit + split; partials go to `part`
   float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
+  const int* skv_dev;      // optional: Skv = *skv_dev + Sq read on the device (graph-replayable decode step)
 };
 
 template <typename T> struct AMma;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   const int split = blockIdx.x % p.nsplit;
   const int q0 = (blockIdx.x / p.nsplit) * BQ, head = blockIdx.y, b = blockIdx.z;
   const int kvh = head / (p.Hq / p.Hkv);
-  const int D = p.D, Sq = p.Sq, Skv = p.Skv;
+  const int D = p.D, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
   const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
   const T* Kg = (const T*)p.K + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
   const T* Vg = (const T*)p.V + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
@@ -273,7 +274,7 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
                                     int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
                                     int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
                                     int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
-                                    vg_stream_t stream) {
+                                    const int* skv_dev, vg_stream_t stream) {
   VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_attention: null pointer");
   VG_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Sq >= 0 && Skv > 0, VG_ERR_ARG,
            "vg_attention: bad shape B=%d Hq=%d Hkv=%d Sq=%d Skv=%d", B, Hq, Hkv, Sq, Skv);
@@ -293,7 +294,7 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
              "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(D+2) floats)");
   }
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
-             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace};
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace, skv_dev};
   hipStream_t st = (hipStream_t)stream;
   int rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
   if (rc != VG_OK || nsplit == 1) return rc;
@@ -310,5 +311,5 @@ extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O
                             int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
                             int causal, int dtype, vg_stream_t stream) {
   return vg_attention_splitkv(Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh,
-                              o_sb, o_ss, o_sh, scale, causal, dtype, nullptr, 0, 1, stream);
+                              o_sb, o_ss, o_sh, scale, causal, dtype, nullptr, 0, 1, nullptr, stream);
 }

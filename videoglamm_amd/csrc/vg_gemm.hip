@@ -14,6 +14,7 @@ struct GemmArgs {
   const void* A; const void* W; void* C; const float* bias; const float* gamma; const void* R;
   int64_t lda, ldw, ldc, ldr, sA, sW, sC, sR;
   int M, N, K, act;
+  int vec_out;  // C/R rows are 16-byte aligned: the epilogue stores whole 16-byte chunks
 };
 
 template <typename T> struct MmaOp;
@@ -40,7 +41,12 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
   constexpr int BK = 128 / sizeof(T);   // K elements per step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
+  // XCD-aware tile order (guide T1): workgroup id b lands on XCD b % 8; give every XCD a contiguous run of the
+  // row-major tile order so tiles sharing an A row-panel / W column-panel hit the same L2.  Bijective for any grid.
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int bn = wgid % gridDim.x, bm = wgid / gridDim.x, bz = blockIdx.z;
   const int M = p.M, N = p.N, K = p.K;
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* W = (const T*)p.W + (int64_t)bz * p.sW;
@@ -102,6 +108,67 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
   const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  if (p.vec_out) {
+    // Stage the wave's 64x64 fp32 tile through LDS (the K loop is done with it) so that every lane then owns 8
+    // consecutive columns of one row: residual loads and C stores become 16-byte accesses and 8 lanes write a
+    // full 128-byte line, instead of 2-byte stores scattered over the MFMA accumulator layout.
+    constexpr int ES = 68;                       // fp32 row stride (64 + 4 pad)
+    float* ws = (float*)smem + wave * 64 * ES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = j * 32 + l31;
+        const int n = bn * GBN + wn * 64 + nl;
+        const float bv = (p.bias && n < N) ? p.bias[n] : 0.f;
+        const float gv = (p.gamma && n < N) ? p.gamma[n] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ws[(i * 32 + mfma32_row(r, h)) * ES + nl] = vg_act(acc[i][j][r] + bv, p.act) * gv;
+      }
+    __syncthreads();
+    const int cg = lane & 7, rsub = lane >> 3;    // 8 column groups x 8 rows per pass
+    const int n0 = bn * GBN + wn * 64 + cg * 8;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int ml = pass * 8 + rsub;
+      const int m = bm * GBM + wm * 64 + ml;
+      if (m >= M || n0 >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ws[ml * ES + cg * 8 + e];
+      TO* cp = C + (int64_t)m * p.ldc + n0;
+      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -211,7 +278,10 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && sA % kpc == 0 && sW % kpc == 0, VG_ERR_ARG,
            "vg_gemm: K/lda/ldw/strides must be multiples of %d (K=%d lda=%lld ldw=%lld)", kpc, K, (long long)lda, (long long)ldw);
   VG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, VG_ERR_ARG, "vg_gemm: A/W must be 16-byte aligned");
-  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act};
+  const int ovec = out_dtype == VG_BF16 ? 8 : 4;
+  const int vec_out = (ldc % ovec == 0) && (sC % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
+                      (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out};
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);

@@ -196,3 +196,81 @@ extern "C" int vg_embed(const int64_t* ids, const void* table, void* out, int64_
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// Fused RoPE + KV-cache append for one LLM layer.  qkv: [S, (H + 2*Hkv)*D] (fused projection output, row stride
+// ld).  q is rotated in place; k is rotated and written to k_cache[pos + s]; v is copied to v_cache[pos + s].
+// pos = pos_dev ? *pos_dev : pos0 — reading the position from device memory keeps a decode step replayable
+// inside a HIP graph.
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(void* qkv, int64_t ld, void* kc, void* vc, const float* cs,
+                                                             const float* sn, int S, int H, int Hkv, int D, int pos0,
+                                                             const int* pos_dev, int dt) {
+  const int pos = pos_dev ? *pos_dev : pos0;
+  const int hd = D / 2;
+  const int HT = H + 2 * Hkv;
+  const int64_t n = (int64_t)S * HT * hd;
+  PW_LOOP(i, n) {
+    const int d = (int)(i % hd);
+    const int64_t t = i / hd;
+    const int hh = (int)(t % HT);
+    const int s = (int)(t / HT);
+    const int64_t src = (int64_t)s * ld + (int64_t)hh * D;
+    const float x1 = ld_any(qkv, src + d, dt), x2 = ld_any(qkv, src + d + hd, dt);
+    if (hh >= H + Hkv) {  // v head: plain copy into the cache
+      const int64_t dst = ((int64_t)(pos + s) * Hkv + (hh - H - Hkv)) * D;
+      st_any(vc, dst + d, dt, x1);
+      st_any(vc, dst + d + hd, dt, x2);
+      continue;
+    }
+    const float c = cs[(int64_t)(pos + s) * hd + d], sv = sn[(int64_t)(pos + s) * hd + d];
+    float o1, o2;
+    if (dt == VG_BF16) {
+      const float cb = bf2f(f2bf(c)), sb = bf2f(f2bf(sv));
+      o1 = bf2f(f2bf(x1 * cb)) + bf2f(f2bf(-x2 * sb));
+      o2 = bf2f(f2bf(x2 * cb)) + bf2f(f2bf(x1 * sb));
+    } else {
+      o1 = x1 * c - x2 * sv;
+      o2 = x2 * c + x1 * sv;
+    }
+    if (hh < H) {
+      st_any(qkv, src + d, dt, o1);
+      st_any(qkv, src + d + hd, dt, o2);
+    } else {
+      const int64_t dst = ((int64_t)(pos + s) * Hkv + (hh - H)) * D;
+      st_any(kc, dst + d, dt, o1);
+      st_any(kc, dst + d + hd, dt, o2);
+    }
+  }
+}
+extern "C" int vg_rope_kv_append(void* qkv, int64_t ld, void* k_cache, void* v_cache, const float* cos, const float* sin,
+                                 int S, int H, int Hkv, int D, int pos0, const int* pos_dev, int dtype, vg_stream_t stream) {
+  VG_CHECK(qkv && k_cache && v_cache && cos && sin && S >= 0 && H > 0 && Hkv > 0 && D > 0 && D % 2 == 0, VG_ERR_ARG,
+           "vg_rope_kv_append: bad args");
+  if (S == 0) return VG_OK;
+  rope_kv_append_kernel<<<pw_grid((int64_t)S * (H + 2 * Hkv) * D / 2), 256, 0, (hipStream_t)stream>>>(
+      qkv, ld, k_cache, v_cache, cos, sin, S, H, Hkv, D, pos0, pos_dev, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// dst[(*idx_dev + idx_off) * n + i] = src[i]  — row store at a device-resident index (graph-replayable)
+__global__ __launch_bounds__(256) void store_row_kernel(const void* src, void* dst, int64_t n, const int* idx_dev, int idx_off, int dt) {
+  const int64_t base = ((int64_t)(*idx_dev) + idx_off) * n;
+  PW_LOOP(i, n) {
+    if (dt == VG_BF16) ((bf16_t*)dst)[base + i] = ((const bf16_t*)src)[i];
+    else ((float*)dst)[base + i] = ((const float*)src)[i];
+  }
+}
+extern "C" int vg_store_row(const void* src, void* dst, int64_t n, const int* idx_dev, int idx_off, int dtype, vg_stream_t stream) {
+  VG_CHECK(src && dst && idx_dev && n > 0, VG_ERR_ARG, "vg_store_row: bad args");
+  store_row_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(src, dst, n, idx_dev, idx_off, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ void add_int_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
+extern "C" int vg_add_int(int* p, int v, vg_stream_t stream) {
+  VG_CHECK(p, VG_ERR_ARG, "vg_add_int: null");
+  add_int_kernel<<<1, 64, 0, (hipStream_t)stream>>>(p, v);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -106,16 +106,62 @@ def attention(q, k, v, scale, causal=False):
     # few query rows against a long KV range (LLM decode, mask-decoder tokens -> image): split the KV range over
     # workgroups so the chip is filled, merge the partial softmaxes afterwards
     nsplit, ws = 1, None
-    if Sq <= 64 and Skv >= 1024:
-        nsplit = min(64, -(-Skv // 256))
+    blocks = -(-Sq // (128 if q.dtype == torch.bfloat16 else 64)) * Hq * B   # workgroups without splitting
+    if Skv >= 512 and blocks < 384:                                           # < 1.5 workgroups per CU: split KV
+        nsplit = max(1, min(64, 512 // blocks, Skv // 128))
+    if nsplit > 1:
         ws = torch.empty(B * Hq * nsplit * Sq * (D + 2), dtype=torch.float32, device=q.device)
     rc = lib.vg_attention_splitkv(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
                                   q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                   v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
                                   float(scale), int(bool(causal)), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit,
-                                  _stream())
+                                  None, _stream())
     _lib.check(rc, "vg_attention")
     return out
+
+
+def attention_decode(q, k_cache, v_cache, pos_dev, scale):
+    """One decode step against a growing KV cache: q [1,1,Hq,D]; k_cache/v_cache [max_len,Hkv,D]; the number of valid
+    keys is *pos_dev + 1, read on the device (graph-replayable).  The split geometry is fixed by max_len."""
+    lib = _lib.load()
+    _, Sq, Hq, D = q.shape
+    max_len, Hkv = k_cache.shape[0], k_cache.shape[1]
+    out = torch.empty(1, Sq, Hq, D, dtype=q.dtype, device=q.device)
+    nsplit = max(1, min(64, -(-max_len // 256)))
+    ws = torch.empty(Hq * nsplit * Sq * (D + 2), dtype=torch.float32, device=q.device)
+    rc = lib.vg_attention_splitkv(_p(q), _p(k_cache), _p(v_cache), _p(out), 1, Hq, Hkv, Sq, max_len, D,
+                                  q.stride(0), q.stride(1), q.stride(2), 0, k_cache.stride(0), k_cache.stride(1),
+                                  0, v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1), out.stride(2),
+                                  float(scale), 1, _dt(q), _p(ws), ws.numel(), nsplit, _p(pos_dev), _stream())
+    _lib.check(rc, "vg_attention_splitkv(decode)")
+    return out
+
+
+def rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos0=0, pos_dev=None):
+    """in place on the fused projection qkv [S,(H+2Hkv)*D]: rotate q, rotate k -> k_cache[pos+s], v -> v_cache[pos+s]."""
+    lib = _lib.load()
+    S = qkv.shape[0]
+    assert qkv.stride(1) == 1 and k_cache.is_contiguous() and v_cache.is_contiguous()
+    rc = lib.vg_rope_kv_append(_p(qkv), qkv.stride(0), _p(k_cache), _p(v_cache), _p(_f32(cos)), _p(_f32(sin)), S, H, Hkv, D,
+                               int(pos0), _p(pos_dev), _dt(qkv), _stream())
+    _lib.check(rc, "vg_rope_kv_append")
+    return qkv
+
+
+def store_row_(src, dst, idx_dev, idx_off=0):
+    """dst[*idx_dev + idx_off] = src (one row), index read on the device."""
+    lib = _lib.load()
+    n = src.numel()
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
+    _lib.check(lib.vg_store_row(_p(src), _p(dst), n, _p(idx_dev), int(idx_off), _dt(src), _stream()), "vg_store_row")
+    return dst
+
+
+def add_int_(p, v):
+    lib = _lib.load()
+    assert p.dtype == torch.int32
+    _lib.check(lib.vg_add_int(_p(p), int(v), _stream()), "vg_add_int")
+    return p
 
 
 def layernorm(x, w, b, eps, out_dtype=None):
@@ -253,12 +299,14 @@ def embed(ids, table):
     return out
 
 
-def argmax(x):
+def argmax(x, out=None):
     lib = _lib.load()
     x = x.contiguous()
     n = x.shape[-1]
     rows = x.numel() // n
-    out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    assert out.dtype == torch.int64 and out.numel() == rows and out.is_contiguous()
     _lib.check(lib.vg_argmax(_p(x), rows, n, _p(out), _dt(x), _stream()), "vg_argmax")
     return out
 

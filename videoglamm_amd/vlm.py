@@ -115,13 +115,19 @@ class VisionTowers:
 
 
 class LlamaDecoder:
-    """HF LlamaModel arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache."""
+    """HF LlamaModel arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache.
 
-    def __init__(self, params, cfg, max_len):
+    Prefill runs eagerly (sequence length varies per clip).  A decode step is fully static — the token id, the
+    cache position and the KV length all live in device memory (tok_dev / pos_dev) — so it is captured ONCE into
+    a HIP graph (torch.cuda.CUDAGraph around the same C-ABI launches) and replayed per generated token: ~330
+    kernel launches per token stop costing host time.  One instance is kept per model and max_len bucket."""
+
+    def __init__(self, params, cfg, max_len, use_graph=None):
         self.P, self.c = params, cfg
         c = cfg
         self.D, self.H, self.Hkv = c["hidden"], c["num_heads"], c["num_kv_heads"]
         self.hd = self.D // self.H
+        self.max_len = max_len
         dev, dt = params.device, params.dtype
         self.kc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
         self.vc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
@@ -130,29 +136,81 @@ class LlamaDecoder:
         self.cos = fr.cos().to(dev).contiguous()
         self.sin = fr.sin().to(dev).contiguous()
         self.pos = 0
+        self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tok_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.hid_all = torch.empty(max_len, self.D, dtype=dt, device=dev)   # final-norm state of every position
+        self.use_graph = (dev.type == "cuda") if use_graph is None else use_graph
+        self.graph = None
 
-    def forward(self, x):
-        """x [S,D] new tokens appended at self.pos -> final-normed hidden [S,D]."""
+    def reset(self):
+        self.pos = 0
+        self.pos_dev.zero_()
+
+    def _layers(self, x, pos0, pos_dev):
+        """decoder stack on x [S,D]; KV appended at pos (host value pos0, or *pos_dev when given)."""
         P, c = self.P, self.c
-        S, pos = x.shape[0], self.pos
+        S = x.shape[0]
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
             h = ops.rmsnorm(x, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
-            q = ops.linear(h, P.w(l + "self_attn.q_proj")).view(S, self.H, self.hd)
-            k = self.kc[i][pos:pos + S]
-            v = self.vc[i][pos:pos + S]
-            ops.linear(h, P.w(l + "self_attn.k_proj"), out=k.view(S, self.Hkv * self.hd))
-            ops.linear(h, P.w(l + "self_attn.v_proj"), out=v.view(S, self.Hkv * self.hd))
-            ops.rope_half_(q, self.cos, self.sin, pos)
-            ops.rope_half_(k, self.cos, self.sin, pos)
-            o = ops.attention(q.unsqueeze(0), self.kc[i][:pos + S].unsqueeze(0), self.vc[i][:pos + S].unsqueeze(0),
-                              self.hd ** -0.5, causal=True).view(S, self.D)
-            x = ops.linear(o, P.w(l + "self_attn.o_proj"), residual=x)
+            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"])
+            qkv = ops.linear(h, wqkv)
+            ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, pos0, pos_dev)
+            q = qkv[:, : self.H * self.hd].view(1, S, self.H, self.hd)
+            if pos_dev is None:
+                n = pos0 + S
+                o = ops.attention(q, self.kc[i][:n].unsqueeze(0), self.vc[i][:n].unsqueeze(0), self.hd ** -0.5, causal=True)
+            else:
+                o = ops.attention_decode(q, self.kc[i], self.vc[i], pos_dev, self.hd ** -0.5)
+            x = ops.linear(o.view(S, self.D), P.w(l + "self_attn.o_proj"), residual=x)
             h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
             wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
             x = ops.linear(ops.swiglu(ops.linear(h, wgu)), P.w(l + "mlp.down_proj"), residual=x)
-        self.pos = pos + S
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
+
+    def forward(self, x):
+        """eager: x [S,D] new tokens appended at self.pos -> final-normed hidden [S,D] (also kept in hid_all)."""
+        S, pos = x.shape[0], self.pos
+        assert pos + S <= self.max_len
+        h = self._layers(x, pos, None)
+        self.hid_all[pos:pos + S].copy_(h)
+        self.pos = pos + S
+        self.pos_dev.fill_(self.pos)
+        return h
+
+    def next_token(self, hidden_row):
+        """lm_head + argmax of one final-norm row -> tok_dev (device int64[1])."""
+        logits = ops.linear(hidden_row, self.P.w("lm_head"), out_dtype=torch.float32)
+        ops.argmax(logits.view(1, -1), out=self.tok_dev)
+
+    def _decode_step(self):
+        """static step: consume tok_dev at position *pos_dev, emit the next token into tok_dev, advance pos_dev."""
+        x = ops.embed(self.tok_dev, self.P.t("model.embed_tokens.weight"))
+        h = self._layers(x, 0, self.pos_dev)
+        ops.store_row_(h, self.hid_all, self.pos_dev)
+        self.next_token(h)
+        ops.add_int_(self.pos_dev, 1)
+
+    def decode_step(self):
+        assert self.pos + 1 <= self.max_len
+        if not self.use_graph:
+            self._decode_step()
+        else:
+            if self.graph is None:
+                # one eager step first (lazy weight packing, kernel attribute setup), then rewind and capture
+                snap_tok, snap_pos = self.tok_dev.clone(), self.pos_dev.clone()
+                self._decode_step()
+                torch.cuda.synchronize()
+                self.tok_dev.copy_(snap_tok)
+                self.pos_dev.copy_(snap_pos)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._decode_step()
+                self.graph = g
+                self.tok_dev.copy_(snap_tok)
+                self.pos_dev.copy_(snap_pos)
+            self.graph.replay()
+        self.pos += 1
 
 
 def splice(params, input_ids, visual):
@@ -183,29 +241,33 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     if visual is None:
         visual = towers.encode(images, context_images)
     x = splice(params, input_ids, visual)
-    dec = LlamaDecoder(params, cfg["llm"], x.shape[0] + max_new_tokens + 1)
-    lm_head = params.w("lm_head")
-    table = params.t("model.embed_tokens.weight")
-    hiddens = [dec.forward(x)]                 # rows 0..S-1: final-norm states of the spliced prompt
-    hidden = hiddens[0][-1:]
+    need = x.shape[0] + max_new_tokens + 1
+    dec = getattr(params, "_decoder", None)
+    if dec is None or dec.max_len < need:
+        dec = LlamaDecoder(params, cfg["llm"], -(-need // 1024) * 1024)
+        params._decoder = dec          # KV cache + captured decode graph are reused across clips
+    dec.reset()
+    hidden = dec.forward(x)[-1:]                # hid_all rows 0..S-1: final-norm states of the spliced prompt
     added = x.shape[0] - input_ids.numel()      # "num_newly_added_tokens" (VideoGLaMM.py:613,786)
     ids = input_ids.tolist()
+    if max_new_tokens > 0:
+        dec.next_token(hidden)
     for step in range(max_new_tokens):
-        nxt = int(ops.argmax(ops.linear(hidden, lm_head, out_dtype=torch.float32))[0])
+        nxt = int(dec.tok_dev[0])
         if forced_tokens and step in forced_tokens:
             nxt = int(forced_tokens[step])
+            dec.tok_dev.fill_(nxt)
         ids.append(nxt)
         if (eos_token_id is not None and nxt == eos_token_id) or step == max_new_tokens - 1:
             break
-        hidden = dec.forward(ops.embed(torch.tensor([nxt], device=params.device), table))
-        hiddens.append(hidden)
+        dec.decode_step()
     out_ids = torch.tensor(ids, dtype=torch.int64)
     # seg_token_mask = (output_ids[:,1:] == seg) left-padded by `added` (VideoGLaMM.py:630-633,803-806):
     # the row picked for a [SEG] at output position j is j-1+added, i.e. the state that emitted it
     rows = [j - 1 + added for j in range(1, len(ids)) if ids[j] == seg_idx]
     if not rows:
         return out_ids, torch.empty(0, 256, dtype=params.dtype, device=params.device)
-    h = torch.cat(hiddens, dim=0)[torch.tensor(rows, device=params.device)]
+    h = dec.hid_all[torch.tensor(rows, device=params.device)]
     fc = "model.text_hidden_fcs.0."
     h = ops.linear(h, params.w(fc + "0"), params.b(fc + "0"), act=ops.ACT_RELU)
     return out_ids, ops.linear(h, params.w(fc + "2"), params.b(fc + "2"))
