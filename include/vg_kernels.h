@@ -62,7 +62,9 @@ int vg_init(int device);
 int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
             void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
             const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
-            int in_dtype, int out_dtype, int act, vg_stream_t stream);
+            int in_dtype, int out_dtype, int act, int a_op, vg_stream_t stream);
+/* a_op = 1 (M <= 16 only): A is the packed gate|up activation [M, 2K] and the contraction operand is
+ * silu(gate)*up formed on the fly — HF LlamaMLP down_proj(act(gate)*up) without materialising the product. */
 
 /* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
  * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)

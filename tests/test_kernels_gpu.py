@@ -51,6 +51,44 @@ def test_gemm(cuda, dtype, M, N, K):
         close(y, ref.linear(x, w, out_dtype=torch.float32), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [1, 3, 40])
+def test_gemm_fused_swiglu_operand(cuda, dtype, M):
+    """down_proj(silu(gate)*up) with the product formed inside the skinny kernel (M <= 16) or by vg_swiglu (M > 16)."""
+    from videoglamm_amd import ops
+    F_, N = 352, 96
+    gu, w, res = rnd(M, 2 * F_, dtype=dtype, seed=1), rnd(N, F_, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
+    y = ops.linear(gu.to(cuda), w.to(cuda), residual=res.to(cuda), swiglu_in=True)
+    close(y, ref.linear(gu, w, residual=res, swiglu_in=True), **tol(dtype, F_))
+
+
+def test_decode_step_kernels(cuda):
+    """rope+kv-append, device-indexed attention length, row store and counter bump used by the graph-replayed decode."""
+    from videoglamm_amd import ops
+    H, Hkv, D, max_len, pos = 8, 2, 64, 640, 517
+    for dtype in DT:
+        qkv = rnd(1, (H + 2 * Hkv) * D, dtype=dtype, seed=1)
+        kc, vc = rnd(max_len, Hkv, D, dtype=dtype, seed=2), rnd(max_len, Hkv, D, dtype=dtype, seed=3)
+        ang = torch.arange(max_len)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, D, 2).float() / D)))[None]
+        cos, sin = ang.cos(), ang.sin()
+        pos_dev = torch.tensor([pos], dtype=torch.int32)
+        g_qkv, g_kc, g_vc, g_pos = qkv.to(cuda), kc.to(cuda), vc.to(cuda), pos_dev.to(cuda)
+        ops.rope_kv_append_(g_qkv, g_kc, g_vc, cos.to(cuda), sin.to(cuda), H, Hkv, D, 0, g_pos)
+        r_qkv, r_kc, r_vc = qkv.clone(), kc.clone(), vc.clone()
+        ref.rope_kv_append_(r_qkv, r_kc, r_vc, cos, sin, H, Hkv, D, 0, pos_dev)
+        close(g_qkv, r_qkv, **tol(dtype)); close(g_kc, r_kc, **tol(dtype)); close(g_vc, r_vc, **tol(dtype))
+        q = g_qkv[:, : H * D].view(1, 1, H, D)
+        o = ops.attention_decode(q, g_kc, g_vc, g_pos, D ** -0.5)
+        t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+        close(o, ref.attention_decode(r_qkv[:, : H * D].view(1, 1, H, D), r_kc, r_vc, pos_dev, D ** -0.5), **t)
+        hid = torch.zeros(max_len, 32, dtype=dtype, device=cuda)
+        row = rnd(1, 32, dtype=dtype, seed=4)
+        ops.store_row_(row.to(cuda), hid, g_pos)
+        assert torch.equal(hid[pos].cpu(), row[0]) and float(hid.float().abs().sum()) == float(row.float().abs().sum())
+        ops.add_int_(g_pos, 1)
+        assert int(g_pos[0]) == pos + 1
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops

@@ -296,7 +296,10 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
              v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace, skv_dev};
   hipStream_t st = (hipStream_t)stream;
-  int rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
+  // <= 32 query rows (decode step, mask-decoder tokens): one wave per workgroup instead of 3 idle ones
+  int rc;
+  if (Sq <= 32) rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 1>(p, st) : dispatch_dp<float, 32, 1>(p, st);
+  else rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
   if (rc != VG_OK || nsplit == 1) return rc;
   dim3 grid(Sq, Hq, B);
   if (dtype == VG_BF16) attn_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(p);

@@ -15,6 +15,7 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, ldr, sA, sW, sC, sR;
   int M, N, K, act;
   int vec_out;  // C/R rows are 16-byte aligned: the epilogue stores whole 16-byte chunks
+  int a_op;     // 1: A holds gate|up ([M,2K]); the operand is silu(gate)*up formed on the fly (skinny path only)
 };
 
 template <typename T> struct MmaOp;
@@ -216,6 +217,31 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   float acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  if (p.a_op == 1) {
+    // fused SwiGLU operand (HF LlamaMLP): a[k] = bf16(silu(gate[k])) * up[k], gate|up packed as A[m, 0:K | K:2K]
+    for (int k = lane * KPC; k < p.K; k += 64 * KPC) {
+      const u32x4_t wv = *(const u32x4_t*)(Wr + k);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m < p.M) {
+          const T* ar = A + (int64_t)m * p.lda;
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) {
+            float g = vg_elt<T>::ld(ar + k + e);
+            const float u = vg_elt<T>::ld(ar + p.K + k + e);
+            g = g / (1.0f + __expf(-g));
+            if (sizeof(T) == 2) g = bf2f(f2bf(g));
+            float a = g * u;
+            if (sizeof(T) == 2) a = bf2f(f2bf(a));
+            s = fmaf(a, vg_elt<T>::ld(Wr + k + e), s);
+          }
+          acc[m] += s;
+        }
+      }
+      (void)wv;
+    }
+  } else {
   for (int k = lane * KPC; k < p.K; k += 64 * KPC) {
     const u32x4_t wv = *(const u32x4_t*)(Wr + k);
 #pragma unroll
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         acc[m] += dot16<T>(wv, av);
       }
     }
+  }
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
@@ -269,10 +296,11 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
 extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
                        void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
                        const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
-                       int in_dtype, int out_dtype, int act, vg_stream_t stream) {
+                       int in_dtype, int out_dtype, int act, int a_op, vg_stream_t stream) {
   VG_CHECK(A && W && C, VG_ERR_ARG, "vg_gemm: null pointer");
   VG_CHECK(M >= 0 && N > 0 && K > 0 && batch >= 1, VG_ERR_ARG, "vg_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   if (M == 0) return VG_OK;
+  VG_CHECK(a_op == 0 || (a_op == 1 && M <= 16), VG_ERR_ARG, "vg_gemm: a_op=1 (fused SwiGLU operand) needs M <= 16");
   const int kpc = in_dtype == VG_BF16 ? 8 : 4;
   VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_gemm: bad in_dtype %d", in_dtype);
   VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && sA % kpc == 0 && sW % kpc == 0, VG_ERR_ARG,
@@ -281,7 +309,7 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   const int ovec = out_dtype == VG_BF16 ? 8 : 4;
   const int vec_out = (ldc % ovec == 0) && (sC % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                       (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
-  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out};
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op};
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);

@@ -47,6 +47,11 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
   const TI* xr = x + row * ldx;
   TO* yr = y + row * ldy;
   auto reduce = [&](float v) {
+    if constexpr (TPR == 16) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      return v;
+    }
     v = wave_sum(v);
     if constexpr (TPR == 256) {
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -111,6 +116,9 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
     dim3 grid((unsigned)rows);
     if (vec) norm_kernel<TI, TO, RMS, 256, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
     else norm_kernel<TI, TO, RMS, 256, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
+  } else if (vec && C <= 512) {   // short rows (Hiera stage 1-2: C = 144 / 288): 16 lanes per row, 16 rows per workgroup
+    dim3 grid((unsigned)((rows + 15) / 16));
+    norm_kernel<TI, TO, RMS, 16, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   } else {
     dim3 grid((unsigned)((rows + 3) / 4));
     if (vec) norm_kernel<TI, TO, RMS, 64, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);

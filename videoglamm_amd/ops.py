@@ -56,12 +56,15 @@ def _rows2d(x):
     return x2, x2.shape[0], K
 
 
-def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None):
-    """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K)."""
+def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, swiglu_in=False):
+    """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K).
+    swiglu_in: x is the packed gate|up activation [..., 2K]; the operand is silu(gate)*up (fused for <= 16 rows)."""
     lib = _lib.load()
+    if swiglu_in and x.numel() // x.shape[-1] > 16:
+        x, swiglu_in = swiglu(x), False
     x2, M, lda = _rows2d(x)
     N, K = w.shape
-    assert x2.shape[1] == K, (x.shape, w.shape)
+    assert x2.shape[1] == (2 * K if swiglu_in else K), (x.shape, w.shape)
     assert w.stride(1) == 1
     odt = out_dtype if out_dtype is not None else x.dtype
     if out is None:
@@ -75,7 +78,7 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
         assert Mr == M and r2.shape[1] == N
     assert _dt(w) == _dt(x2)
     rc = lib.vg_gemm(_p(x2), lda, 0, _p(w), w.stride(0), 0, _p(o2), ldc, 0, _p(_f32(bias)), _p(_f32(gamma)),
-                     _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, _stream())
+                     _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, int(bool(swiglu_in)), _stream())
     _lib.check(rc, "vg_gemm")
     return out
 
@@ -91,7 +94,7 @@ def bmm_nt(a, w, out_dtype=None):
     odt = out_dtype if out_dtype is not None else a.dtype
     out = torch.empty(B, M, N, dtype=odt, device=a.device)
     rc = lib.vg_gemm(_p(a), K, M * K, _p(w), K, sW, _p(out), N, M * N, None, None, None, 0, 0, M, N, K, B,
-                     _dt(a), _dt(out), ACT_NONE, _stream())
+                     _dt(a), _dt(out), ACT_NONE, 0, _stream())
     _lib.check(rc, "vg_gemm(batched)")
     return out
 

@@ -165,7 +165,7 @@ class LlamaDecoder:
             x = ops.linear(o.view(S, self.D), P.w(l + "self_attn.o_proj"), residual=x)
             h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
             wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
-            x = ops.linear(ops.swiglu(ops.linear(h, wgu)), P.w(l + "mlp.down_proj"), residual=x)
+            x = ops.linear(ops.linear(h, wgu), P.w(l + "mlp.down_proj"), residual=x, swiglu_in=True)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
 
     def forward(self, x):
