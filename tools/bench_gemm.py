@@ -24,6 +24,8 @@ for name, M, N, K in shapes:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ms = t(lambda: ops.linear(a, w, out=out))
     print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s")
+if os.environ.get('VG_BENCH_ONLY') == 'gemm':
+    sys.exit(0)
 for name, B, H, Hkv, Sq, Skv, D, causal in [("llm prefill", 1, 32, 8, 1697, 1697, 128, True), ("llm decode", 1, 32, 8, 1, 1730, 128, True),
                                             ("iv2", 2, 16, 16, 1025, 1025, 88, False), ("clip", 8, 16, 16, 577, 577, 64, False),
                                             ("hiera win8", 8192, 2, 2, 64, 64, 72, False), ("hiera glob", 8, 8, 8, 4096, 4096, 72, False),

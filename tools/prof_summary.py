@@ -1,0 +1,23 @@
+"""Summarise a rocprofv3 rocpd database: per-kernel time (and PMC counters when present).
+usage: python tools/prof_summary.py <results.db> [steps]"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+cur = db.cursor()
+rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc"))
+tot = sum(r[2] for r in rows)
+print(f"total kernel time {tot:.2f} ms over {steps:g} step(s) = {tot / steps:.2f} ms/step")
+print(f"{'ms/step':>10} {'launches/step':>14} {'avg us':>10}  kernel")
+for r in rows[:30]:
+    print(f"{r[2] / steps:10.2f} {r[1] / steps:14.1f} {r[3]:10.1f}  {r[0][:110]}")
+try:
+    pm = list(cur.execute("select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
+                          "group by k.name, p.counter_name order by 4 desc limit 20"))
+    if pm:
+        print("\nPMC (sum over dispatches, avg per dispatch):")
+        for r in pm:
+            print(f"{r[1]:>14} n={r[2]:6d} sum={r[3]:.4g} avg={r[4]:.4g}  {r[0][:90]}")
+except sqlite3.Error as e:
+    print("no PMC tables:", e)

@@ -20,6 +20,8 @@ struct AttnArgs {
   int nsplit, split_len;   // split-KV: blockIdx.x = q_tile * nsplit + split; partials go to `part`
   float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
   const int* skv_dev;      // optional: Skv = *skv_dev + Sq read on the device (graph-replayable decode step)
+  int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
+                           // (row = g*Sq + q) of ONE query tile, so K/V are staged once per KV head (G*Sq <= tile)
 };
 
 template <typename T> struct AMma;
@@ -86,25 +88,30 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int split = blockIdx.x % p.nsplit;
   const int q0 = (blockIdx.x / p.nsplit) * BQ, head = blockIdx.y, b = blockIdx.z;
-  const int kvh = head / (p.Hq / p.Hkv);
+  const int G = p.Hq / p.Hkv;
+  const int kvh = p.fold ? head : head / G;
   const int D = p.D, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
-  const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
+  const int nrow = p.fold ? G * Sq : Sq;   // valid rows of the query tile space
+  const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (p.fold ? 0 : (int64_t)head * p.q_sh);
   const T* Kg = (const T*)p.K + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
   const T* Vg = (const T*)p.V + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 
   for (int idx = tid; idx < BQ * CPR; idx += NT) {
     const int row = idx / CPR, c = idx - row * CPR;
-    const int q = q0 + row;
+    const int qr = q0 + row;
     u32x4_t v = zero4;
-    if (q < Sq && c * KPC < D) v = *(const u32x4_t*)(Qg + (int64_t)q * p.q_ss + c * KPC);
+    if (qr < nrow && c * KPC < D) {
+      const int64_t qo = p.fold ? (int64_t)(head * G + qr / Sq) * p.q_sh + (int64_t)(qr % Sq) * p.q_ss : (int64_t)qr * p.q_ss;
+      v = *(const u32x4_t*)(Qg + qo + c * KPC);
+    }
     *(u32x4_t*)(Qs + row * RS + c * 16) = v;
   }
 
   const int off = Skv - Sq;
   int kv_end = Skv;
   if (p.causal) {
-    const int lim = q0 + BQ + off;  // keys >= lim are invisible to every query of this block
+    const int lim = (p.fold ? Sq : q0 + BQ) + off;  // keys >= lim are invisible to every query of this block
     kv_end = lim < Skv ? (lim > 0 ? lim : 0) : Skv;
   }
 
@@ -116,7 +123,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
   const int q_local = wave * 32 + l31;
-  const int q_idx = q0 + q_local;
+  const int q_row = q0 + q_local;                        // row in the tile space
+  const int q_idx = p.fold ? q_row % Sq : q_row;         // query position (causal mask)
+  const int q_head = p.fold ? head * G + q_row / Sq : head;
   const char* qrow = Qs + q_local * RS + h * 16;
 
   int kv_begin = 0;
@@ -198,8 +207,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   }
 
   if (p.nsplit > 1) {
-    if (q_idx < Sq) {
-      float* pp = p.part + ((((int64_t)b * p.Hq + head) * p.nsplit + split) * Sq + q_idx) * (D + 2);
+    if (q_row < nrow) {
+      float* pp = p.part + ((((int64_t)b * p.Hq + q_head) * p.nsplit + split) * Sq + q_idx) * (D + 2);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -211,9 +220,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     }
     return;
   }
-  if (q_idx < Sq) {
+  if (q_row < nrow) {
     const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
-    T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)q_idx * p.o_ss;
+    T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)q_head * p.o_sh + (int64_t)q_idx * p.o_ss;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -234,27 +243,39 @@ static int launch_attn(const AttnArgs& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(((p.Sq + NW * 32 - 1) / (NW * 32)) * p.nsplit, p.Hq, p.B);
+  if (p.fold) grid = dim3(p.nsplit, p.Hkv, p.B);
   attn_kernel<T, DP, BKV, NW><<<grid, NW * 64, lds, st>>>(p);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
 
-// merge the split-KV partials: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}
+// merge the split-KV partials: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}.  One workgroup per (q, head, b):
+// the per-split weights are formed once in LDS, then the D columns are accumulated with independent (pipelined) loads.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p) {
-  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, D = p.D;
-  const float* base = p.part + (((int64_t)b * p.Hq + head) * p.nsplit * p.Sq + q) * (D + 2);
+  __shared__ float wgt[64];
+  __shared__ float s_l;
+  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, D = p.D, ns = p.nsplit;
+  const float* base = p.part + (((int64_t)b * p.Hq + head) * ns * p.Sq + q) * (D + 2);
   const int64_t sstride = (int64_t)p.Sq * (D + 2);
-  float m = -INFINITY;
-  for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, base[s * sstride + D]);
-  const float ms = (m == -INFINITY) ? 0.f : m;
-  float l = 0.f;
-  for (int s = 0; s < p.nsplit; ++s) l += base[s * sstride + D + 1] * __expf(base[s * sstride + D] - ms);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (threadIdx.x < 64) {
+    const int s = threadIdx.x;
+    const float ms = s < ns ? base[s * sstride + D] : -INFINITY;
+    const float ls = s < ns ? base[s * sstride + D + 1] : 0.f;
+    const float m = wave_max(ms);
+    const float msafe = (m == -INFINITY) ? 0.f : m;
+    const float w = __expf(ms - msafe);
+    wgt[s] = w;
+    const float l = wave_sum(ls * w);
+    if (s == 0) s_l = l;
+  }
+  __syncthreads();
+  const float inv = s_l > 0.f ? 1.0f / s_l : 0.f;
   T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)q * p.o_ss;
   for (int d = threadIdx.x; d < D; d += 256) {
     float acc = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) acc += base[s * sstride + d] * __expf(base[s * sstride + D] - ms);
+#pragma unroll 8
+    for (int s = 0; s < ns; ++s) acc += base[s * sstride + d] * wgt[s];
     vg_elt<T>::st(Og + d, acc * inv);
   }
 }
@@ -275,6 +296,7 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
                                     int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
                                     int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
                                     const int* skv_dev, vg_stream_t stream) {
+  VG_CHECK(nsplit <= 64, VG_ERR_ARG, "vg_attention_splitkv: nsplit must be <= 64");
   VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_attention: null pointer");
   VG_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Sq >= 0 && Skv > 0, VG_ERR_ARG,
            "vg_attention: bad shape B=%d Hq=%d Hkv=%d Sq=%d Skv=%d", B, Hq, Hkv, Sq, Skv);
@@ -294,12 +316,15 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
              "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(D+2) floats)");
   }
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
-             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace, skv_dev};
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace, skv_dev, 0};
+  // fold the G query heads of a KV head into one query tile when they all fit (decode: G*Sq = 4 rows): K/V staged
+  // once per KV head instead of once per query head
+  const int tile_rows = dtype == VG_BF16 ? 128 : 64;
+  if (Hq > Hkv && (Hq / Hkv) * Sq <= tile_rows) p.fold = 1;
   hipStream_t st = (hipStream_t)stream;
-  // <= 32 query rows (decode step, mask-decoder tokens): one wave per workgroup instead of 3 idle ones
-  int rc;
-  if (Sq <= 32) rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 1>(p, st) : dispatch_dp<float, 32, 1>(p, st);
-  else rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
+  // (measured: a 1-wave workgroup for <= 32 query rows is SLOWER — 50 vs 31 us per decode launch — because the
+  // K/V tile staging, not the MFMA work, dominates a few-row block and 64 threads stage 4x slower than 256)
+  int rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
   if (rc != VG_OK || nsplit == 1) return rc;
   dim3 grid(Sq, Hq, B);
   if (dtype == VG_BF16) attn_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(p);

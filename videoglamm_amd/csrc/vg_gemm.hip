@@ -9,6 +9,7 @@
 //   gemm_skinny_kernel M <= 16 rows (LLM decode GEMV, mask-decoder token MLPs): one wave per output
 //                      column streams its W row once with 16-byte loads; HBM-bound by construction.
 #include "vg_common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
   const void* A; const void* W; void* C; const float* bias; const float* gamma; const void* R;
@@ -33,13 +34,21 @@ template <> struct MmaOp<float> {
   }
 };
 
-constexpr int GBM = 128, GBN = 128, GROWB = 144, GTILEB = 128 * GROWB;  // bytes
+constexpr int GBM = 128, GBN = 128;
 
-template <typename T, typename TO>
+// BKB = bytes of K per step (128: 64 bf16 / 32 f32; 64: half of that, half the LDS -> more workgroups per CU).
+// PF  = register prefetch depth: 1 = next tile loaded while computing the current one; 2 = two tiles in flight
+//       (tile t+2 is issued before tile t is computed and written to LDS a full iteration later).
+template <typename T, typename TO, int BKB, int PF>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);   // elements per 16-byte chunk
-  constexpr int BK = 128 / sizeof(T);   // K elements per step
+  constexpr int KPC = 16 / sizeof(T);     // elements per 16-byte chunk
+  constexpr int BK = BKB / sizeof(T);     // K elements per step
+  constexpr int ROWB = BKB + 16;          // padded LDS row: conflict-free ds_read_b128 fragments
+  constexpr int TILEB = 128 * ROWB;
+  constexpr int CPR = BKB / 16;           // 16-byte chunks per row
+  constexpr int NCH = 128 * CPR / 256;    // chunks per thread per operand
+  constexpr int NG = BKB / 32;            // MFMA k-groups per step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
   // XCD-aware tile order (guide T1): workgroup id b lands on XCD b % 8; give every XCD a contiguous run of the
@@ -52,11 +61,11 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* W = (const T*)p.W + (int64_t)bz * p.sW;
 
-  u32x4_t ra[4], rb[4];
-  auto gload = [&](int kt) {
+  u32x4_t ra0[NCH], rb0[NCH], ra1[PF == 2 ? NCH : 1], rb1[PF == 2 ? NCH : 1];
+  auto gload = [&](int kt, u32x4_t* ra, u32x4_t* rb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
       const int k = kt * BK + kc * KPC;
       const int gm = bm * GBM + row, gn = bn * GBN + row;
       u32x4_t z = {0u, 0u, 0u, 0u};
@@ -64,14 +73,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
       rb[i] = (gn < N && k < K) ? *(const u32x4_t*)(W + (int64_t)gn * p.ldw + k) : z;
     }
   };
-  auto swrite = [&](int buf) {
-    char* sa = smem + buf * 2 * GTILEB;
-    char* sb = sa + GTILEB;
+  auto swrite = [&](int buf, const u32x4_t* ra, const u32x4_t* rb) {
+    char* sa = smem + buf * 2 * TILEB;
+    char* sb = sa + TILEB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-      *(u32x4_t*)(sa + row * GROWB + kc * 16) = ra[i];
-      *(u32x4_t*)(sb + row * GROWB + kc * 16) = rb[i];
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
+      *(u32x4_t*)(sa + row * ROWB + kc * 16) = ra[i];
+      *(u32x4_t*)(sb + row * ROWB + kc * 16) = rb[i];
     }
   };
 
@@ -83,28 +92,49 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const char* sa = smem + buf * 2 * GTILEB + (wm * 64 + l31) * GROWB + h * 16;
-    const char* sb = smem + buf * 2 * GTILEB + GTILEB + (wn * 64 + l31) * GROWB + h * 16;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * 2 * TILEB + (wm * 64 + l31) * ROWB + h * 16;
+    const char* sb = smem + buf * 2 * TILEB + TILEB + (wn * 64 + l31) * ROWB + h * 16;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NG; ++g) {
       u32x4_t a0 = *(const u32x4_t*)(sa + g * 32);
-      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * GROWB + g * 32);
+      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * ROWB + g * 32);
       u32x4_t b0 = *(const u32x4_t*)(sb + g * 32);
-      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * GROWB + g * 32);
+      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * ROWB + g * 32);
       MmaOp<T>::run(a0, b0, acc[0][0]);
       MmaOp<T>::run(a0, b1, acc[0][1]);
       MmaOp<T>::run(a1, b0, acc[1][0]);
       MmaOp<T>::run(a1, b1, acc[1][1]);
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
-    __syncthreads();
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0, ra0, rb0);
+  swrite(0, ra0, rb0);
+  if constexpr (PF == 2) {
+    if (nk > 1) gload(1, ra1, rb1);
+  }
+  __syncthreads();
+  if constexpr (PF == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1, ra0, rb0);
+      compute(buf);
+      if (kt + 1 < nk) swrite(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) gload(kt + 2, ra0, rb0);     // even tile kt lives in buf 0; tile kt+1 waits in set 1
+      compute(0);
+      if (kt + 1 < nk) swrite(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) gload(kt + 3, ra1, rb1);     // odd tile kt+1 in buf 1; tile kt+2 waits in set 0
+      compute(1);
+      if (kt + 2 < nk) swrite(0, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
@@ -206,6 +236,16 @@ template <> __device__ __forceinline__ float dot16<bf16_t>(const u32x4_t& a, con
   return s;
 }
 
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+}
+
 template <typename T, typename TO, int MT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   constexpr int KPC = 16 / sizeof(T);
@@ -225,16 +265,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
       for (int m = 0; m < MT; ++m) {
         if (m < p.M) {
           const T* ar = A + (int64_t)m * p.lda;
+          const u32x4_t gv = *(const u32x4_t*)(ar + k), uv = *(const u32x4_t*)(ar + p.K + k);
+          float gf[KPC], uf[KPC], wf[KPC];
+          unpack16<T>(gv, gf); unpack16<T>(uv, uf); unpack16<T>(wv, wf);
           float s = 0.f;
 #pragma unroll
           for (int e = 0; e < KPC; ++e) {
-            float g = vg_elt<T>::ld(ar + k + e);
-            const float u = vg_elt<T>::ld(ar + p.K + k + e);
-            g = g / (1.0f + __expf(-g));
+            float g = gf[e] / (1.0f + __expf(-gf[e]));
             if (sizeof(T) == 2) g = bf2f(f2bf(g));
-            float a = g * u;
+            float a = g * uf[e];
             if (sizeof(T) == 2) a = bf2f(f2bf(a));
-            s = fmaf(a, vg_elt<T>::ld(Wr + k + e), s);
+            s = fmaf(a, wf[e], s);
           }
           acc[m] += s;
         }
@@ -280,14 +321,24 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     else if (p.M <= 8) gemm_skinny_kernel<T, TO, 8><<<grid, 256, 0, st>>>(p);
     else gemm_skinny_kernel<T, TO, 16><<<grid, 256, 0, st>>>(p);
   } else {
-    static bool attr_set = false;
-    const int lds = 4 * GTILEB;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
+    // main-loop variant: VG_GEMM_VARIANT = "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} (A/B knob;
+    // the default is the measured best)
+    static int variant = -1;
+    if (variant < 0) {
+      const char* e = getenv("VG_GEMM_VARIANT");
+      variant = e ? atoi(e) : 1281;
+      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
     }
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
-    gemm_tile_kernel<T, TO><<<grid, 256, lds, st>>>(p);
+    // the fp32 epilogue staging needs 4 x 64 x 68 floats = 69632 B of LDS whatever the K step
+    const int lds128 = 4 * 128 * 144, lds64 = 4 * 64 * 68 * 4;
+    if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(p);
+    else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(p);
+    else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(p);
+    else gemm_tile_kernel<T, TO, 128, 1><<<grid, 256, lds128, st>>>(p);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;

@@ -61,6 +61,52 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
     }
     return v;
   };
+  if constexpr (VEC) {
+    if (C <= TPR * NV * 4) {
+      // the whole row fits in registers (<= 4 x 16-byte chunks per lane): ONE global read, two in-register passes
+      float v[4][NV];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (t + j * TPR) * NV;
+        if (c < C) {
+          RowVec<TI>::ld(xr + c, v[j]);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) s += v[j][e];
+        }
+      }
+      const float mean_r = RMS ? 0.f : reduce(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (t + j * TPR) * NV;
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < NV; ++e) { const float d = v[j][e] - mean_r; q += d * d; }
+        }
+      }
+      const float rstd_r = rsqrtf(reduce(q) / (float)C + eps);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (t + j * TPR) * NV;
+        if (c < C) {
+          float o[NV];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) {
+            float n = (v[j][e] - mean_r) * rstd_r;
+            if (RMS) {
+              if (sizeof(TI) == 2) n = bf2f(f2bf(n));
+              o[e] = w ? n * w[c + e] : n;
+            } else {
+              o[e] = n * (w ? w[c + e] : 1.f) + (b ? b[c + e] : 0.f);
+            }
+          }
+          row_store<TO, NV>(yr + c, o);
+        }
+      }
+      return;
+    }
+  }
   float mean = 0.f;
   if (!RMS) {
     float s = 0.f;
@@ -112,7 +158,7 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
   const bool vec = (C % NV == 0) && (ldx % NV == 0) && (ldy % NV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
   const TI* xi = (const TI*)x;
   TO* yo = (TO*)y;
-  if (rows < 1024) {
+  if (rows < 1024 || (vec && C > 64 * NV * 4)) {   // few rows, or rows too long for one wave's registers
     dim3 grid((unsigned)rows);
     if (vec) norm_kernel<TI, TO, RMS, 256, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
     else norm_kernel<TI, TO, RMS, 256, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);

@@ -162,9 +162,14 @@ __global__ __launch_bounds__(256) void window_part_kernel(const void* src_, void
       const int wy = (int)(r % nH);
       const int b = (int)(r / nH);
       const int yy = wy * ws + rr, xx = wx * ws + cc;
-      float v = 0.f;
-      if (yy < H && xx < W) v = ld_any(src_, (((int64_t)b * H + yy) * W + xx) * C + c, dt);
-      st_any(dst_, i, dt, v);
+      const bool in = yy < H && xx < W;
+      const int64_t si = (((int64_t)b * H + yy) * W + xx) * C + c;
+      if (dt == 2) {  // 16-byte chunk mode: "C" counts chunks
+        u32x4_t z = {0u, 0u, 0u, 0u};
+        ((u32x4_t*)dst_)[i] = in ? ((const u32x4_t*)src_)[si] : z;
+      } else {
+        st_any(dst_, i, dt, in ? ld_any(src_, si, dt) : 0.f);
+      }
     }
   } else {
     const int64_t n = (int64_t)B * H * W * C;
@@ -176,13 +181,16 @@ __global__ __launch_bounds__(256) void window_part_kernel(const void* src_, void
       const int b = (int)(r / H);
       const int wy = yy / ws, rr = yy % ws, wx = xx / ws, cc = xx % ws;
       const int64_t src = (((((int64_t)b * nH + wy) * nW + wx) * ws + rr) * ws + cc) * C + c;
-      st_any(dst_, i, dt, ld_any(src_, src, dt));
+      if (dt == 2) ((u32x4_t*)dst_)[i] = ((const u32x4_t*)src_)[src];
+      else st_any(dst_, i, dt, ld_any(src_, src, dt));
     }
   }
 }
 extern "C" int vg_window_partition(const void* x, void* win, int B, int H, int W, int C, int ws, int dtype, vg_stream_t stream) {
   VG_CHECK(x && win && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, VG_ERR_ARG, "vg_window_partition: bad args");
   const int nH = (H + ws - 1) / ws, nW = (W + ws - 1) / ws;
+  const int es = dtype == VG_BF16 ? 2 : 4;
+  if ((C * es) % 16 == 0 && (((uintptr_t)x | (uintptr_t)win) & 15) == 0) { C = C * es / 16; dtype = 2; }  // move whole 16-byte chunks
   window_part_kernel<<<sp_grid((int64_t)B * nH * nW * ws * ws * C), 256, 0, (hipStream_t)stream>>>(x, win, B, H, W, C, ws, nH, nW, dtype, 0);
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -190,6 +198,8 @@ extern "C" int vg_window_partition(const void* x, void* win, int B, int H, int W
 extern "C" int vg_window_unpartition(const void* win, void* x, int B, int H, int W, int C, int ws, int dtype, vg_stream_t stream) {
   VG_CHECK(x && win && B > 0 && H > 0 && W > 0 && C > 0 && ws > 0, VG_ERR_ARG, "vg_window_unpartition: bad args");
   const int nH = (H + ws - 1) / ws, nW = (W + ws - 1) / ws;
+  const int es = dtype == VG_BF16 ? 2 : 4;
+  if ((C * es) % 16 == 0 && (((uintptr_t)x | (uintptr_t)win) & 15) == 0) { C = C * es / 16; dtype = 2; }
   window_part_kernel<<<sp_grid((int64_t)B * H * W * C), 256, 0, (hipStream_t)stream>>>(win, x, B, H, W, C, ws, nH, nW, dtype, 1);
   VG_LAUNCH_CHECK();
   return VG_OK;

@@ -130,7 +130,7 @@ def attention_decode(q, k_cache, v_cache, pos_dev, scale):
     _, Sq, Hq, D = q.shape
     max_len, Hkv = k_cache.shape[0], k_cache.shape[1]
     out = torch.empty(1, Sq, Hq, D, dtype=q.dtype, device=q.device)
-    nsplit = max(1, min(64, -(-max_len // 256)))
+    nsplit = max(1, min(64, -(-max_len // 64)))   # one 64-key tile per workgroup x Hkv KV heads (GQA-folded rows)
     ws = torch.empty(Hq * nsplit * Sq * (D + 2), dtype=torch.float32, device=q.device)
     rc = lib.vg_attention_splitkv(_p(q), _p(k_cache), _p(v_cache), _p(out), 1, Hq, Hkv, Sq, max_len, D,
                                   q.stride(0), q.stride(1), q.stride(2), 0, k_cache.stride(0), k_cache.stride(1),
