@@ -63,8 +63,8 @@ int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, 
             void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
             const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
             int in_dtype, int out_dtype, int act, int a_op, vg_stream_t stream);
-/* a_op = 1 (M <= 16 only): A is the packed gate|up activation [M, 2K] and the contraction operand is
- * silu(gate)*up formed on the fly — HF LlamaMLP down_proj(act(gate)*up) without materialising the product. */
+/* a_op = 1 (M <= 16 only): W holds 2N rows, gate rows then up rows; C[:, n] = silu(A·W[n]) * (A·W[N+n]) —
+ * HF LlamaMLP act(gate_proj(x)) * up_proj(x) with the SwiGLU done in the GEMV epilogue (decode path). */
 
 /* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
  * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)

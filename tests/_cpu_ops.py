@@ -25,9 +25,9 @@ def _act(x, act):
     return x
 
 
-def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, swiglu_in=False):
-    if swiglu_in:
-        x = swiglu(x)
+def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
+    if glu:
+        return swiglu(linear(x, w, bias))
     odt = out_dtype if out_dtype is not None else x.dtype
     y = x.float() @ w.float().t()
     if bias is not None:

@@ -54,13 +54,14 @@ def test_gemm(cuda, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M", [1, 3, 40])
-def test_gemm_fused_swiglu_operand(cuda, dtype, M):
-    """down_proj(silu(gate)*up) with the product formed inside the skinny kernel (M <= 16) or by vg_swiglu (M > 16)."""
+def test_gemm_glu_epilogue(cuda, dtype, M):
+    """silu(x.gate^T) * (x.up^T) with the SwiGLU in the skinny kernel's epilogue (M <= 16) or GEMM + vg_swiglu (M > 16)."""
     from videoglamm_amd import ops
-    F_, N = 352, 96
-    gu, w, res = rnd(M, 2 * F_, dtype=dtype, seed=1), rnd(N, F_, dtype=dtype, seed=2), rnd(M, N, dtype=dtype, seed=3)
-    y = ops.linear(gu.to(cuda), w.to(cuda), residual=res.to(cuda), swiglu_in=True)
-    close(y, ref.linear(gu, w, residual=res, swiglu_in=True), **tol(dtype, F_))
+    K, F_ = 328, 96
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(2 * F_, K, dtype=dtype, seed=2)
+    y = ops.linear(x.to(cuda), w.to(cuda), glu=True)
+    assert y.shape == (M, F_)
+    close(y, ref.linear(x, w, glu=True), **tol(dtype, K))
 
 
 def test_decode_step_kernels(cuda):

@@ -16,7 +16,7 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, ldr, sA, sW, sC, sR;
   int M, N, K, act;
   int vec_out;  // C/R rows are 16-byte aligned: the epilogue stores whole 16-byte chunks
-  int a_op;     // 1: A holds gate|up ([M,2K]); the operand is silu(gate)*up formed on the fly (skinny path only)
+  int a_op;     // 1: W holds gate|up rows ([2N,K]); output column n = silu(A.gate_n)*(A.up_n) (skinny path only)
 };
 
 template <typename T> struct MmaOp;
@@ -405,56 +405,64 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, f
   for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
 }
 
-template <typename T, typename TO, int MT>
+// M <= 16 rows.  One wave per output column n streams W[n,:] once (16-byte loads, 4 independent loads in flight per
+// lane) against the L1/L2-resident A rows.  a_op == 1: W is [2N, K] = gate rows | up rows and column n of the
+// output is silu(A.gate_n) * (A.up_n) (HF LlamaMLP act(gate(x)) * up(x)) — the SwiGLU never touches HBM.
+template <typename T, typename TO, int MT, bool GLU>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   constexpr int KPC = 16 / sizeof(T);
+  constexpr int UNR = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave, bz = blockIdx.z;
   if (n >= p.N) return;
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* Wr = (const T*)p.W + (int64_t)bz * p.sW + (int64_t)n * p.ldw;
-  float acc[MT];
+  const T* Wu = Wr + (int64_t)p.N * p.ldw;   // GLU only
+  float acc[MT], accu[GLU ? MT : 1];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  if (p.a_op == 1) {
-    // fused SwiGLU operand (HF LlamaMLP): a[k] = bf16(silu(gate[k])) * up[k], gate|up packed as A[m, 0:K | K:2K]
-    for (int k = lane * KPC; k < p.K; k += 64 * KPC) {
-      const u32x4_t wv = *(const u32x4_t*)(Wr + k);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (m < p.M) {
-          const T* ar = A + (int64_t)m * p.lda;
-          const u32x4_t gv = *(const u32x4_t*)(ar + k), uv = *(const u32x4_t*)(ar + p.K + k);
-          float gf[KPC], uf[KPC], wf[KPC];
-          unpack16<T>(gv, gf); unpack16<T>(uv, uf); unpack16<T>(wv, wf);
-          float s = 0.f;
+  for (int m = 0; m < (GLU ? MT : 1); ++m) accu[m] = 0.f;
+  const int step = 64 * KPC;
+  int k = lane * KPC;
+  for (; k + (UNR - 1) * step < p.K; k += UNR * step) {
+    u32x4_t wv[UNR], uv[GLU ? UNR : 1];
 #pragma unroll
-          for (int e = 0; e < KPC; ++e) {
-            float g = gf[e] / (1.0f + __expf(-gf[e]));
-            if (sizeof(T) == 2) g = bf2f(f2bf(g));
-            float a = g * uf[e];
-            if (sizeof(T) == 2) a = bf2f(f2bf(a));
-            s = fmaf(a, wf[e], s);
-          }
-          acc[m] += s;
+    for (int u = 0; u < UNR; ++u) {
+      wv[u] = *(const u32x4_t*)(Wr + k + u * step);
+      if constexpr (GLU) uv[u] = *(const u32x4_t*)(Wu + k + u * step);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < p.M) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const u32x4_t av = *(const u32x4_t*)(A + (int64_t)m * p.lda + k + u * step);
+          acc[m] += dot16<T>(wv[u], av);
+          if constexpr (GLU) accu[m] += dot16<T>(uv[u], av);
         }
       }
-      (void)wv;
     }
-  } else {
-  for (int k = lane * KPC; k < p.K; k += 64 * KPC) {
+  }
+  for (; k < p.K; k += step) {
     const u32x4_t wv = *(const u32x4_t*)(Wr + k);
+    u32x4_t uv = wv;
+    if constexpr (GLU) uv = *(const u32x4_t*)(Wu + k);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (m < p.M) {
         const u32x4_t av = *(const u32x4_t*)(A + (int64_t)m * p.lda + k);
         acc[m] += dot16<T>(wv, av);
+        if constexpr (GLU) accu[m] += dot16<T>(uv, av);
       }
     }
   }
-  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+  if constexpr (GLU) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) accu[m] = wave_sum(accu[m]);
+  }
   if (lane == 0) {
     TO* C = (TO*)p.C + (int64_t)bz * p.sC;
     const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
@@ -463,7 +471,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (m < p.M) {
-        float v = vg_act(acc[m] + bv, p.act) * gv;
+        float v;
+        if constexpr (GLU) {
+          float g = acc[m] + bv, u = accu[m] + (p.bias ? p.bias[p.N + n] : 0.f);
+          if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
+          g = g / (1.0f + __expf(-g));
+          if (sizeof(T) == 2) g = bf2f(f2bf(g));
+          v = g * u * gv;
+        } else {
+          v = vg_act(acc[m] + bv, p.act) * gv;
+        }
         if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
         vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
       }
@@ -471,14 +488,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   }
 }
 
+template <typename T, typename TO, bool GLU>
+static void launch_skinny(const GemmArgs& p, int batch, hipStream_t st) {
+  dim3 grid((p.N + 3) / 4, 1, batch);
+  if (p.M <= 1) gemm_skinny_kernel<T, TO, 1, GLU><<<grid, 256, 0, st>>>(p);
+  else if (p.M <= 4) gemm_skinny_kernel<T, TO, 4, GLU><<<grid, 256, 0, st>>>(p);
+  else if (p.M <= 8) gemm_skinny_kernel<T, TO, 8, GLU><<<grid, 256, 0, st>>>(p);
+  else gemm_skinny_kernel<T, TO, 16, GLU><<<grid, 256, 0, st>>>(p);
+}
+
 template <typename T, typename TO>
 static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
   if (p.M <= 16) {
-    dim3 grid((p.N + 3) / 4, 1, batch);
-    if (p.M <= 1) gemm_skinny_kernel<T, TO, 1><<<grid, 256, 0, st>>>(p);
-    else if (p.M <= 4) gemm_skinny_kernel<T, TO, 4><<<grid, 256, 0, st>>>(p);
-    else if (p.M <= 8) gemm_skinny_kernel<T, TO, 8><<<grid, 256, 0, st>>>(p);
-    else gemm_skinny_kernel<T, TO, 16><<<grid, 256, 0, st>>>(p);
+    if (p.a_op == 1) launch_skinny<T, TO, true>(p, batch, st);
+    else launch_skinny<T, TO, false>(p, batch, st);
   } else {
     // main-loop variant: VG_GEMM_VARIANT = "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} (A/B knob;
     // the default is the measured best)
@@ -524,7 +547,7 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   VG_CHECK(A && W && C, VG_ERR_ARG, "vg_gemm: null pointer");
   VG_CHECK(M >= 0 && N > 0 && K > 0 && batch >= 1, VG_ERR_ARG, "vg_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   if (M == 0) return VG_OK;
-  VG_CHECK(a_op == 0 || (a_op == 1 && M <= 16), VG_ERR_ARG, "vg_gemm: a_op=1 (fused SwiGLU operand) needs M <= 16");
+  VG_CHECK(a_op == 0 || (a_op == 1 && M <= 16), VG_ERR_ARG, "vg_gemm: a_op=1 (fused SwiGLU epilogue) needs M <= 16");
   const int kpc = in_dtype == VG_BF16 ? 8 : 4;
   VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_gemm: bad in_dtype %d", in_dtype);
   VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && sA % kpc == 0 && sW % kpc == 0, VG_ERR_ARG,

@@ -56,15 +56,18 @@ def _rows2d(x):
     return x2, x2.shape[0], K
 
 
-def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, swiglu_in=False):
+def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
     """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K).
-    swiglu_in: x is the packed gate|up activation [..., 2K]; the operand is silu(gate)*up (fused for <= 16 rows)."""
+    glu: w is [2N, K] = gate rows | up rows and y = silu(x @ gate^T) * (x @ up^T) — done in the GEMV epilogue for
+    <= 16 rows (decode), as GEMM + vg_swiglu otherwise."""
     lib = _lib.load()
-    if swiglu_in and x.numel() // x.shape[-1] > 16:
-        x, swiglu_in = swiglu(x), False
+    if glu and x.numel() // x.shape[-1] > 16:
+        return swiglu(linear(x, w, bias))
     x2, M, lda = _rows2d(x)
     N, K = w.shape
-    assert x2.shape[1] == (2 * K if swiglu_in else K), (x.shape, w.shape)
+    if glu:
+        N //= 2
+    assert x2.shape[1] == K, (x.shape, w.shape)
     assert w.stride(1) == 1
     odt = out_dtype if out_dtype is not None else x.dtype
     if out is None:
@@ -78,7 +81,7 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
         assert Mr == M and r2.shape[1] == N
     assert _dt(w) == _dt(x2)
     rc = lib.vg_gemm(_p(x2), lda, 0, _p(w), w.stride(0), 0, _p(o2), ldc, 0, _p(_f32(bias)), _p(_f32(gamma)),
-                     _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, int(bool(swiglu_in)), _stream())
+                     _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, int(bool(glu)), _stream())
     _lib.check(rc, "vg_gemm")
     return out
 

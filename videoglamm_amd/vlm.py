@@ -165,9 +165,8 @@ class LlamaDecoder:
             x = ops.linear(o.view(S, self.D), P.w(l + "self_attn.o_proj"), residual=x)
             h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
             wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
-            # (the fused-operand GEMV, linear(..., swiglu_in=True), measured slower: every output column's wave
-            # recomputes silu(gate)*up for the whole row — 122 vs 86+7 ms per clip — so SwiGLU stays a separate pass)
-            x = ops.linear(ops.swiglu(ops.linear(h, wgu)), P.w(l + "mlp.down_proj"), residual=x)
+            # gate|up in one GEMM; for the decode step the SwiGLU runs in that GEMV's epilogue (ops.linear(glu=True))
+            x = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
 
     def forward(self, x):
