@@ -40,21 +40,25 @@ class FrameSharder:
         """all-gather of the [N,256] [SEG] embeddings; every rank adopts rank 0's copy."""
         return self._all_gather(emb)[0]
 
-    def framewise(self, sam2, images_for_sam, emb, hw):
-        """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W]."""
+    def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None):
+        """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W].
+        frame_feats: optional precomputed Hiera features of THIS rank's frames ({frame: [3 levels]})."""
         emb = self.sync_seg_embeddings(emb)
         frames = self.my_frames(images_for_sam.shape[0])
-        logits, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames)
+        logits, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats)
         local = ops.threshold(logits)                      # [T/world, N, H, W] uint8, on device
         return torch.cat(self._all_gather(local), dim=0).cpu()
 
-    def hiera_all_frames(self, sam2, images_for_sam):
-        """frame-sharded Hiera + FPN, features all-gathered level by level -> list over frames of fpn lists."""
-        T = images_for_sam.shape[0]
+    def gather_frame_feats(self, local_feats, T):
+        """all-gather per-frame FPN features ({frame: [3 levels]} of this rank's frames) -> the same for all T frames."""
         frames = self.my_frames(T)
-        local = [sam2.forward_image(images_for_sam[t:t + 1]) for t in frames]
         levels = []
         for lv in range(3):
-            stacked = torch.cat([f[lv] for f in local], dim=0)      # [T/world, h, w, c]
+            stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0)      # [T/world, h, w, c]
             levels.append(torch.cat(self._all_gather(stacked), dim=0))
-        return [[levels[lv][t:t + 1] for lv in range(3)] for t in range(T)]
+        return {t: [levels[lv][t:t + 1] for lv in range(3)] for t in range(T)}
+
+    def hiera_all_frames(self, sam2, images_for_sam):
+        """frame-sharded Hiera + FPN, features all-gathered level by level -> {frame: fpn levels}."""
+        T = images_for_sam.shape[0]
+        return self.gather_frame_feats(sam2.hiera_frames(images_for_sam, self.my_frames(T)), T)

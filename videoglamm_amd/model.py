@@ -97,15 +97,28 @@ class VideoGLaMMForCausalLM:
         return self.inference_framewise(images, context_images, images_for_sam, input_ids, resize_list,
                                         original_size_list, max_new_tokens)
 
-    def _text_side(self, images, context_images, input_ids, max_new_tokens):
+    def _text_side(self, images, context_images, input_ids, max_new_tokens, after_prefill=None):
         assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
         ctx = context_images[0] if context_images is not None else None
         if ctx is None:
             raise NotImplementedError("single-image prompts (context_images=None) are outside the video hot path")
         out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
-                                forced_tokens=self.cfg.get("forced_tokens"))
+                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill)
         return out_ids.unsqueeze(0), emb
+
+    def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens):
+        """LLM side + Hiera features of this rank's frames.  Hiera is enqueued on the side stream right after the
+        prefill, so it runs underneath the decode loop (see _hiera_async)."""
+        frames = self.comm.my_frames(sam.shape[0]) if self.comm is not None else None
+        box = {}
+
+        def start():
+            box["feats"], box["join"] = self._hiera_async(sam, frames)
+
+        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens, after_prefill=start)
+        box["join"]()
+        return out_ids, emb, box["feats"]
 
     @staticmethod
     def _segments(mask_u8):
@@ -113,33 +126,52 @@ class VideoGLaMMForCausalLM:
         m = mask_u8.numpy().astype(bool)
         return {t: {k: m[t, k] for k in range(m.shape[1])} for t in range(m.shape[0])}
 
+    def _hiera_async(self, sam, frames=None):
+        """Hiera + FPN of the SAM frames on a side HIP stream.  It depends only on the pixels, not on the LLM, and it is
+        MFMA/LDS-bound while the LLM decode loop is an HBM-bound GEMV chain: the two overlap on the chip.  Returns
+        (features per frame, join) — call join() on the consuming stream before reading the features."""
+        if self.device.type != "cuda":
+            return self.sam2.hiera_frames(sam, frames), (lambda: None)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            feats = self.sam2.hiera_frames(sam, frames)
+
+        def join():
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            for f in feats.values():
+                for t in f:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+        return feats, join
+
     def inference_framewise(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
                             max_new_tokens=32):
         """R/model/VideoGLaMM.py:598-768 -> (output_ids [1,L+G], [ {frame: {obj: mask}} ])."""
-        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+        sam = images_for_sam[0].to(self.device)
+        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens)
         if emb.shape[0] == 0:
             # the reference dereferences `.shape` of a tuple here (VideoGLaMM.py:732): same exception type
             raise AttributeError("'tuple' object has no attribute 'shape'")
         hw = tuple(original_size_list[0])
-        sam = images_for_sam[0].to(self.device)
         if self.comm is not None:
-            masks = self.comm.framewise(self.sam2, sam, emb, hw)
+            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats)
         else:
-            logits, _ = self.sam2.framewise_branch(sam, emb, hw)
+            logits, _ = self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats)
             masks = ops.threshold(logits).cpu()
         return out_ids, [self._segments(masks)]
 
     def inference_video_branch(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
                                max_new_tokens=32):
         """R/model/VideoGLaMM.py:770-879; empty dict when no [SEG] was emitted (:840-842)."""
-        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+        sam = images_for_sam[0].to(self.device)
+        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens)
         if emb.shape[0] == 0:
             return out_ids, [{}]
         hw = tuple(original_size_list[0])
-        sam = images_for_sam[0].to(self.device)
-        feats = None
         if self.comm is not None:
             emb = self.comm.sync_seg_embeddings(emb)
-            feats = self.comm.hiera_all_frames(self.sam2, sam)
+            feats = self.comm.gather_frame_feats(feats, sam.shape[0])
         logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
         return out_ids, [self._segments(ops.threshold(logits).cpu())]

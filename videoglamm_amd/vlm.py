@@ -231,7 +231,7 @@ def splice(params, input_ids, visual):
 
 
 def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
-             forced_tokens=None):
+             forced_tokens=None, after_prefill=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
@@ -253,6 +253,9 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     ids = input_ids.tolist()
     if max_new_tokens > 0:
         dec.next_token(hidden)
+    if after_prefill is not None:
+        after_prefill()   # e.g. enqueue the (LLM-independent, MFMA-bound) Hiera pass on a side stream so that it
+        #                   overlaps the HBM-bound decode loop below
     for step in range(max_new_tokens):
         nxt = int(dec.tok_dev[0])
         if forced_tokens and step in forced_tokens:
