@@ -65,13 +65,16 @@ class GemmMeter:
     def __enter__(self):
         def timed(x, w, *a, **k):
             M = x.numel() // x.shape[-1]
-            if M <= 16:
+            if M <= 16 or k.get("glu"):   # skinny path, or the GLU wrapper (its inner GEMM call is metered)
                 return self.orig(x, w, *a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             y = self.orig(x, w, *a, **k)
             e1.record()
-            self.rec.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1))
+            N, K = w.shape[0] // (2 if k.get("glu") else 1), w.shape[1]
+            es = x.element_size()
+            nbytes = (M * K + w.shape[0] * K) * es + M * N * y.element_size() * (2 if k.get("residual") is not None else 1)
+            self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes))
             return y
         self.ops.linear = timed
         return self
@@ -83,7 +86,7 @@ class GemmMeter:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
-        return flops, ms, len(self.rec)
+        return flops, ms, len(self.rec), sum(r[3] for r in self.rec)
 
 
 def cpu_baseline(cfg, args):
@@ -209,12 +212,22 @@ def main():
         # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream
         with GemmMeter(ops) as gm:
             step()
-        flops, ms, n = gm.summary()
+        flops, ms, n, nbytes = gm.summary()
         peak = 2500.0
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summary):
+        # only quoted for the workload it was measured on (C1 framewise, 1 GPU)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_tile.json")
+        if os.path.exists(pmc) and world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8:
+            with open(pmc) as fh:
+                traffic = round(json.load(fh)["traffic_bytes_per_launch"])
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                           "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2), "kernel_ms_per_step": round(ms, 2)}
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                           "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
+                           "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
+                           "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                           "kernel_ms_per_step": round(ms, 2)}
     if rank == 0 and not args.no_cpu_baseline and not args.tiny:
         res["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:

@@ -101,6 +101,22 @@ int vg_rope_kv_append(void* qkv, int64_t ld, void* k_cache, void* v_cache, const
 int vg_store_row(const void* src, void* dst, int64_t n, const int* idx_dev, int idx_off, int dtype, vg_stream_t stream);
 int vg_add_int(int* p, int v, vg_stream_t stream);
 
+/* ---- fused single-token decode step (HF LlamaDecoderLayer.forward at q_len = 1, transformers==4.41.0; called per
+ * generated token from R/model/VideoGLaMM.py:616-628 / 789-801 via self.generate) ---------------------------------
+ * vg_decode_gemv: y[N] = f(x)[K] . W[N,K]^T (+ R[N]).  norm_w != NULL: f = LlamaRMSNorm(eps) with weight norm_w (fp32
+ *   copy of the norm weight) — input_layernorm / post_attention_layernorm fused into the q|k|v and gate|up projections.
+ *   glu != 0: W is [2N,K] = gate rows | up rows and y[n] = silu(x.gate_n) * (x.up_n) (LlamaMLP).  Row stride of W = ldw.
+ * vg_decode_attention: qkv = fused projection row [(H+2*Hkv)*D] of the new token at position p = *pos_dev.  Applies
+ *   rotate-half RoPE (cos/sin tables [max_len, D/2]) to q and k, appends k/v to the caches ([max_len,Hkv,D]) and writes
+ *   softmax(q.K[0..p]^T * scale).V[0..p] to out [H*D].  workspace: fp32, vg_decode_attention_ws_floats() floats, must be
+ *   zero-filled ONCE by the caller before the first launch (it ends with self-resetting per-head counters). */
+int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y, const float* norm_w, float eps,
+                   const void* R, int N, int K, int glu, int in_dtype, int out_dtype, vg_stream_t stream);
+int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_len);
+int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
+                        void* out, int H, int Hkv, int D, int max_len, float scale, const int* pos_dev,
+                        float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream);
+
 /* ---- row normalisation -------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, two-pass fp32): nn.LayerNorm and LayerNorm2d
  * (R/model/segment_anything_2/sam2/modeling/sam2_utils.py:137-149 — channels-last makes them identical).

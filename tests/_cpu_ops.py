@@ -175,6 +175,22 @@ def rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos0=0, pos_dev=
     return qkv
 
 
+def decode_gemv(x, w, norm_w=None, eps=0.0, residual=None, glu=False, out_dtype=None, out=None):
+    h = rmsnorm(x, norm_w, eps) if norm_w is not None else x
+    return linear(h.view(1, -1), w, residual=residual, out_dtype=out_dtype, out=out, glu=glu)
+
+
+def decode_attention_workspace(H, Hkv, D, max_len, device):
+    return torch.zeros(1)
+
+
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws):
+    qkv = qkv.clone()
+    rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, 0, pos_dev)
+    q = qkv[:, : H * D].view(1, 1, H, D)
+    return attention_decode(q, k_cache, v_cache, pos_dev, scale).view(1, H * D)
+
+
 def store_row_(src, dst, idx_dev, idx_off=0):
     dst.view(-1, src.numel())[int(idx_dev[0]) + idx_off] = src.reshape(-1)
     return dst

@@ -78,3 +78,25 @@ def test_host_graph_cpu(cpu_ops):
 def test_hip_parity_fp32(cuda):
     """mask logits within 1e-3 of the reference in fp32 mode (BASELINE.md target)."""
     run_checks(cuda, dict(rtol=1e-3, atol=1e-3))
+
+
+@pytest.mark.gpu
+def test_hip_bf16_mask_miou(cuda):
+    """bf16 performance mode: mask mIoU vs the reference (IoU = sum(and)/sum(or), R/eval_gcg_metrics.py:26-35) on the
+    framewise and video branches of the micro fixture.  Reported, and required to stay high."""
+    from videoglamm_amd.host import mask_iou
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+
+    fx = G.fixture("sam2_micro.npz")
+    T, N, H, W = [int(v) for v in fx["meta"]]
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_overrides())
+    m = SAM2(Params(sd, cuda, torch.bfloat16), "", G.sam2_cfg())
+    images = G.rnd((T, 3, m.S, m.S), 11).to(cuda)
+    text = G.rnd((N, 256), 12, 0.5).to(cuda)
+    fw, _ = m.framewise_branch(images, text, (H, W))
+    vid = m.video_branch(images, text, (H, W))
+    iou_fw = mask_iou((fw.cpu() > 0).numpy(), (fx["framewise_logits"] > 0).numpy())
+    iou_vid = mask_iou((vid.cpu() > 0).numpy(), (fx["video_logits"][:, :, 0] > 0).numpy())
+    print(f"bf16 mask mIoU vs reference: framewise {iou_fw:.4f}, video branch {iou_vid:.4f}")
+    assert iou_fw > 0.97 and iou_vid > 0.95, (iou_fw, iou_vid)

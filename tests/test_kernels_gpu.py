@@ -91,6 +91,59 @@ def test_decode_step_kernels(cuda):
         assert int(g_pos[0]) == pos + 1
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("N,K", [(96, 64), (6144, 4096), (33, 176), (4096, 14336), (257, 2048)])
+def test_decode_gemv(cuda, dtype, N, K):
+    """fused [RMSNorm ->] GEMV [-> SwiGLU] [+ residual] of one row vs the fp32 statement, and vs the unfused HIP path."""
+    from videoglamm_amd import ops
+    x = rnd(1, K, dtype=dtype, seed=1)
+    w = rnd(2 * N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    nw = (1.0 + 0.1 * rnd(K, seed=3)).to(dtype).float()
+    res = rnd(1, N, dtype=dtype, seed=4)
+    gx, gw, gnw, gres = x.to(cuda), w.to(cuda), nw.to(cuda), res.to(cuda)
+    t = tol(dtype, K)
+    close(ops.decode_gemv(gx, gw[:N]), ref.linear(x, w[:N]), **t)
+    close(ops.decode_gemv(gx, gw[:N], residual=gres), ref.linear(x, w[:N], residual=res), **t)
+    close(ops.decode_gemv(gx, gw[:N], norm_w=gnw, eps=1e-5), ref.linear(ref.rmsnorm(x, nw, 1e-5), w[:N]), **t)
+    close(ops.decode_gemv(gx, gw, norm_w=gnw, eps=1e-5, glu=True), ref.linear(ref.rmsnorm(x, nw, 1e-5), w, glu=True), **t)
+    close(ops.decode_gemv(gx, gw[:N], out_dtype=torch.float32), ref.linear(x, w[:N], out_dtype=torch.float32), **t)
+    # same arithmetic, same order as the stand-alone kernels: the fused launch must not move a single bit
+    assert torch.equal(ops.decode_gemv(gx, gw[:N], norm_w=gnw, eps=1e-5, residual=gres),
+                       ops.linear(ops.rmsnorm(gx, gnw, 1e-5), gw[:N], residual=gres))
+    assert torch.equal(ops.decode_gemv(gx, gw, glu=True), ops.linear(gx, gw, glu=True))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("H,Hkv,D,max_len", [(8, 2, 64, 640), (32, 8, 128, 2048), (4, 2, 16, 128), (4, 4, 96, 256), (8, 1, 32, 192)])
+def test_decode_attention(cuda, dtype, H, Hkv, D, max_len):
+    """fused RoPE + KV append + split attention + last-workgroup merge vs rope_kv_append + attention of the fp32
+    statement; replayed at several positions (split boundaries, first and last slot) on ONE workspace."""
+    from videoglamm_amd import ops
+    kc, vc = rnd(max_len, Hkv, D, dtype=dtype, seed=2), rnd(max_len, Hkv, D, dtype=dtype, seed=3)
+    ang = torch.arange(max_len)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, D, 2).float() / D)))[None]
+    cos, sin = ang.cos(), ang.sin()
+    g_cos, g_sin = cos.to(cuda), sin.to(cuda)
+    ws = ops.decode_attention_workspace(H, Hkv, D, max_len, cuda)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    for pos in (0, 1, 63, 64, 65, max_len // 2 + 5, max_len - 1):
+        qkv = rnd(1, (H + 2 * Hkv) * D, dtype=dtype, seed=10 + pos)
+        pos_dev = torch.tensor([pos], dtype=torch.int32)
+        g_kc, g_vc = kc.to(cuda), vc.to(cuda)
+        o = ops.decode_attention(qkv.to(cuda), g_kc, g_vc, g_cos, g_sin, H, Hkv, D, pos_dev.to(cuda), D ** -0.5, ws)
+        r_qkv, r_kc, r_vc = qkv.clone(), kc.clone(), vc.clone()
+        ref.rope_kv_append_(r_qkv, r_kc, r_vc, cos, sin, H, Hkv, D, 0, pos_dev)
+        close(o, ref.attention_decode(r_qkv[:, : H * D].view(1, 1, H, D), r_kc, r_vc, pos_dev, D ** -0.5).view(1, H * D), **t)
+        close(g_kc, r_kc, **tol(dtype)); close(g_vc, r_vc, **tol(dtype))
+        # the appended rows are bit-identical to the stand-alone rope+append kernel
+        u_qkv, u_kc, u_vc = qkv.to(cuda), kc.to(cuda), vc.to(cuda)
+        ops.rope_kv_append_(u_qkv, u_kc, u_vc, g_cos, g_sin, H, Hkv, D, 0, pos_dev.to(cuda))
+        if dtype == torch.bfloat16:   # (fp32: the compiler contracts x1*c - x2*s differently in the two kernels, 1 ulp)
+            assert torch.equal(g_kc, u_kc) and torch.equal(g_vc, u_vc)
+        else:
+            close(g_kc, u_kc, rtol=1e-6, atol=1e-6)
+    assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0   # arrival counters reset themselves
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops

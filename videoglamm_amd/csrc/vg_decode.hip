@@ -1,0 +1,662 @@
+// Single-token decode step of the LLM: one new row against the KV cache and against every
+// weight matrix.  The step is HBM-bound (all weights stream once per token) and latency-bound (a chain of ~9 dependent
+// launches per layer, each paying ~4-5 us of ramp on top of its bytes), so the kernels here exist to cut launches:
+//   decode_gemv_kernel  : [RMSNorm ->] x.W^T [-> SwiGLU] [+ residual]   (norm and GLU fused into the GEMV)
+//   decode_attn_kernel  : RoPE(q,k) + KV-cache append + split-KV attention + merge of the splits by the last
+//                         workgroup to finish (no separate rope / combine launches)
+// Arithmetic mirrors the stand-alone kernels (vg_rmsnorm, vg_gemm skinny path, vg_rope_kv_append) step for step.
+#include "vg_common.h"
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ void dec_unpack(const u32x4_t& v, float* f);
+template <> __device__ __forceinline__ void dec_unpack<float>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+}
+template <> __device__ __forceinline__ void dec_unpack<bf16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ u32x4_t dec_pack(const float* f);
+template <> __device__ __forceinline__ u32x4_t dec_pack<float>(const float* f) {
+  u32x4_t v = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+  return v;
+}
+template <> __device__ __forceinline__ u32x4_t dec_pack<bf16_t>(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (uint32_t)f2bf(f[2 * e]) | ((uint32_t)f2bf(f[2 * e + 1]) << 16);
+  return v;
+}
+template <typename T> __device__ __forceinline__ float dec_dot(const u32x4_t& a, const u32x4_t& b);
+template <> __device__ __forceinline__ float dec_dot<float>(const u32x4_t& a, const u32x4_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = fmaf(__uint_as_float(a[e]), __uint_as_float(b[e]), s);
+  return s;
+}
+template <> __device__ __forceinline__ float dec_dot<bf16_t>(const u32x4_t& a, const u32x4_t& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), s);
+    s = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), s);
+  }
+  return s;
+}
+template <typename T> __device__ __forceinline__ float dec_round(float v) { return v; }
+template <> __device__ __forceinline__ float dec_round<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMV.  x (one row, K elements) is staged once per workgroup into LDS — normalised on the way when norm_w is given
+// (HF LlamaRMSNorm: fp32 mean of squares, x*rstd cast to the activation dtype, then * weight) — and every wave streams
+// PAIRS of weight rows against it: rows (2i, 2i+1), or (i, N+i) = gate|up of output i when GLU.
+struct DecGemvArgs {
+  const void* x; const void* W; void* y; const float* nw; const void* R;
+  int N, K; int64_t ldw; float eps; int ppw;
+};
+
+template <typename T, typename TO, bool GLU>
+__device__ __forceinline__ void dec_gemv_store(const DecGemvArgs& p, int pi, float a0, float a1) {
+  const int n0 = GLU ? pi : 2 * pi, n1 = GLU ? p.N + pi : 2 * pi + 1;
+  TO* y = (TO*)p.y;
+  const TO* R = (const TO*)p.R;
+  if constexpr (GLU) {
+    float g = a0, u = a1;
+    if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
+    g = g / (1.0f + __expf(-g));
+    if (sizeof(T) == 2) g = bf2f(f2bf(g));
+    float v = g * u;
+    if (R) v += vg_elt<TO>::ld(R + n0);
+    vg_elt<TO>::st(y + n0, v);
+  } else {
+    float v = a0;
+    if (R) v += vg_elt<TO>::ld(R + n0);
+    vg_elt<TO>::st(y + n0, v);
+    if (n1 < p.N) {
+      v = a1;
+      if (R) v += vg_elt<TO>::ld(R + n1);
+      vg_elt<TO>::st(y + n1, v);
+    }
+  }
+}
+
+// Fast path, K = NB * 256 16-byte chunks.  A wave owns `ppw` consecutive pairs and walks them as one flat sequence of
+// batches (2 rows x 4 chunks per lane), software-pipelined two batches deep = 16 x 16-byte loads in flight per lane.
+// Everything the kernel must wait for is requested up front, oldest-needed first (vmcnt retires in order): x, the norm
+// weights, then both pipeline stages of W — the norm runs underneath the HBM round trip.  The loop body is branch-free
+// and issues no stores: results go to LDS and are written out (with the residual / SwiGLU epilogue) once at the end,
+// because on gfx9 a pending store makes every later vmcnt wait a full drain.
+constexpr int DEC_MAX_PPW = 64;
+
+template <typename T, typename TO, bool GLU, int NB>
+__global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+  __shared__ float red[4];
+  __shared__ float res[4][DEC_MAX_PPW][2];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int NWV = KPC / 4;     // float4 loads of norm weight per chunk
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t* xs = (u32x4_t*)dec_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npair = GLU ? p.N : (p.N + 1) / 2;
+  const int gw = blockIdx.x * 4 + wave;
+  const T* W = (const T*)p.W;
+  const int p0 = gw * p.ppw;
+  const int np = max(min(p0 + p.ppw, npair) - p0, 0);     // pairs of this wave
+  const int total = np * NB;
+
+  // ---- 1. every load up front
+  u32x4_t xr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) xr[i] = ((const u32x4_t*)p.x)[tid + 256 * i];
+  f32x4_t nwr[NB][NWV];
+  if (p.nw) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NWV; ++j) nwr[i][j] = ((const f32x4_t*)p.nw)[(tid + 256 * i) * NWV + j];
+  }
+  int ipi = p0, icb = 0;           // issue cursor (pair, batch within the pair)
+  u32x4_t va0[4], va1[4], vb0[4], vb1[4];
+  auto issue = [&](u32x4_t (&v0)[4], u32x4_t (&v1)[4]) {
+    const int pc = min(ipi, npair - 1);                      // clamped: the two prologue issues are unconditional
+    const int n0 = GLU ? pc : 2 * pc;
+    const int n1 = GLU ? p.N + pc : min(2 * pc + 1, p.N - 1);
+    const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw) + icb * 256 + lane;
+    const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw) + icb * 256 + lane;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v0[u] = __builtin_nontemporal_load(w0 + u * 64);
+      v1[u] = __builtin_nontemporal_load(w1 + u * 64);
+    }
+    if (++icb == NB) { icb = 0; ++ipi; }
+  };
+  issue(va0, va1);
+  issue(vb0, vb1);
+
+  // ---- 2. stage x (normalised) into LDS
+  {
+    float rstd = 1.f;
+    if (p.nw) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        float f[KPC];
+        dec_unpack<T>(xr[i], f);
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) ss += f[e] * f[e];
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        float f[KPC];
+        dec_unpack<T>(xr[i], f);
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) f[e] = dec_round<T>(f[e] * rstd) * nwr[i][e / 4][e % 4];
+        xr[i] = dec_pack<T>(f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) xs[tid + 256 * i] = xr[i];
+    __syncthreads();
+  }
+
+  // ---- 3. the stream
+  float a0 = 0.f, a1 = 0.f;
+  int cpl = 0, ccb = 0;            // consume cursor (local pair, batch within the pair)
+  auto consume = [&](const u32x4_t (&v0)[4], const u32x4_t (&v1)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4_t xv = xs[ccb * 256 + u * 64 + lane];
+      a0 += dec_dot<T>(v0[u], xv);
+      a1 += dec_dot<T>(v1[u], xv);
+    }
+    if (++ccb == NB) {
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (lane == 0) { res[wave][cpl][0] = a0; res[wave][cpl][1] = a1; }
+      a0 = 0.f;
+      a1 = 0.f;
+      ccb = 0;
+      ++cpl;
+    }
+  };
+  int b = 0;
+  for (; b + 4 <= total; b += 2) {      // on entry: batch b in set a, batch b+1 in set b
+    consume(va0, va1);
+    issue(va0, va1);
+    consume(vb0, vb1);
+    issue(vb0, vb1);
+  }
+  const int rem = total - b;
+  if (rem == 3) {
+    consume(va0, va1);
+    issue(va0, va1);
+    consume(vb0, vb1);
+    consume(va0, va1);
+  } else if (rem == 2) {
+    consume(va0, va1);
+    consume(vb0, vb1);
+  } else if (rem == 1) {
+    consume(va0, va1);
+  }
+  // ---- 4. epilogue: one lane per pair
+  for (int i = lane; i < np; i += 64) dec_gemv_store<T, TO, GLU>(p, p0 + i, res[wave][i][0], res[wave][i][1]);
+}
+
+template <typename T, typename TO, bool GLU>
+__global__ __launch_bounds__(256) void decode_gemv_kernel(DecGemvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+  __shared__ float red[4];
+  constexpr int KPC = 16 / sizeof(T);
+  u32x4_t* xs = (u32x4_t*)dec_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = p.K / KPC;
+  const int npair = GLU ? p.N : (p.N + 1) / 2;
+  const int gw = blockIdx.x * 4 + wave;
+  const T* W = (const T*)p.W;
+  {
+    const u32x4_t* xg = (const u32x4_t*)p.x;
+    float ss = 0.f;
+    for (int c = tid; c < nch; c += 256) {
+      const u32x4_t v = xg[c];
+      xs[c] = v;
+      if (p.nw) {
+        float f[KPC];
+        dec_unpack<T>(v, f);
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) ss += f[e] * f[e];
+      }
+    }
+    if (p.nw) {
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+      for (int c = tid; c < nch; c += 256) {   // each thread re-reads only the chunks it wrote itself
+        float f[KPC];
+        dec_unpack<T>(xs[c], f);
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) f[e] = dec_round<T>(f[e] * rstd) * p.nw[c * KPC + e];
+        xs[c] = dec_pack<T>(f);
+      }
+    }
+    __syncthreads();
+  }
+  const int TW = gridDim.x * 4;
+  for (int i = gw; i < npair; i += TW) {
+    const int n0 = GLU ? i : 2 * i;
+    const int n1 = GLU ? p.N + i : min(2 * i + 1, p.N - 1);
+    const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw);
+    const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw);
+    float a0 = 0.f, a1 = 0.f;
+    int c = lane;
+    for (; c + 3 * 64 < nch; c += 4 * 64) {
+      u32x4_t v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v0[u] = w0[c + u * 64]; v1[u] = w1[c + u * 64]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const u32x4_t xv = xs[c + u * 64];
+        a0 += dec_dot<T>(v0[u], xv);
+        a1 += dec_dot<T>(v1[u], xv);
+      }
+    }
+    for (; c < nch; c += 64) {
+      const u32x4_t xv = xs[c];
+      a0 += dec_dot<T>(w0[c], xv);
+      a1 += dec_dot<T>(w1[c], xv);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) dec_gemv_store<T, TO, GLU>(p, i, a0, a1);
+  }
+}
+
+template <typename T, typename TO, bool GLU>
+static int launch_decode_gemv(DecGemvArgs p, hipStream_t st) {
+  constexpr int KPC = 16 / sizeof(T);
+  static int bpc = -1;
+  if (bpc < 0) {
+    const char* e = getenv("VG_DEC_BPC");   // max workgroups per CU the row pairs are spread over (tuning knob)
+    bpc = e ? atoi(e) : 4;
+    if (bpc < 1) bpc = 1;
+  }
+  const int npair = GLU ? p.N : (p.N + 1) / 2;
+  const int maxw = 256 * bpc * 4;
+  int ppw = (npair + maxw - 1) / maxw;              // row pairs per wave
+  // prefer a split that gives every CU the same number of workgroups (a multiple of 256 workgroups)
+  for (int c = ppw; c <= 2 * ppw; ++c)
+    if (((npair + 4 * c - 1) / (4 * c)) % 256 == 0 && npair % (4 * c) == 0) { ppw = c; break; }
+  if (ppw > DEC_MAX_PPW) ppw = DEC_MAX_PPW;
+  const int blocks = (npair + 4 * ppw - 1) / (4 * ppw);
+  p.ppw = ppw;
+  const size_t lds = (size_t)p.K * sizeof(T);
+  const int nch = p.K / KPC;
+  const int nb = nch % 256 == 0 ? nch / 256 : 0;
+  switch (nb) {
+    case 1: decode_gemv_fast_kernel<T, TO, GLU, 1><<<blocks, 256, lds, st>>>(p); break;
+    case 2: decode_gemv_fast_kernel<T, TO, GLU, 2><<<blocks, 256, lds, st>>>(p); break;
+    case 4: decode_gemv_fast_kernel<T, TO, GLU, 4><<<blocks, 256, lds, st>>>(p); break;
+    case 7: decode_gemv_fast_kernel<T, TO, GLU, 7><<<blocks, 256, lds, st>>>(p); break;
+    case 8: decode_gemv_fast_kernel<T, TO, GLU, 8><<<blocks, 256, lds, st>>>(p); break;
+    default: decode_gemv_kernel<T, TO, GLU><<<blocks, 256, lds, st>>>(p); break;
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y, const float* norm_w, float eps,
+                              const void* R, int N, int K, int glu, int in_dtype, int out_dtype, vg_stream_t stream) {
+  VG_CHECK(x && W && y && N > 0 && K > 0, VG_ERR_ARG, "vg_decode_gemv: bad args N=%d K=%d", N, K);
+  VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_decode_gemv: bad in_dtype %d", in_dtype);
+  const int kpc = in_dtype == VG_BF16 ? 8 : 4, es = in_dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK(K % kpc == 0 && ldw % kpc == 0, VG_ERR_ARG, "vg_decode_gemv: K/ldw must be multiples of %d (K=%d ldw=%lld)", kpc, K, (long long)ldw);
+  VG_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_w & 15) == 0, VG_ERR_ARG,
+           "vg_decode_gemv: x/W/norm_w must be 16-byte aligned");
+  VG_CHECK((int64_t)K * es <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_decode_gemv: K=%d does not fit the LDS staging", K);
+  DecGemvArgs p{x, W, y, norm_w, R, N, K, ldw, eps, 1};
+  hipStream_t st = (hipStream_t)stream;
+#define VG_DEC_GEMV(TI, TOO) return glu ? launch_decode_gemv<TI, TOO, true>(p, st) : launch_decode_gemv<TI, TOO, false>(p, st)
+  if (in_dtype == VG_BF16 && out_dtype == VG_BF16) VG_DEC_GEMV(bf16_t, bf16_t);
+  if (in_dtype == VG_BF16 && out_dtype == VG_F32) VG_DEC_GEMV(bf16_t, float);
+  if (in_dtype == VG_F32 && out_dtype == VG_F32) VG_DEC_GEMV(float, float);
+#undef VG_DEC_GEMV
+  vg_set_error("vg_decode_gemv: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
+  return VG_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention of the one new token.  grid = (ceil(max_len/64) splits, Hkv): a workgroup owns 64 keys of one KV head and
+// the G = H/Hkv query heads that share it.  All K and V bytes of the split are requested up front (one HBM round
+// trip), RoPE of q and of the new k runs while they are in flight, the workgroup that owns position `pos` appends the
+// new k/v rows to the cache, and the last workgroup of a KV head to finish merges the per-split (max, sum, acc)
+// partials — ordering by an agent-scope arrival counter that resets itself, so the launch is graph-replayable.
+struct DecAttnArgs {
+  const void* qkv; void* kc; void* vc; const float* cs; const float* sn; void* o;
+  float* ws; int* cnt; const int* pos_dev;
+  int H, Hkv, D, nsplit; float scale;
+};
+
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load_dword sc1
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_store_dword sc1 (write-through)
+}
+
+// DT = compile-time head_dim (0 = run-time p.D): with it every load loop below has a constant trip count, so the
+// kernel is straight-line up to the first wait and the compiler's vmcnt bookkeeping stays exact.
+template <typename T, int G, int DT>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int L = 64;
+  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+  __shared__ int ticket;
+  const int pos = *p.pos_dev;
+  const int s = blockIdx.x, kvh = blockIdx.y;
+  const int active = pos / L + 1;
+  if (s >= active) return;
+  const int D = DT ? DT : p.D;
+  const int CH = D / KPC, hd = D / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = s * L;
+  const int nk = min(L, pos + 1 - j0);
+  const int KP = 256 / CH, cidx = tid % CH, kslot = min(tid / CH, KP - 1);
+  const bool vlive = tid / CH < KP;
+  const int NKI = DT ? (DT / KPC + 3) / 4 : 8;                 // K chunks per lane (wave w takes chunks w, w+4, ...)
+  const int NVI = DT ? (64 + 256 / (DT / KPC) - 1) / (256 / (DT / KPC)) : 8;   // V rows per thread
+  const int NRI = DT ? ((G + 1) * (DT / 2) + 255) / 256 : ((G + 1) * hd + 255) / 256;   // rope pairs per thread
+  float* qs = (float*)dec_smem;       // [G][D] roped q
+  float* knew = qs + G * D;           // [D] roped new k
+  float* vnew = knew + D;             // [D]
+  float* sp = vnew + D;               // [4 waves][G][64] partial scores
+  float* sc = sp + 4 * G * 64;        // [G][64] exp(score - max)
+  float* ms = sc + G * 64;            // [G] max | [G] sum
+  float* po = ms + 2 * G + ((4 - ((2 * G) & 3)) & 3);   // [KP][G][D] partial outputs
+
+  // ---- 1. every global load up front, the early-needed (L2-resident) ones first: vmcnt retires in order
+  const T* qkv = (const T*)p.qkv;
+  const float* cs = p.cs + (int64_t)pos * hd;
+  const float* sn = p.sn + (int64_t)pos * hd;
+  float rx1[5], rx2[5], rc[5], rs_[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    if (it < NRI) {
+      const int idx = min(tid + 256 * it, (G + 1) * hd - 1);
+      const int gh = idx / hd, d = idx % hd;
+      const T* src = gh < G ? qkv + (int64_t)(kvh * G + gh) * D : qkv + (int64_t)(p.H + kvh) * D;
+      rx1[it] = vg_elt<T>::ld(src + d);
+      rx2[it] = vg_elt<T>::ld(src + d + hd);
+      rc[it] = cs[d];
+      rs_[it] = sn[d];
+    }
+  }
+  const float vn = vg_elt<T>::ld(qkv + (int64_t)(p.H + p.Hkv + kvh) * D + min(tid, D - 1));
+  const int64_t rs = (int64_t)p.Hkv * D;
+  const T* kb = (const T*)p.kc + ((int64_t)j0 * p.Hkv + kvh) * D;
+  const T* vb = (const T*)p.vc + ((int64_t)j0 * p.Hkv + kvh) * D;
+  u32x4_t kreg[8], vreg[8];
+  {
+    const int jl = min(lane, nk - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < NKI) kreg[i] = *(const u32x4_t*)(kb + jl * rs + min(wave + 4 * i, CH - 1) * KPC);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < NVI) vreg[i] = *(const u32x4_t*)(vb + min(kslot + KP * i, nk - 1) * rs + cidx * KPC);
+  }
+  // ---- 2. RoPE of the G query heads and of the new key; the new value row (vg_rope_kv_append arithmetic)
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    if (it < NRI) {
+      const int idx = tid + 256 * it;
+      const int gh = idx / hd, d = idx % hd;
+      const float x1 = rx1[it], x2 = rx2[it], c = rc[it], sv = rs_[it];
+      float o1, o2;
+      if (sizeof(T) == 2) {
+        const float cb = bf2f(f2bf(c)), sb = bf2f(f2bf(sv));
+        o1 = bf2f(f2bf(x1 * cb)) + bf2f(f2bf(-x2 * sb));
+        o2 = bf2f(f2bf(x2 * cb)) + bf2f(f2bf(x1 * sb));
+      } else {
+        o1 = x1 * c - x2 * sv;
+        o2 = x2 * c + x1 * sv;
+      }
+      o1 = dec_round<T>(o1);
+      o2 = dec_round<T>(o2);
+      if (idx < (G + 1) * hd) {
+        float* dst = gh < G ? qs + gh * D : knew;
+        dst[d] = o1;
+        dst[d + hd] = o2;
+      }
+    }
+  }
+  if (tid < D) vnew[tid] = vn;
+  __syncthreads();
+  if (s == active - 1) {   // this split holds position `pos`: append the new rows to the cache
+    T* kdst = (T*)p.kc + ((int64_t)pos * p.Hkv + kvh) * D;
+    T* vdst = (T*)p.vc + ((int64_t)pos * p.Hkv + kvh) * D;
+    if (tid < D) {
+      vg_elt<T>::st(kdst + tid, knew[tid]);
+      vg_elt<T>::st(vdst + tid, vnew[tid]);
+    }
+  }
+  // ---- 3. q.k: lane = key, wave w covers 16-byte chunks w, w+4, ... of the head dimension
+  {
+    const bool isnew = (j0 + lane == pos);
+    float part[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) part[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = wave + 4 * i;
+      if (i < NKI && c < CH) {
+        float kf[KPC];
+        dec_unpack<T>(kreg[i], kf);
+        if (isnew) {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) kf[e] = knew[c * KPC + e];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) part[g] = fmaf(kf[e], qs[g * D + c * KPC + e], part[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) sp[(wave * G + g) * 64 + lane] = part[g];
+  }
+  __syncthreads();
+  for (int g = wave; g < G; g += 4) {
+    float v = (sp[(0 * G + g) * 64 + lane] + sp[(1 * G + g) * 64 + lane] + sp[(2 * G + g) * 64 + lane] + sp[(3 * G + g) * 64 + lane]) * p.scale;
+    if (lane >= nk) v = -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < nk ? __expf(v - m) : 0.f;
+    const float l = wave_sum(e);
+    sc[g * 64 + lane] = e;
+    if (lane == 0) { ms[g] = m; ms[G + g] = l; }
+  }
+  __syncthreads();
+  // ---- 4. p.v: thread = (key slot, 16-byte chunk of the head dimension)
+  {
+    float acc[G][KPC];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) acc[g][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = kslot + KP * i;
+      if (i < NVI && vlive && j < nk) {
+        float vf[KPC];
+        dec_unpack<T>(vreg[i], vf);
+        if (j0 + j == pos) {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) vf[e] = vnew[cidx * KPC + e];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float pj = sc[g * 64 + j];
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) acc[g][e] = fmaf(pj, vf[e], acc[g][e]);
+        }
+      }
+    }
+    if (vlive) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) po[(kslot * G + g) * D + cidx * KPC + e] = acc[g][e];
+    }
+  }
+  __syncthreads();
+  // ---- 5. publish the split's partials write-through (sc1): the merging workgroup reads them with sc1 loads, so the
+  //         hand-off needs no cache write-back / invalidate fences (MI355X_MICROARCH.md, valid hand-off forms)
+  float* wsp = p.ws + ((int64_t)kvh * p.nsplit + s) * G * (D + 2);
+  for (int o = tid; o < G * D; o += 256) {
+    const int g = o / D, d = o % D;
+    float sum = 0.f;
+    for (int k = 0; k < KP; ++k) sum += po[(k * G + g) * D + d];
+    st_agent(wsp + g * (D + 2) + d, sum);
+  }
+  if (tid < G) { st_agent(wsp + tid * (D + 2) + D, ms[tid]); st_agent(wsp + tid * (D + 2) + D + 1, ms[G + tid]); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) ticket = __hip_atomic_fetch_add(&p.cnt[kvh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != active - 1) return;
+  // ---- 6. merge by the last workgroup of this KV head to arrive.  All loads of a pass (the (max, sum) of every
+  //         split and two accumulator columns per thread) are requested together: one fabric round trip per pass.
+  const float* wbase = p.ws + (int64_t)kvh * p.nsplit * G * (D + 2);
+  float* cw = sp;                    // [active][G] max -> weight      (sp is free again; nsplit*G*2 <= 4*G*64)
+  float* cl = sp + p.nsplit * G;     // [active][G] sum
+  T* out = (T*)p.o;
+  const int nml = active * G;
+  for (int o0 = 0; o0 < G * D; o0 += 512) {
+    int oo[2], og[2], od[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      oo[k] = o0 + tid + 256 * k;
+      const int oc = min(oo[k], G * D - 1);
+      og[k] = oc / D;
+      od[k] = oc % D;
+    }
+    float num[2] = {0.f, 0.f};
+    for (int sb = 0; sb < active; sb += 32) {
+      float mv[2], lv[2];
+      if (o0 == 0 && sb == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {       // nml <= 128 * 8: two slots per thread cover 512, the rest loops below
+          const float* w = wbase + (int64_t)min(tid + 256 * k, nml - 1) * (D + 2);
+          mv[k] = ld_agent(w + D);
+          lv[k] = ld_agent(w + D + 1);
+        }
+      }
+      float v[2][32];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          v[k][u] = ld_agent(wbase + ((int64_t)min(sb + u, active - 1) * G + og[k]) * (D + 2) + od[k]);
+      if (o0 == 0 && sb == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (tid + 256 * k < nml) { cw[tid + 256 * k] = mv[k]; cl[tid + 256 * k] = lv[k]; }
+        for (int t = tid + 512; t < nml; t += 256) {
+          const float* w = wbase + (int64_t)t * (D + 2);
+          cw[t] = ld_agent(w + D);
+          cl[t] = ld_agent(w + D + 1);
+        }
+        __syncthreads();
+        for (int gg = wave; gg < G; gg += 4) {
+          float M = -INFINITY;
+          for (int s2 = lane; s2 < active; s2 += 64) M = fmaxf(M, cw[s2 * G + gg]);
+          M = wave_max(M);
+          float den = 0.f;
+          for (int s2 = lane; s2 < active; s2 += 64) {
+            const float wgt = __expf(cw[s2 * G + gg] - M);
+            cw[s2 * G + gg] = wgt;
+            den = fmaf(wgt, cl[s2 * G + gg], den);
+          }
+          den = wave_sum(den);
+          if (lane == 0) ms[gg] = 1.0f / den;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          if (sb + u < active) num[k] = fmaf(cw[(sb + u) * G + og[k]], v[k][u], num[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (oo[k] < G * D) vg_elt<T>::st(out + (int64_t)(kvh * G + og[k]) * D + od[k], num[k] * ms[og[k]]);
+  }
+  if (tid == 0) __hip_atomic_store(&p.cnt[kvh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int G, int DT>
+static void launch_decode_attn_gd(const DecAttnArgs& p, dim3 grid, size_t lds, hipStream_t st) {
+  static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap only when a shape needs it (never inside a replay)
+  if (lds > lds_cap) {
+    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<T, G, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_cap = lds;
+  }
+  decode_attn_kernel<T, G, DT><<<grid, 256, lds, st>>>(p);
+}
+
+template <typename T, int G>
+static void launch_decode_attn_g(const DecAttnArgs& p, dim3 grid, size_t lds, hipStream_t st) {
+  if (p.D == 128) launch_decode_attn_gd<T, G, 128>(p, grid, lds, st);
+  else launch_decode_attn_gd<T, G, 0>(p, grid, lds, st);
+}
+
+template <typename T>
+static int launch_decode_attn(const DecAttnArgs& p, int G, hipStream_t st) {
+  constexpr int KPC = 16 / sizeof(T);
+  const int KP = 256 / (p.D / KPC);
+  const size_t lds = sizeof(float) * ((size_t)G * p.D + 2 * p.D + 4 * G * 64 + G * 64 + 2 * G + 4 + (size_t)KP * G * p.D);
+  dim3 grid(p.nsplit, p.Hkv);
+  switch (G) {
+    case 1: launch_decode_attn_g<T, 1>(p, grid, lds, st); break;
+    case 2: launch_decode_attn_g<T, 2>(p, grid, lds, st); break;
+    case 4: launch_decode_attn_g<T, 4>(p, grid, lds, st); break;
+    case 8: launch_decode_attn_g<T, 8>(p, grid, lds, st); break;
+    default:
+      vg_set_error("vg_decode_attention: H/Hkv = %d not in {1,2,4,8}", G);
+      return VG_ERR_UNSUPPORTED;
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_len) {
+  if (H <= 0 || Hkv <= 0 || D <= 0 || max_len <= 0 || H % Hkv) return -1;
+  const int64_t nsplit = (max_len + 63) / 64;
+  return (int64_t)Hkv * nsplit * (H / Hkv) * (D + 2) + Hkv;
+}
+
+extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
+                                   void* out, int H, int Hkv, int D, int max_len, float scale, const int* pos_dev,
+                                   float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream) {
+  VG_CHECK(qkv && k_cache && v_cache && cos && sin && out && pos_dev && workspace, VG_ERR_ARG, "vg_decode_attention: null pointer");
+  VG_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && D > 0 && D % 2 == 0 && max_len > 0, VG_ERR_ARG,
+           "vg_decode_attention: bad shape H=%d Hkv=%d D=%d max_len=%d", H, Hkv, D, max_len);
+  VG_CHECK(dtype == VG_BF16 || dtype == VG_F32, VG_ERR_ARG, "vg_decode_attention: bad dtype %d", dtype);
+  const int kpc = dtype == VG_BF16 ? 8 : 4, es = dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK(D % kpc == 0 && D * es <= 512, VG_ERR_UNSUPPORTED, "vg_decode_attention: head_dim %d unsupported (multiple of %d, <= %d)", D, kpc, 512 / es);
+  VG_CHECK((((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) == 0, VG_ERR_ARG, "vg_decode_attention: caches must be 16-byte aligned");
+  const int64_t need = vg_decode_attention_ws_floats(H, Hkv, D, max_len);
+  VG_CHECK(ws_floats >= need, VG_ERR_ARG, "vg_decode_attention: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
+  const int nsplit = (max_len + 63) / 64;
+  VG_CHECK(nsplit <= 128, VG_ERR_UNSUPPORTED, "vg_decode_attention: max_len %d > 8192", max_len);
+  DecAttnArgs p{qkv, k_cache, v_cache, cos, sin, out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale};
+  if (dtype == VG_BF16) return launch_decode_attn<bf16_t>(p, H / Hkv, (hipStream_t)stream);
+  return launch_decode_attn<float>(p, H / Hkv, (hipStream_t)stream);
+}

@@ -36,6 +36,10 @@ template <> struct MmaOp<float> {
 
 constexpr int GBM = 128, GBN = 128;
 
+template <typename TO>
+__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int bm, int bn, int bz,
+                                                 int wm, int wn, int wave, int lane);
+
 // BKB = bytes of K per step (128: 64 bf16 / 32 f32; 64: half of that, half the LDS -> more workgroups per CU).
 // PF  = register prefetch depth: 1 = next tile loaded while computing the current one; 2 = two tiles in flight
 //       (tile t+2 is issued before tile t is computed and written to LDS a full iteration later).
@@ -137,6 +141,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
     }
   }
 
+  gemm_epilogue128<TO>(p, acc, smem, bm, bn, bz, wm, wn, wave, lane);
+}
+
+// Epilogue shared by the 128x128-tile kernels: bias/activation/LayerScale, optional residual, store.
+template <typename TO>
+__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int bm, int bn, int bz,
+                                                 int wm, int wn, int wave, int lane) {
+  const int M = p.M, N = p.N, l31 = lane & 31, h = lane >> 5;
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
   const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
   if (p.vec_out) {
@@ -217,6 +229,113 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
         vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
       }
     }
+}
+
+// 128x128 tile with LDS-DMA staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The DMA writes
+// LDS lane-linearly (wave-uniform base + lane*16), so rows are unpadded 128-byte lines and bank conflicts are avoided
+// by an XOR swizzle applied to the per-lane SOURCE chunk and again to the fragment reads (slot = chunk ^ ((row>>1)&7):
+// within a ds_read_b128 lane group the 16 rows then hit 16 distinct 4-bank slots).  Out-of-range rows are clamped
+// and discarded by the epilogue; a partial last K step goes through registers (issue_tail).
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int TILEB = 128 * 128;        // bytes per operand per stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int bn = wgid % gridDim.x, bm = wgid / gridDim.x, bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // this lane's 4 source rows per operand (wave w stages rows [32w, 32w+32) in 4 DMA instructions of 8 rows)
+  const T* asrc[4];
+  const T* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * GBM + row, gn = bn * GBN + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    char* sa = smem + buf * 2 * TILEB + wave * 32 * 128;
+    char* sb = sa + TILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment row bases and swizzle keys (rows r and r+32 share ((r>>1)&7) because 32>>1 = 16 ≡ 0 mod 8)
+  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+  // A partial last K step (K % BK != 0) cannot go through the DMA (no zero fill): that one step is staged through
+  // registers into the same lane-linear / source-swizzled layout, with chunks past K written as zeros.
+  auto issue_tail = [&](int kt, int buf) {
+    char* sa = smem + buf * 2 * TILEB + wave * 32 * 128 + lane * 16;
+    char* sb = sa + TILEB;
+    u32x4_t va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const bool ok = kt * BK + chunk * KPC < K;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      va[i] = ok ? *(const u32x4_t*)(asrc[i] + (int64_t)kt * BK) : z;
+      vb[i] = ok ? *(const u32x4_t*)(wsrc[i] + (int64_t)kt * BK) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4_t*)(sa + i * 1024) = va[i];
+      *(u32x4_t*)(sb + i * 1024) = vb[i];
+    }
+  };
+  const int nkf = K / BK, nk = (K + BK - 1) / BK;
+  if (nkf > 0) issue(0, 0);
+  else issue_tail(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkf) issue(kt + 1, buf ^ 1);
+    else if (kt + 1 < nk) issue_tail(kt + 1, buf ^ 1);
+    const char* sa = smem + buf * 2 * TILEB + ra * 128;
+    const char* sb = smem + buf * 2 * TILEB + TILEB + rb * 128;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 2 * g + h;
+      u32x4_t a0 = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
+      u32x4_t b0 = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
+      MmaOp<T>::run(a0, b0, acc[0][0]);
+      MmaOp<T>::run(a0, b1, acc[0][1]);
+      MmaOp<T>::run(a1, b0, acc[1][0]);
+      MmaOp<T>::run(a1, b1, acc[1][1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue128<TO>(p, acc, smem, bm, bn, bz, wm, wn, wave, lane);
 }
 
 // 256x256 output tile / 512 threads (8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles).  Same
@@ -503,12 +622,12 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     if (p.a_op == 1) launch_skinny<T, TO, true>(p, batch, st);
     else launch_skinny<T, TO, false>(p, batch, st);
   } else {
-    // main-loop variant: VG_GEMM_VARIANT = "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} (A/B knob;
-    // the default is the measured best)
+    // main-loop variant (A/B knob, the default is the measured best): VG_GEMM_VARIANT = 1283 LDS-DMA staging (default);
+    // "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} = the register-staged kernel
     static int variant = -1;
     if (variant < 0) {
       const char* e = getenv("VG_GEMM_VARIANT");
-      variant = e ? atoi(e) : 1281;
+      variant = e ? atoi(e) : 1283;
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
@@ -531,7 +650,13 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
     // the fp32 epilogue staging needs 4 x 64 x 68 floats = 69632 B of LDS whatever the K step
     const int lds128 = 4 * 128 * 144, lds64 = 4 * 64 * 68 * 4;
-    if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(p);
+    static bool glds_attr = false;
+    if (!glds_attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+      glds_attr = true;
+    }
+    if (variant == 1283) gemm_tile_glds_kernel<T, TO><<<grid, 256, lds128, st>>>(p);
+    else if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(p);
     else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(p);
     else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(p);
     else gemm_tile_kernel<T, TO, 128, 1><<<grid, 256, lds128, st>>>(p);

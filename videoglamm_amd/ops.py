@@ -154,6 +154,44 @@ def rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos0=0, pos_dev=
     return qkv
 
 
+def decode_gemv(x, w, norm_w=None, eps=0.0, residual=None, glu=False, out_dtype=None, out=None):
+    """Decode-step projection of ONE row: y[N] = rmsnorm(x; norm_w, eps) (or x) @ w^T, optional SwiGLU over w = [gate|up]
+    rows and optional residual — HF LlamaRMSNorm + nn.Linear (+ LlamaMLP act) in one launch (vg_decode_gemv)."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    assert x.numel() == K and x.is_contiguous() and w.stride(1) == 1 and w.shape[1] == K
+    N = w.shape[0] // 2 if glu else w.shape[0]
+    odt = out_dtype or x.dtype
+    y = out if out is not None else torch.empty(1, N, dtype=odt, device=x.device)
+    assert y.is_contiguous() and y.numel() == N
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == N and residual.dtype == y.dtype
+    rc = lib.vg_decode_gemv(_p(x), _p(w), w.stride(0), _p(y), _p(None if norm_w is None else _f32(norm_w)), float(eps),
+                            _p(residual), N, K, int(bool(glu)), _dt(x), _dt(y), _stream())
+    _lib.check(rc, "vg_decode_gemv")
+    return y
+
+
+def decode_attention_workspace(H, Hkv, D, max_len, device):
+    """zero-filled once: the workspace ends with per-KV-head arrival counters that the kernel resets itself."""
+    n = _lib.load().vg_decode_attention_ws_floats(H, Hkv, D, max_len)
+    if n < 0:
+        raise _lib.VGKernelError(f"vg_decode_attention_ws_floats: bad shape H={H} Hkv={Hkv} D={D} max_len={max_len}")
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws):
+    """Fused RoPE + KV append + attention of the one new token (vg_decode_attention): qkv [1,(H+2Hkv)*D] -> [1,H*D]."""
+    lib = _lib.load()
+    assert qkv.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and pos_dev.dtype == torch.int32
+    max_len = k_cache.shape[0]
+    out = torch.empty(1, H * D, dtype=qkv.dtype, device=qkv.device)
+    rc = lib.vg_decode_attention(_p(qkv), _p(k_cache), _p(v_cache), _p(_f32(cos)), _p(_f32(sin)), _p(out), H, Hkv, D, max_len,
+                                 float(scale), _p(pos_dev), _p(ws), ws.numel(), _dt(qkv), _stream())
+    _lib.check(rc, "vg_decode_attention")
+    return out
+
+
 def store_row_(src, dst, idx_dev, idx_off=0):
     """dst[*idx_dev + idx_off] = src (one row), index read on the device."""
     lib = _lib.load()

@@ -7,6 +7,8 @@ the LLM keeps a KV cache, where the reference re-encodes the clip and re-runs th
 generated token (generate(use_cache=False), R/model/VideoGLaMM.py:617-626,790-799;
 R/model/videogpt_plus/model/language_model/llama3_1.py:110-134).
 """
+import os
+
 import torch
 
 from . import ops
@@ -141,6 +143,13 @@ class LlamaDecoder:
         self.hid_all = torch.empty(max_len, self.D, dtype=dt, device=dev)   # final-norm state of every position
         self.use_graph = (dev.type == "cuda") if use_graph is None else use_graph
         self.graph = None
+        self.attn_ws = None
+        es = 2 if dt == torch.bfloat16 else 4
+        ffn = c.get("ffn") or params.t("model.layers.0.mlp.down_proj.weight").shape[1]
+        # the fused decode kernels' shape limits (vg_decode_gemv / vg_decode_attention); VG_DECODE_FUSED=0 = A/B knob
+        self.fused_decode = (os.environ.get("VG_DECODE_FUSED", "1") != "0" and (self.H // self.Hkv) in (1, 2, 4, 8)
+                             and self.hd % (16 // es) == 0 and self.hd * es <= 512 and max_len <= 8192
+                             and max(self.D, ffn) * es <= 65536 and self.D % (16 // es) == 0 and ffn % (16 // es) == 0)
 
     def reset(self):
         self.pos = 0
@@ -169,6 +178,24 @@ class LlamaDecoder:
             x = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
 
+    def _layers_decode(self, x):
+        """the same stack for ONE new row at position *pos_dev, on the fused decode kernels: 5 launches per layer
+        (norm+qkv, rope+append+attention+merge, o+residual, norm+gate|up+SwiGLU, down+residual) instead of 9."""
+        P, c = self.P, self.c
+        if self.attn_ws is None:
+            self.attn_ws = ops.decode_attention_workspace(self.H, self.Hkv, self.hd, self.max_len, x.device)
+        for i in range(c["num_layers"]):
+            l = f"model.layers.{i}."
+            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"])
+            qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
+            o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
+                                     self.pos_dev, self.hd ** -0.5, self.attn_ws)
+            x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
+            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
+            a = ops.decode_gemv(x, wgu, norm_w=P.f32(l + "post_attention_layernorm.weight"), eps=c["rms_eps"], glu=True)
+            x = ops.decode_gemv(a, P.w(l + "mlp.down_proj"), residual=x)
+        return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
+
     def forward(self, x):
         """eager: x [S,D] new tokens appended at self.pos -> final-normed hidden [S,D] (also kept in hid_all)."""
         S, pos = x.shape[0], self.pos
@@ -187,7 +214,7 @@ class LlamaDecoder:
     def _decode_step(self):
         """static step: consume tok_dev at position *pos_dev, emit the next token into tok_dev, advance pos_dev."""
         x = ops.embed(self.tok_dev, self.P.t("model.embed_tokens.weight"))
-        h = self._layers(x, 0, self.pos_dev)
+        h = self._layers_decode(x) if self.fused_decode else self._layers(x, 0, self.pos_dev)
         ops.store_row_(h, self.hid_all, self.pos_dev)
         self.next_token(h)
         ops.add_int_(self.pos_dev, 1)
