@@ -17,7 +17,21 @@ struct GemmArgs {
   int M, N, K, act;
   int vec_out;  // C/R rows are 16-byte aligned: the epilogue stores whole 16-byte chunks
   int a_op;     // 1: W holds gate|up rows ([2N,K]); output column n = silu(A.gate_n)*(A.up_n) (skinny path only)
+  int gn;       // tile order: column groups of gn N-tiles, M-tiles fastest-but-one inside a group (see gemm_tile_of)
 };
+
+// Linear tile id (already XCD-remapped: every XCD owns a contiguous run) -> (bm, bn).  Tiles are walked in column
+// groups `gn` N-tiles wide, row by row inside a group, so that the ~64 tiles an XCD runs concurrently form a roughly
+// square gn x (64/gn) patch and share their A row-panels and W column-panels through that XCD's L2.  A plain row-major
+// walk makes those 64 tiles ONE row of 64 N-tiles: every W panel is then fetched once per M-tile (measured r01: the
+// Llama gate|up GEMM pulled 3.2 GB through the fabric for 250 MB of operands).
+__device__ __forceinline__ void gemm_tile_of(int wgid, int mt, int nt, int gn, int& bm, int& bn) {
+  const int per = gn * mt;
+  const int g = wgid / per, r = wgid - g * per;
+  const int w = min(gn, nt - g * gn);
+  bm = r / w;
+  bn = g * gn + (r - bm * w);
+}
 
 template <typename T> struct MmaOp;
 template <> struct MmaOp<bf16_t> {
@@ -37,8 +51,8 @@ template <> struct MmaOp<float> {
 constexpr int GBM = 128, GBN = 128;
 
 template <typename TO>
-__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int bm, int bn, int bz,
-                                                 int wm, int wn, int wave, int lane);
+__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int m0w, int n0w, int bz,
+                                                 int wave, int lane);
 
 // BKB = bytes of K per step (128: 64 bf16 / 32 f32; 64: half of that, half the LDS -> more workgroups per CU).
 // PF  = register prefetch depth: 1 = next tile loaded while computing the current one; 2 = two tiles in flight
@@ -60,7 +74,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
   const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
   const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int bn = wgid % gridDim.x, bm = wgid / gridDim.x, bz = blockIdx.z;
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
   const int M = p.M, N = p.N, K = p.K;
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* W = (const T*)p.W + (int64_t)bz * p.sW;
@@ -141,13 +157,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
     }
   }
 
-  gemm_epilogue128<TO>(p, acc, smem, bm, bn, bz, wm, wn, wave, lane);
+  gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
 // Epilogue shared by the 128x128-tile kernels: bias/activation/LayerScale, optional residual, store.
 template <typename TO>
-__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int bm, int bn, int bz,
-                                                 int wm, int wn, int wave, int lane) {
+__device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int m0w, int n0w, int bz,
+                                                 int wave, int lane) {
   const int M = p.M, N = p.N, l31 = lane & 31, h = lane >> 5;
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
   const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
@@ -162,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nl = j * 32 + l31;
-        const int n = bn * GBN + wn * 64 + nl;
+        const int n = n0w + nl;
         const float bv = (p.bias && n < N) ? p.bias[n] : 0.f;
         const float gv = (p.gamma && n < N) ? p.gamma[n] : 1.f;
 #pragma unroll
@@ -170,11 +186,11 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       }
     __syncthreads();
     const int cg = lane & 7, rsub = lane >> 3;    // 8 column groups x 8 rows per pass
-    const int n0 = bn * GBN + wn * 64 + cg * 8;
+    const int n0 = n0w + cg * 8;
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int ml = pass * 8 + rsub;
-      const int m = bm * GBM + wm * 64 + ml;
+      const int m = m0w + ml;
       if (m >= M || n0 >= N) continue;
       float v[8];
 #pragma unroll
@@ -216,13 +232,13 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int n = bn * GBN + wn * 64 + j * 32 + l31;
+      const int n = n0w + j * 32 + l31;
       if (n >= N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
       const float gv = p.gamma ? p.gamma[n] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = bm * GBM + wm * 64 + i * 32 + mfma32_row(r, h);
+        const int m = m0w + i * 32 + mfma32_row(r, h);
         if (m >= M) continue;
         float v = vg_act(acc[i][j][r] + bv, p.act) * gv;
         if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
@@ -236,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
 // by an XOR swizzle applied to the per-lane SOURCE chunk and again to the fragment reads (slot = chunk ^ ((row>>1)&7):
 // within a ds_read_b128 lane group the 16 rows then hit 16 distinct 4-bank slots).  Out-of-range rows are clamped
 // and discarded by the epilogue; a partial last K step goes through registers (issue_tail).
-template <typename T, typename TO>
+template <typename T, typename TO, bool FRAG_ALL = false>
 __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KPC = 16 / sizeof(T);
@@ -247,7 +263,9 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
   const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int bn = wgid % gridDim.x, bm = wgid / gridDim.x, bz = blockIdx.z;
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
   const int M = p.M, N = p.N, K = p.K;
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* W = (const T*)p.W + (int64_t)bz * p.sW;
@@ -320,6 +338,122 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     else if (kt + 1 < nk) issue_tail(kt + 1, buf ^ 1);
     const char* sa = smem + buf * 2 * TILEB + ra * 128;
     const char* sb = smem + buf * 2 * TILEB + TILEB + rb * 128;
+    if constexpr (FRAG_ALL) {
+      // all 16 fragment reads of the K-step are requested first; the MFMAs then start as the first ones land
+      u32x4_t fa0[4], fa1[4], fb0[4], fb1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 2 * g + h;
+        fa0[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+        fb0[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+        fa1[g] = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
+        fb1[g] = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+        MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+        MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+        MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 2 * g + h;
+        u32x4_t a0 = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+        u32x4_t a1 = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
+        u32x4_t b0 = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+        u32x4_t b1 = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
+        MmaOp<T>::run(a0, b0, acc[0][0]);
+        MmaOp<T>::run(a0, b1, acc[0][1]);
+        MmaOp<T>::run(a1, b0, acc[1][0]);
+        MmaOp<T>::run(a1, b1, acc[1][1]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
+}
+
+// 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
+// by LDS-DMA two K-steps ahead.  The 128x128 kernels drain their DMA queue at every barrier (vmcnt(0) inside
+// __syncthreads) with only one K-step (~0.2 us of MFMA) of prefetch distance against ~1-2 us of L2/HBM latency; here
+// the loads of stage kt+1 stay in flight across the barrier (counted vmcnt + raw s_barrier) and each staged byte feeds
+// 1.33x the MFMA work.  Needs K % (128/sizeof(T)) == 0; the launcher falls back to the 128x128 kernel otherwise.
+// LDS: 3 x (256 + 128) rows x 128 B = 144 KB (1 workgroup per CU); the epilogue staging (8 x 64 x 68 fp32) reuses it.
+template <typename T, typename TO>
+__global__ __launch_bounds__(512) void gemm_tile_ring_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int TA = 256 * 128, STAGE = (256 + 128) * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // this wave's DMA pieces per stage: A rows [32w, 32w+32) in 4 instructions of 8 rows, W rows [16w, 16w+16) in 2
+  const T* asrc[4];
+  const T* wsrc[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * 256 + row;
+    gm = gm < M ? gm : M - 1;
+    asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 16 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gn = bn * 128 + row;
+    gn = gn < N ? gn : N - 1;
+    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    char* sa = smem + buf * STAGE + wave * 32 * 128;
+    char* sb = smem + buf * STAGE + TA + wave * 16 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+  const int nk = K / BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of stage kt have landed once at most the 6 DMAs of stage kt+1 are still outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone is done reading buffer (kt+2)%3 = (kt-1)%3
+    if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+    const char* sa = smem + buf * STAGE + ra * 128;
+    const char* sb = smem + buf * STAGE + TA + rb * 128;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c = 2 * g + h;
@@ -332,10 +466,10 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
       MmaOp<T>::run(a1, b0, acc[1][0]);
       MmaOp<T>::run(a1, b1, acc[1][1]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    buf = buf == 2 ? 0 : buf + 1;
   }
-  gemm_epilogue128<TO>(p, acc, smem, bm, bn, bz, wm, wn, wave, lane);
+  __syncthreads();   // the epilogue reuses the ring as fp32 staging
+  gemm_epilogue128<TO>(p, acc, smem, bm * 256 + wm * 64, bn * 128 + wn * 64, bz, wave, lane);
 }
 
 // 256x256 output tile / 512 threads (8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles).  Same
@@ -354,7 +488,9 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs p) {
   const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
   const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int bn = wgid % gridDim.x, bm = wgid / gridDim.x, bz = blockIdx.z;
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
   const int M = p.M, N = p.N, K = p.K;
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* W = (const T*)p.W + (int64_t)bz * p.sW;
@@ -622,12 +758,26 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     if (p.a_op == 1) launch_skinny<T, TO, true>(p, batch, st);
     else launch_skinny<T, TO, false>(p, batch, st);
   } else {
-    // main-loop variant (A/B knob, the default is the measured best): VG_GEMM_VARIANT = 1283 LDS-DMA staging (default);
+    // tile walk (gemm_tile_of): VG_GEMM_GN = N-tiles per column group; 0 (default) = 4, i.e. a 4 x 16 patch of
+    // concurrent tiles per XCD; a huge value = plain row-major
+    static int gn_env = -1;
+    if (gn_env < 0) {
+      const char* e = getenv("VG_GEMM_GN");
+      gn_env = e ? atoi(e) : 0;
+    }
+    auto pick_gn = [&](int mt, int nt) {
+      int g = gn_env > 0 ? gn_env : 4;   // measured r01 (tools/bench_gemm.py): 4 >= 8 > 16 > row-major on every C1 shape
+      return g < 1 ? 1 : (g > nt ? nt : g);
+    };
+    GemmArgs q = p;
+    q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + GBN - 1) / GBN);
+    // main-loop variant (A/B knob, the default is the measured best): VG_GEMM_VARIANT = 1284 LDS-DMA staging with all 16
+    // fragment reads of a K-step requested up front (default), 1283 the same with reads group by group;
     // "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} = the register-staged kernel
     static int variant = -1;
     if (variant < 0) {
       const char* e = getenv("VG_GEMM_VARIANT");
-      variant = e ? atoi(e) : 1283;
+      variant = e ? atoi(e) : 1284;
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
@@ -643,7 +793,8 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     const int64_t g256 = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
     if (use256 && g256 >= 384) {   // >= 1.5 workgroups per CU even at 256x256: take the LDS-lean big tile
       dim3 grid256((p.N + 255) / 256, (p.M + 255) / 256, batch);
-      gemm_tile256_kernel<T, TO><<<grid256, 512, 4 * 256 * 144, st>>>(p);
+      q.gn = pick_gn((p.M + 255) / 256, (p.N + 255) / 256);
+      gemm_tile256_kernel<T, TO><<<grid256, 512, 4 * 256 * 144, st>>>(q);
       VG_LAUNCH_CHECK();
       return VG_OK;
     }
@@ -653,13 +804,29 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     static bool glds_attr = false;
     if (!glds_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
       glds_attr = true;
     }
-    if (variant == 1283) gemm_tile_glds_kernel<T, TO><<<grid, 256, lds128, st>>>(p);
-    else if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(p);
-    else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(p);
-    else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(p);
-    else gemm_tile_kernel<T, TO, 128, 1><<<grid, 256, lds128, st>>>(p);
+    // 256x128 ring kernel (VG_GEMM_RING=2 enables it where K is whole K-steps and there are >= 200 tiles): measured r01
+    // within +-3% of the 128x128 kernel on the C1 shapes (+5% only at 8192^3) -- both sit at the LDS-read ceiling of a
+    // 64x64-per-wave tiling -- so it stays an A/B knob
+    static int ring = -1;
+    if (ring < 0) {
+      const char* e = getenv("VG_GEMM_RING");
+      ring = e ? atoi(e) : 1;
+      (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
+    }
+    const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
+    if ((variant == 1283 || variant == 1284) && ring == 2 && p.K % (128 / (int)sizeof(T)) == 0 && p.M > 128 && tiles_ring >= 200) {
+      dim3 gridr((p.N + 127) / 128, (p.M + 255) / 256, batch);
+      q.gn = pick_gn((p.M + 255) / 256, (p.N + 127) / 128);
+      gemm_tile_ring_kernel<T, TO><<<gridr, 512, 3 * 384 * 128, st>>>(q);
+    } else if (variant == 1283) gemm_tile_glds_kernel<T, TO><<<grid, 256, lds128, st>>>(q);
+    else if (variant == 1284) gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
+    else if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(q);
+    else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(q);
+    else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(q);
+    else gemm_tile_kernel<T, TO, 128, 1><<<grid, 256, lds128, st>>>(q);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -681,7 +848,7 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   const int ovec = out_dtype == VG_BF16 ? 8 : 4;
   const int vec_out = (ldc % ovec == 0) && (sC % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                       (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
-  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op};
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1};
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);

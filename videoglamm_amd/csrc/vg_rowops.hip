@@ -6,6 +6,12 @@
 template <typename T> struct RowVec;
 template <> struct RowVec<bf16_t> {
   static constexpr int N = 8;
+  typedef u32x4_t Raw;
+  static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { return *(const u32x4_t*)p; }
+  static __device__ __forceinline__ void unpack(const Raw& r, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(r[e] << 16); v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+  }
   static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
     const u32x4_t r = *(const u32x4_t*)p;
 #pragma unroll
@@ -14,6 +20,12 @@ template <> struct RowVec<bf16_t> {
 };
 template <> struct RowVec<float> {
   static constexpr int N = 4;
+  typedef f32x4_t Raw;
+  static __device__ __forceinline__ Raw ldraw(const float* p) { return *(const f32x4_t*)p; }
+  static __device__ __forceinline__ void unpack(const Raw& r, float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r[e];
+  }
   static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
     const f32x4_t r = *(const f32x4_t*)p;
 #pragma unroll
@@ -42,10 +54,6 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
   constexpr int RPB = 256 / TPR;
   constexpr int NV = RowVec<TI>::N;
   const int t = threadIdx.x % TPR;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
-  if (row >= rows) return;  // TPR == 256: block-uniform; TPR == 64: wave-uniform and no block barrier is used
-  const TI* xr = x + row * ldx;
-  TO* yr = y + row * ldy;
   auto reduce = [&](float v) {
     if constexpr (TPR == 16) {
 #pragma unroll
@@ -63,50 +71,77 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
   };
   if constexpr (VEC) {
     if (C <= TPR * NV * 4) {
-      // the whole row fits in registers (<= 4 x 16-byte chunks per lane): ONE global read, two in-register passes
-      float v[4][NV];
-      float s = 0.f;
+      // The whole row fits in registers (<= 4 x 16-byte chunks per lane): ONE global read, two in-register passes.
+      // Persistent over row groups (grid-stride) with the NEXT group's row requested before the current one is
+      // reduced: a one-row-per-wave launch is latency-bound (load -> two dependent reductions -> store) at ~1 TB/s.
+      typedef typename RowVec<TI>::Raw Raw;
+      const int64_t ngroups = (rows + RPB - 1) / RPB;
+      const int sub = threadIdx.x / TPR;
+      auto rowload = [&](int64_t grp, Raw (&r)[4]) {
+        const int64_t rw = min(grp * RPB + sub, rows - 1);   // clamped: the load is unconditional
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (t + j * TPR) * NV;
-        if (c < C) {
-          RowVec<TI>::ld(xr + c, v[j]);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) s += v[j][e];
+        for (int j = 0; j < 4; ++j) {
+          const int c = (t + j * TPR) * NV;
+          r[j] = RowVec<TI>::ldraw(x + rw * ldx + (c < C ? c : 0));
         }
-      }
-      const float mean_r = RMS ? 0.f : reduce(s) / (float)C;
-      float q = 0.f;
+      };
+      Raw cur[4], nxt[4];
+      rowload(blockIdx.x, cur);
+      for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        rowload(min(grp + (int64_t)gridDim.x, ngroups - 1), nxt);
+        const int64_t row = grp * RPB + sub;
+        const bool live = row < rows;          // TPR == 256: block-uniform; 64 / 16: uniform over the lanes that reduce together
+        float v[4][NV];
+        float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (t + j * TPR) * NV;
-        if (c < C) {
+        for (int j = 0; j < 4; ++j) {
+          const int c = (t + j * TPR) * NV;
+          RowVec<TI>::unpack(cur[j], v[j]);
+          if (c < C) {
 #pragma unroll
-          for (int e = 0; e < NV; ++e) { const float d = v[j][e] - mean_r; q += d * d; }
-        }
-      }
-      const float rstd_r = rsqrtf(reduce(q) / (float)C + eps);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (t + j * TPR) * NV;
-        if (c < C) {
-          float o[NV];
-#pragma unroll
-          for (int e = 0; e < NV; ++e) {
-            float n = (v[j][e] - mean_r) * rstd_r;
-            if (RMS) {
-              if (sizeof(TI) == 2) n = bf2f(f2bf(n));
-              o[e] = w ? n * w[c + e] : n;
-            } else {
-              o[e] = n * (w ? w[c + e] : 1.f) + (b ? b[c + e] : 0.f);
-            }
+            for (int e = 0; e < NV; ++e) s += v[j][e];
           }
-          row_store<TO, NV>(yr + c, o);
         }
+        const float mean_r = RMS ? 0.f : reduce(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (t + j * TPR) * NV;
+          if (c < C) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { const float d = v[j][e] - mean_r; q += d * d; }
+          }
+        }
+        const float rstd_r = rsqrtf(reduce(q) / (float)C + eps);
+        TO* yr = y + row * ldy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (t + j * TPR) * NV;
+          if (live && c < C) {
+            float o[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+              float n = (v[j][e] - mean_r) * rstd_r;
+              if (RMS) {
+                if (sizeof(TI) == 2) n = bf2f(f2bf(n));
+                o[e] = w ? n * w[c + e] : n;
+              } else {
+                o[e] = n * (w ? w[c + e] : 1.f) + (b ? b[c + e] : 0.f);
+              }
+            }
+            row_store<TO, NV>(yr + c, o);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
       }
       return;
     }
   }
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+  if (row >= rows) return;  // TPR == 256: block-uniform; TPR == 64: wave-uniform and no block barrier is used
+  const TI* xr = x + row * ldx;
+  TO* yr = y + row * ldy;
   float mean = 0.f;
   if (!RMS) {
     float s = 0.f;
@@ -158,15 +193,18 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
   const bool vec = (C % NV == 0) && (ldx % NV == 0) && (ldy % NV == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
   const TI* xi = (const TI*)x;
   TO* yo = (TO*)y;
+  const unsigned pgrid = 256 * 8;   // persistent cap of the register-resident path: 8 workgroups per CU
   if (rows < 1024 || (vec && C > 64 * NV * 4)) {   // few rows, or rows too long for one wave's registers
     dim3 grid((unsigned)rows);
+    if (vec && C <= 256 * NV * 4 && grid.x > pgrid) grid.x = pgrid;
     if (vec) norm_kernel<TI, TO, RMS, 256, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
     else norm_kernel<TI, TO, RMS, 256, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   } else if (vec && C <= 512) {   // short rows (Hiera stage 1-2: C = 144 / 288): 16 lanes per row, 16 rows per workgroup
-    dim3 grid((unsigned)((rows + 15) / 16));
+    dim3 grid((unsigned)((rows + 15) / 16 < (int64_t)pgrid ? (rows + 15) / 16 : (int64_t)pgrid));
     norm_kernel<TI, TO, RMS, 16, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   } else {
     dim3 grid((unsigned)((rows + 3) / 4));
+    if (vec && grid.x > pgrid) grid.x = pgrid;
     if (vec) norm_kernel<TI, TO, RMS, 64, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
     else norm_kernel<TI, TO, RMS, 64, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   }
