@@ -1,6 +1,6 @@
 """Serial stage budget of the C1 workload (same synthetic model and inputs as bench.py): each stage timed alone with
 HIP events on the launch stream, then the overlapped end-to-end step for comparison.
-usage: python tools/bench_parts.py [reps=3]"""
+usage: python tools/bench_parts.py [reps=3] [hiera|towers|prefill]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ from videoglamm_amd.model import VideoGLaMMForCausalLM  # noqa: E402
 from videoglamm_amd.vlm import generate  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+only = sys.argv[2] if len(sys.argv) > 2 else ""      # "hiera" / "towers" / "prefill": run just that stage (for rocprofv3)
 sys.argv = sys.argv[:1]
 args = bench.parse()
 dev = torch.device("cuda:0")
@@ -36,6 +37,14 @@ def timed(fn, n=reps):
     return e0.elapsed_time(e1) / n, out
 
 
+if only:
+    fn = {"hiera": lambda: model.sam2.hiera_frames(sam, None),
+          "towers": lambda: model.towers.encode(images, context),
+          "prefill": lambda: generate(model.P, model.cfg, model.towers, images, context, ids[0].cpu(), 0,
+                                      visual=torch.zeros(208 * args.te, cfg["llm"]["hidden"], dtype=torch.bfloat16, device=dev))}[only]
+    ms, _ = timed(fn)
+    print(f"{only}: {ms:.2f} ms")
+    sys.exit(0)
 e2e, _ = timed(lambda: model.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=args.max_new_tokens))
 t_enc, visual = timed(lambda: model.towers.encode(images, context))
 t_iv2, _ = timed(lambda: model.towers.iv2(images.view(images.shape[0] // 4, 4, *images.shape[1:])))

@@ -5,6 +5,8 @@
 Same argument meaning, return structure and error behaviour as the reference for this path; batch size 1 is
 asserted exactly like R/model/VideoGLaMM.py:252-253.
 """
+import os
+
 import torch
 
 from . import ops
@@ -108,15 +110,22 @@ class VideoGLaMMForCausalLM:
         return out_ids.unsqueeze(0), emb
 
     def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens):
-        """LLM side + Hiera features of this rank's frames.  Hiera is enqueued on the side stream right after the
-        prefill, so it runs underneath the decode loop (see _hiera_async)."""
+        """LLM side + Hiera features of this rank's frames, Hiera on the side stream (see _hiera_async)."""
         frames = self.comm.my_frames(sam.shape[0]) if self.comm is not None else None
         box = {}
 
         def start():
             box["feats"], box["join"] = self._hiera_async(sam, frames)
 
-        out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens, after_prefill=start)
+        # Hiera goes to the side stream FIRST: it then shares the chip with the towers / LLM prefill (big-K, MFMA-bound
+        # GEMMs that leave HBM idle, where Hiera's small-K GEMMs, norms and window shuffles are bandwidth-hungry) and is
+        # mostly done when the HBM-saturated decode loop starts.  Measured r01: 195 ms/clip vs 200.5 when it is enqueued
+        # after the prefill (VG_HIERA_START=prefill) and 211 with no overlap at all.
+        if os.environ.get("VG_HIERA_START", "first") == "first":
+            start()
+            out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+        else:
+            out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens, after_prefill=start)
         box["join"]()
         return out_ids, emb, box["feats"]
 
