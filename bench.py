@@ -56,8 +56,9 @@ def make_inputs(cfg, args, world, device):
 
 
 class GemmMeter:
-    """Per-launch HIP-event timing of the dominant kernel (gemm_tile_kernel, bf16) on torch's current stream —
-    the stream every vg_* kernel is launched on (videoglamm_amd/ops.py:_stream)."""
+    """Per-launch HIP-event timing of the dominant kernel (gemm_tile_glds_kernel, bf16: every M > 16 ops.linear) on
+    torch's current stream — the stream every vg_* kernel is launched on (videoglamm_amd/ops.py:_stream; the Hiera
+    launches are metered on the side stream they run on)."""
 
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.linear, []
@@ -87,6 +88,34 @@ class GemmMeter:
         flops = sum(r[0] for r in self.rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
         return flops, ms, len(self.rec), sum(r[3] for r in self.rec)
+
+
+class DecodeMeter:
+    """HIP events around every graph-replayed decode step (LlamaDecoder.decode_step): the HBM-bound half of the
+    workload.  Bytes per step = every LLM weight matrix once (lm_head included) — the algorithmic traffic."""
+
+    def __init__(self):
+        from videoglamm_amd import vlm
+        self.cls, self.orig, self.rec = vlm.LlamaDecoder, vlm.LlamaDecoder.decode_step, []
+
+    def __enter__(self):
+        meter = self
+
+        def timed(dec):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            meter.orig(dec)
+            e1.record()
+            meter.rec.append((e0, e1))
+        self.cls.decode_step = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.decode_step = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.rec), len(self.rec)
 
 
 def cpu_baseline(cfg, args):
@@ -209,25 +238,46 @@ def main():
         "load_s": round(t_load, 1),
     }
     if rank == 0 and not args.no_roofline:
-        # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream
-        with GemmMeter(ops) as gm:
-            step()
+        # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream.  It runs
+        # with the Hiera/LLM stream overlap switched off: an event pair on one of two concurrently fed streams also
+        # brackets the time the launch waits behind the other stream's kernels, which is not kernel time
+        # (the rocprofv3 summary under profiles/ is taken on the timed, overlapped configuration)
+        prev = os.environ.get("VG_HIERA_START")
+        os.environ["VG_HIERA_START"] = "serial"
+        try:
+            with GemmMeter(ops) as gm, DecodeMeter() as dm:
+                step()
+        finally:
+            if prev is None:
+                os.environ.pop("VG_HIERA_START", None)
+            else:
+                os.environ["VG_HIERA_START"] = prev
         flops, ms, n, nbytes = gm.summary()
+        dec_ms, dec_n = dm.summary()
         peak = 2500.0
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summary):
         # only quoted for the workload it was measured on (C1 framewise, 1 GPU)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_tile.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_glds.json")
         if os.path.exists(pmc) and world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8:
             with open(pmc) as fh:
                 traffic = round(json.load(fh)["traffic_bytes_per_launch"])
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_glds_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                            "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                            "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
                            "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
                            "kernel_ms_per_step": round(ms, 2)}
+        if dec_n and not args.tiny:
+            c = cfg["llm"]
+            hd = c["hidden"] // c["num_heads"]
+            wbytes = 2.0 * (c["num_layers"] * (c["hidden"] * (c["num_heads"] + 2 * c["num_kv_heads"]) * hd + c["hidden"] * c["hidden"]
+                                               + 3 * c["hidden"] * c["ffn"]) + c["vocab"] * c["hidden"])
+            tbs = wbytes * dec_n / (dec_ms * 1e-3) / 1e12
+            res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 + decode_attn_kernel per layer)",
+                                      "achieved": round(tbs * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tbs / 8.0, 4),
+                                      "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
     if rank == 0 and not args.no_cpu_baseline and not args.tiny:
         res["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:

@@ -68,7 +68,11 @@ __device__ __forceinline__ float vg_half_erfc_neg(float z) {
 // activation codes (vg_kernels.h): 0 none, 1 gelu(erf), 2 quick_gelu, 3 relu, 4 silu, 5 sigmoid
 __device__ __forceinline__ float vg_act(float x, int act) {
   switch (act) {
+#ifdef VG_LIBM_ERF
+    case VG_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+#else
     case VG_ACT_GELU: return x * vg_half_erfc_neg(x * 0.70710678118654752440f);
+#endif
     case VG_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
     case VG_ACT_RELU: return x > 0.f ? x : 0.f;
     case VG_ACT_SILU: return x / (1.0f + __expf(-x));

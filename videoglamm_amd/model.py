@@ -121,7 +121,12 @@ class VideoGLaMMForCausalLM:
         # GEMMs that leave HBM idle, where Hiera's small-K GEMMs, norms and window shuffles are bandwidth-hungry) and is
         # mostly done when the HBM-saturated decode loop starts.  Measured r01: 195 ms/clip vs 200.5 when it is enqueued
         # after the prefill (VG_HIERA_START=prefill) and 211 with no overlap at all.
-        if os.environ.get("VG_HIERA_START", "first") == "first":
+        mode = os.environ.get("VG_HIERA_START", "first")
+        if mode == "serial":      # no overlap (per-kernel timing runs: bench.py's instrumented step)
+            feats = self.sam2.hiera_frames(sam, frames)
+            out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
+            return out_ids, emb, feats
+        if mode == "first":
             start()
             out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
         else:
