@@ -66,9 +66,22 @@ int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, 
 /* a_op = 1 (M <= 16 only): W holds 2N rows, gate rows then up rows; C[:, n] = silu(A·W[n]) * (A·W[N+n]) —
  * HF LlamaMLP act(gate_proj(x)) * up_proj(x) with the SwiGLU done in the GEMV epilogue (decode path). */
 
+/* The same contraction with Hiera's window_partition / window_unpartition (backbones/utils.py:16-38,41-60, called from
+ * hieradet.py:128-136,147-148) folded into it.  GEMM row m is the WINDOW-order row index (window (b,wy,wx), token (r,c)),
+ * M = B*ceil(H/ws)*ceil(W/ws)*ws*ws including the zero padding rows the reference pads with.
+ *   mode 1: A is the IMAGE-order tensor [B,H,W,K] (row stride lda); row m is gathered from it (padding rows read
+ *           zero_row, K zeros) and C is written in window order — window_partition + qkv projection in one pass.
+ *   mode 2: A is window-order; C (row stride ldc) and R (ldr) are IMAGE-order [B,H,W,N]: row m is scattered to its
+ *           pixel, padding rows are dropped — proj + window_unpartition + residual add in one pass. */
+int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                   const float* gamma, const void* R, int64_t ldr, int N, int K, int in_dtype, int out_dtype, int act,
+                   int mode, int B, int H, int Wd, int ws, const void* zero_row, vg_stream_t stream);
+
 /* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
  * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)
- * causal: key j visible to query i iff j <= i + (Skv - Sq).  D % 8 == 0, D <= 256.
+ * causal = 1: key j visible to query i iff j <= i + (Skv - Sq).  causal = -w (w > 0): block-diagonal mask — the
+ * sequence is a pack of independent w-token windows (key j visible to query i iff j/w == i/w; Sq == Skv), which lets
+ * Hiera's 16- / 64-token windows share 128-query tiles.  D % 8 == 0, D <= 256.
  * Strides are in elements: *_sb batch, *_ss token, *_sh head; the head dim is contiguous.
  * Replaces F.scaled_dot_product_attention / naive softmax(QK^T)V at
  *   R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:72-76,

@@ -44,6 +44,14 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     return y
 
 
+def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, residual=None):
+    if scatter:
+        y = linear(x, w, bias, act, gamma)
+        y = window_unpartition(y, ws, B, H, W)
+        return y if residual is None else (y.float() + residual.float()).to(y.dtype)
+    return linear(window_partition(x.view(B, H, W, -1), ws), w, bias, act, gamma)
+
+
 def bmm_nt(a, w, out_dtype=None):
     odt = out_dtype if out_dtype is not None else a.dtype
     return (a.float() @ w.float().transpose(-1, -2)).to(odt)
@@ -62,6 +70,10 @@ def attention(q, k, v, scale, causal=False):
         s = s.masked_fill(j > i + (Skv - Sq), float("-inf"))
     p = torch.softmax(s, dim=-1)
     return (p @ vf).permute(0, 2, 1, 3).contiguous().to(q.dtype)
+
+
+def attention_windows(q, k, v, scale):
+    return attention(q, k, v, scale)
 
 
 def layernorm(x, w, b, eps, out_dtype=None):

@@ -308,6 +308,37 @@ def test_bilinear(cuda):
         close(ops.bilinear(x.to(cuda), Ho, Wo), ref.bilinear(x, Ho, Wo), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 16, 16, 8, 144, 432), (1, 20, 12, 7, 72, 40), (3, 64, 64, 14, 64, 192), (2, 8, 8, 4, 288, 288)])
+def test_gemm_window(cuda, dtype, B, H, W, ws, K, N):
+    """window_partition folded into the A-row gather and window_unpartition + residual into the epilogue scatter,
+    incl. shapes that need the reference's zero padding (20x12 / 7, 64x64 / 14)."""
+    from videoglamm_amd import ops
+    x = rnd(B, H, W, K, dtype=dtype, seed=1)
+    w, bias = rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.linear_window(x.to(cuda), w.to(cuda), bias.to(cuda), B, H, W, ws, scatter=False)
+    r = ref.linear_window(x, w, bias, B, H, W, ws, scatter=False)
+    close(y, r, **tol(dtype, K))
+    # same numbers as the two-kernel path, bit for bit
+    assert torch.equal(y, ops.linear(ops.window_partition(x.to(cuda), ws), w.to(cuda), bias.to(cuda)))
+    w2, res = rnd(K, N, dtype=dtype, seed=4, scale=N ** -0.5), rnd(B, H, W, K, dtype=dtype, seed=5)
+    z = ops.linear_window(y, w2.to(cuda), None, B, H, W, ws, scatter=True, residual=res.to(cuda))
+    close(z, ref.linear_window(r.to(dtype), w2, None, B, H, W, ws, scatter=True, residual=res), **tol(dtype, N))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Bw,wtok,H,D", [(64, 16, 4, 72), (8, 64, 2, 72), (6, 16, 2, 32), (16, 49, 4, 72), (24, 32, 1, 64)])
+def test_attention_windows(cuda, dtype, Bw, wtok, H, D):
+    """many small windows packed into 128-token tiles under the block-diagonal mask == per-window attention; q/k/v are
+    strided views of one fused [Bw, wtok, 3, H, D] projection as in Hiera (49 tokens / 6 windows: unpackable -> fallback)."""
+    from videoglamm_amd import ops
+    qkv = rnd(Bw, wtok, 3, H, D, dtype=dtype, seed=7)
+    g = qkv.to(cuda)
+    o = ops.attention_windows(g[:, :, 0], g[:, :, 1], g[:, :, 2], D ** -0.5)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    close(o, ref.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5), **t)
+
+
 def test_errors_are_loud(cuda):
     from videoglamm_amd import _lib, ops
     with pytest.raises(_lib.VGKernelError):

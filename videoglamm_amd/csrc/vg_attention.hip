@@ -110,9 +110,18 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 
   const int off = Skv - Sq;
   int kv_end = Skv;
-  if (p.causal) {
+  if (p.causal > 0) {
     const int lim = (p.fold ? Sq : q0 + BQ) + off;  // keys >= lim are invisible to every query of this block
     kv_end = lim < Skv ? (lim > 0 ? lim : 0) : Skv;
+  }
+  // causal < 0: block-diagonal mask, windows of wtok = -causal tokens packed back to back along the sequence (Hiera's
+  // 16- and 64-token windows: 8 or 2 of them fill one 128-query tile instead of one padded tile each)
+  const int wtok = p.causal < 0 ? -p.causal : 0;
+  int kv_first = 0;
+  if (wtok) {
+    kv_first = q0 / wtok * wtok;
+    const int e = (q0 + BQ + wtok - 1) / wtok * wtok;
+    kv_end = e < Skv ? e : Skv;
   }
 
   float m_i = -INFINITY, l_i = 0.f;
@@ -128,7 +137,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   const int q_head = p.fold ? head * G + q_row / Sq : head;
   const char* qrow = Qs + q_local * RS + h * 16;
 
-  int kv_begin = 0;
+  const int wlo = wtok ? q_idx / wtok * wtok : 0, whi = wtok ? wlo + wtok : 0x7fffffff;
+  int kv_begin = kv_first;
   if (p.nsplit > 1) {
     kv_begin = split * p.split_len;
     const int e = kv_begin + p.split_len;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + kt * 32 + mfma32_row(r, h);
-        const bool ok = key < Skv && (!p.causal || key <= q_idx + off);
+        const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi;
         const float v = ok ? s[kt][r] * p.scale : -INFINITY;
         s[kt][r] = v;
         mx = fmaxf(mx, v);
@@ -308,6 +318,8 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
            VG_ERR_ARG, "vg_attention: q/k/v strides must keep 16-byte alignment");
   VG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, VG_ERR_ARG, "vg_attention: q/k/v must be 16-byte aligned");
   if (Sq == 0) return VG_OK;
+  VG_CHECK(causal >= 0 || (Sq == Skv && nsplit == 1 && Hq == Hkv), VG_ERR_ARG,
+           "vg_attention: the block-diagonal window mask (causal = -tokens_per_window) needs Sq == Skv, no KV split, no GQA");
   VG_CHECK(nsplit >= 1, VG_ERR_ARG, "vg_attention: nsplit must be >= 1");
   int split_len = 0;
   if (nsplit > 1) {

@@ -18,7 +18,23 @@ struct GemmArgs {
   int vec_out;  // C/R rows are 16-byte aligned: the epilogue stores whole 16-byte chunks
   int a_op;     // 1: W holds gate|up rows ([2N,K]); output column n = silu(A.gate_n)*(A.up_n) (skinny path only)
   int gn;       // tile order: column groups of gn N-tiles, M-tiles fastest-but-one inside a group (see gemm_tile_of)
+  // window-order <-> image-order row maps (vg_gemm_window): wmode 1 = A rows are gathered from an image-order tensor
+  // (window_partition fused into the load), 2 = C and R rows are scattered to / read from image order (window_unpartition
+  // + residual add fused into the epilogue).  GEMM row m is always the window-order index.
+  int wmode, wH, wW, wws, wnH, wnW;
+  const void* zrow;   // K zeros: source of the padded window rows (the LDS-DMA cannot zero-fill)
 };
+
+// window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
+__device__ __forceinline__ int64_t gemm_window_row(const GemmArgs& p, int m) {
+  const int per = p.wws * p.wws;
+  const int win = m / per, tok = m - win * per;
+  const int rr = tok / p.wws, cc = tok - rr * p.wws;
+  const int wx = win % p.wnW, t = win / p.wnW;
+  const int wy = t % p.wnH, b = t / p.wnH;
+  const int y = wy * p.wws + rr, x = wx * p.wws + cc;
+  return (y < p.wH && x < p.wW) ? ((int64_t)b * p.wH + y) * p.wW + x : -1;
+}
 
 // Linear tile id (already XCD-remapped: every XCD owns a contiguous run) -> (bm, bn).  Tiles are walked in column
 // groups `gn` N-tiles wide, row by row inside a group, so that the ~64 tiles an XCD runs concurrently form a roughly
@@ -192,11 +208,16 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       const int ml = pass * 8 + rsub;
       const int m = m0w + ml;
       if (m >= M || n0 >= N) continue;
+      int64_t mo = m;
+      if (p.wmode == 2) {
+        mo = gemm_window_row(p, m);
+        if (mo < 0) continue;
+      }
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ws[ml * ES + cg * 8 + e];
-      TO* cp = C + (int64_t)m * p.ldc + n0;
-      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+      TO* cp = C + mo * p.ldc + n0;
+      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
       if (n0 + 8 <= N) {
         if constexpr (sizeof(TO) == 2) {
           if (rp) {
@@ -240,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       for (int r = 0; r < 16; ++r) {
         const int m = m0w + i * 32 + mfma32_row(r, h);
         if (m >= M) continue;
-        float v = vg_act(acc[i][j][r] + bv, p.act) * gv;
+        float v = vg_act(acc[i][j][r] + bv, p.act) * gv;   // (window scatter takes the 16-byte path only: vg_gemm_window checks)
         if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
         vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
       }
@@ -280,7 +301,12 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     int gm = bm * GBM + row, gn = bn * GBN + row;
     gm = gm < M ? gm : M - 1;
     gn = gn < N ? gn : N - 1;
-    asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    if (p.wmode == 1) {
+      const int64_t r = gemm_window_row(p, gm);
+      asrc[i] = (r >= 0 ? A + r * p.lda : (const T*)p.zrow) + chunk * KPC;
+    } else {
+      asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    }
     wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
   }
   auto issue = [&](int kt, int buf) {
@@ -791,7 +817,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 144);
     }
     const int64_t g256 = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-    if (use256 && g256 >= 384) {   // >= 1.5 workgroups per CU even at 256x256: take the LDS-lean big tile
+    if (use256 && !p.wmode && g256 >= 384) {   // >= 1.5 workgroups per CU even at 256x256: take the LDS-lean big tile
       dim3 grid256((p.N + 255) / 256, (p.M + 255) / 256, batch);
       q.gn = pick_gn((p.M + 255) / 256, (p.N + 255) / 256);
       gemm_tile256_kernel<T, TO><<<grid256, 512, 4 * 256 * 144, st>>>(q);
@@ -817,7 +843,9 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
     }
     const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
-    if ((variant == 1283 || variant == 1284) && ring == 2 && p.K % (128 / (int)sizeof(T)) == 0 && p.M > 128 && tiles_ring >= 200) {
+    if (p.wmode) {
+      gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
+    } else if ((variant == 1283 || variant == 1284) && ring == 2 && p.K % (128 / (int)sizeof(T)) == 0 && p.M > 128 && tiles_ring >= 200) {
       dim3 gridr((p.N + 127) / 128, (p.M + 255) / 256, batch);
       q.gn = pick_gn((p.M + 255) / 256, (p.N + 127) / 128);
       gemm_tile_ring_kernel<T, TO><<<gridr, 512, 3 * 384 * 128, st>>>(q);
@@ -831,6 +859,10 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
+struct GemmWindow { int mode, H, W, ws; const void* zrow; };
+static thread_local GemmWindow g_window{0, 0, 0, 0, nullptr};
 
 extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
                        void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
@@ -848,7 +880,14 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   const int ovec = out_dtype == VG_BF16 ? 8 : 4;
   const int vec_out = (ldc % ovec == 0) && (sC % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                       (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
-  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1};
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1, 0, 0, 0, 0, 0, 0, nullptr};
+  if (g_window.mode) {
+    VG_CHECK(g_window.mode != 2 || vec_out, VG_ERR_UNSUPPORTED, "vg_gemm_window: scattered C/R rows must be 16-byte aligned (ldc=%lld ldr=%lld)",
+             (long long)ldc, (long long)ldr);
+    p.wmode = g_window.mode; p.wH = g_window.H; p.wW = g_window.W; p.wws = g_window.ws;
+    p.wnH = (g_window.H + g_window.ws - 1) / g_window.ws; p.wnW = (g_window.W + g_window.ws - 1) / g_window.ws;
+    p.zrow = g_window.zrow;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);
@@ -856,4 +895,18 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   if (in_dtype == VG_F32 && out_dtype == VG_BF16) return launch_gemm<float, bf16_t>(p, batch, st);
   vg_set_error("vg_gemm: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
   return VG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                              const float* gamma, const void* R, int64_t ldr, int N, int K, int in_dtype, int out_dtype, int act,
+                              int mode, int B, int H, int Wd, int ws, const void* zero_row, vg_stream_t stream) {
+  VG_CHECK((mode == 1 || mode == 2) && B > 0 && H > 0 && Wd > 0 && ws > 0, VG_ERR_ARG, "vg_gemm_window: bad window mode=%d B=%d H=%d W=%d ws=%d", mode, B, H, Wd, ws);
+  VG_CHECK(mode != 1 || zero_row, VG_ERR_ARG, "vg_gemm_window: mode 1 needs a row of K zeros");
+  const int nH = (H + ws - 1) / ws, nW = (Wd + ws - 1) / ws;
+  const int64_t M = (int64_t)B * nH * nW * ws * ws;
+  VG_CHECK(M > 16 && M < (1ll << 31), VG_ERR_UNSUPPORTED, "vg_gemm_window: %lld rows", (long long)M);
+  g_window = GemmWindow{mode, H, Wd, ws, zero_row};
+  const int rc = vg_gemm(A, lda, 0, W, ldw, 0, C, ldc, 0, bias, gamma, R, ldr, 0, (int)M, N, K, 1, in_dtype, out_dtype, act, 0, stream);
+  g_window.mode = 0;
+  return rc;
 }

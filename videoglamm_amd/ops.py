@@ -86,6 +86,46 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     return out
 
 
+_ZROWS = {}
+
+
+def _zero_row(K, dtype, device):
+    key = (dtype, str(device))
+    z = _ZROWS.get(key)
+    if z is None or z.numel() < K:
+        z = _ZROWS[key] = torch.zeros(max(K, 8192), dtype=dtype, device=device)
+    return z
+
+
+def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, residual=None):
+    """Hiera's windowed projections with the partition folded into the GEMM (vg_gemm_window).
+    scatter=False: x image-order [B,H,W,K] -> window-order [Bw, ws*ws, N]   (window_partition + linear)
+    scatter=True : x window-order [Bw, ws*ws, K] -> image-order [B,H,W,N] (+ residual [B,H,W,N])  (linear + unpartition + add)"""
+    lib = _lib.load()
+    N, K = w.shape
+    nH, nW = -(-H // ws), -(-W // ws)
+    Bw = B * nH * nW
+    x2, Mx, lda = _rows2d(x)
+    assert x2.shape[1] == K and w.stride(1) == 1 and _dt(w) == _dt(x2)
+    if scatter:
+        assert Mx == Bw * ws * ws, (x.shape, B, H, W, ws)
+        out = torch.empty(B, H, W, N, dtype=x.dtype, device=x.device)
+    else:
+        assert Mx == B * H * W, (x.shape, B, H, W)
+        assert residual is None
+        out = torch.empty(Bw, ws * ws, N, dtype=x.dtype, device=x.device)
+    o2, _, ldc = _rows2d(out)
+    r2, ldr = None, 0
+    if residual is not None:
+        assert residual.dtype == out.dtype
+        r2, Mr, ldr = _rows2d(residual)
+        assert Mr == B * H * W and r2.shape[1] == N
+    rc = lib.vg_gemm_window(_p(x2), lda, _p(w), w.stride(0), _p(o2), ldc, _p(_f32(bias)), _p(_f32(gamma)), _p(r2), ldr, N, K,
+                            _dt(x2), _dt(out), act, 2 if scatter else 1, B, H, W, ws, _p(_zero_row(K, x.dtype, x.device)), _stream())
+    _lib.check(rc, "vg_gemm_window")
+    return out
+
+
 def bmm_nt(a, w, out_dtype=None):
     """c[b] = a[b] @ w[b]^T ; a: [B,M,K], w: [B,N,K] (or [N,K] shared) -> [B,M,N]."""
     lib = _lib.load()
@@ -123,6 +163,28 @@ def attention(q, k, v, scale, causal=False):
                                   float(scale), int(bool(causal)), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit,
                                   None, _stream())
     _lib.check(rc, "vg_attention")
+    return out
+
+
+def attention_windows(q, k, v, scale):
+    """Self-attention inside many small independent windows: q/k/v [Bw, wtok, H, D] views of one fused projection.
+    Windows are packed back to back into 128-token sequences under a block-diagonal mask (vg_attention, causal = -wtok),
+    so a 16-token window costs 1/8 of a query tile instead of a whole padded one.  Falls back to attention() when the
+    windows do not pack (wtok >= 128, odd strides, or a window count that is not a multiple of the pack)."""
+    Bw, wtok, H, D = q.shape
+    pack = 128 // wtok if wtok > 0 else 0
+    ok = (pack >= 2 and Bw % pack == 0 and k.shape == q.shape and v.shape == q.shape
+          and all(t.stride(0) == wtok * t.stride(1) and t.stride(3) == 1 for t in (q, k, v)))
+    if not ok:
+        return attention(q, k, v, scale)
+    lib = _lib.load()
+    B, S = Bw // pack, pack * wtok
+    out = torch.empty(Bw, wtok, H, D, dtype=q.dtype, device=q.device)
+    rc = lib.vg_attention_splitkv(_p(q), _p(k), _p(v), _p(out), B, H, H, S, S, D,
+                                  S * q.stride(1), q.stride(1), q.stride(2), S * k.stride(1), k.stride(1), k.stride(2),
+                                  S * v.stride(1), v.stride(1), v.stride(2), S * H * D, H * D, D,
+                                  float(scale), -wtok, _dt(q), None, 0, 1, None, _stream())
+    _lib.check(rc, "vg_attention(windows)")
     return out
 
 

@@ -116,23 +116,29 @@ class SAM2:
                 shortcut = ops.pool2(shortcut, True)
         ws = blk["window"]
         if ws > 0:
-            xw = ops.window_partition(xn, ws)           # [Bw, ws*ws, C]
+            # window_partition rides in the qkv GEMM's A-row gather (padding rows read zeros, like the reference's F.pad)
+            qkv = ops.linear_window(xn, self.P.w(self.p + p + "attn.qkv"), self.P.b(self.p + p + "attn.qkv"), B, H, W, ws, scatter=False)
             h = w = ws
+            Bw = qkv.shape[0]
+            qkv = qkv.view(Bw, h * w, 3, nh, hd)
         else:
-            xw, h, w = xn.view(B, H * W, -1), H, W
-        Bw = xw.shape[0]
-        qkv = self.lin(p + "attn.qkv", xw).view(Bw, h * w, 3, nh, hd)
+            h, w, Bw = H, W, B
+            qkv = self.lin(p + "attn.qkv", xn.view(B, H * W, -1)).view(Bw, h * w, 3, nh, hd)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         if blk["q_stride"]:
             q = ops.pool2(q.reshape(Bw, h, w, do) if q.is_contiguous() else qkv.view(Bw, h, w, 3 * do)[..., :do], True)
             h, w = h // 2, w // 2
             q = q.view(Bw, h * w, nh, hd)
-        o = ops.attention(q, k, v, hd ** -0.5).view(Bw, h * w, do)
+        if ws > 0 and not blk["q_stride"]:
+            o = ops.attention_windows(q, k, v, hd ** -0.5).view(Bw, h * w, do)    # 16/64-token windows share query tiles
+        else:
+            o = ops.attention(q, k, v, hd ** -0.5).view(Bw, h * w, do)
         Hs, Ws = shortcut.shape[1:3]
         if ws > 0:
-            o = self.lin(p + "attn.proj", o)
+            # proj + window_unpartition + residual add in one pass (rows scattered to their pixels by the epilogue)
             wse = ws // 2 if blk["q_stride"] else ws
-            x = ops.add(shortcut, ops.window_unpartition(o, wse, B, Hs, Ws))
+            x = ops.linear_window(o, self.P.w(self.p + p + "attn.proj"), self.P.b(self.p + p + "attn.proj"), B, Hs, Ws, wse,
+                                  scatter=True, residual=shortcut)
         else:
             x = self.lin(p + "attn.proj", o, residual=shortcut.view(B, Hs * Ws, do)).view(B, Hs, Ws, do)
         hmid = self.lin(p + "mlp.layers.0", self.ln(p + "norm2", x, 1e-6), act=ops.ACT_GELU)
