@@ -43,18 +43,21 @@ template <> struct AMma<float> {
 template <typename T, int RS>
 __device__ __forceinline__ void pv_step(const char* vs, int col, int h, const f32x16_t& p, f32x16_t& o);
 
-template <int RS>
-__device__ __forceinline__ void pv_step_bf16(const char* vs, int col, int h, const f32x16_t& p, f32x16_t& o) {
+// bf16 PV step.  V is staged TRANSPOSED: Vt[d][key], 128-byte rows (64 keys), keys permuted inside every 16-key block
+// ([0-3, 8-11, 4-7, 12-15]) so that the 8 keys an MFMA A operand needs — rows {4h..4h+3, 8+4h..8+4h+3} of the P
+// accumulator (the 32x32 C-layout row map) — are one 16-byte group; groups are XOR-swizzled with (d>>1)&7 so the 32
+// rows of a ds_read_b128 hit distinct bank slots.  One ds_read_b128 per MFMA instead of sixteen ds_read_u16.
+__device__ __forceinline__ void pv_step_bf16t(const char* vt, int d, int kt, int h, const f32x16_t& p, f32x16_t& o) {
+  const char* row = vt + d * 128;
+  const int sw = (d >> 1) & 7;
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    u32x4_t a, b;
+    const u32x4_t a = *(const u32x4_t*)(row + (((kt * 4 + st * 2 + h) ^ sw) << 4));
+    u32x4_t b;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const int r0 = st * 8 + jj * 2, r1 = r0 + 1;
-      const uint32_t v0 = *(const bf16_t*)(vs + mfma32_row(r0, h) * RS + col * 2);
-      const uint32_t v1 = *(const bf16_t*)(vs + mfma32_row(r1, h) * RS + col * 2);
-      a[jj] = v0 | (v1 << 16);
-      b[jj] = (uint32_t)f2bf(p[r0]) | ((uint32_t)f2bf(p[r1]) << 16);
+      const int r0 = st * 8 + jj * 2;
+      b[jj] = f2bf2(p[r0], p[r0 + 1]);
     }
     o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                 __builtin_bit_cast(bf16x8_t, b), o, 0, 0, 0);
@@ -69,8 +72,15 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
   }
 }
 
+#ifndef VG_ATTN_PREFETCH
+#define VG_ATTN_PREFETCH 1
+#endif
+#ifndef VG_ATTN_MINW
+#define VG_ATTN_MINW 2
+#endif
+
 template <typename T, int DP, int BKV, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (DP <= 128 ? VG_ATTN_MINW : 1)) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int KPC = 16 / ES;
@@ -124,7 +134,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     kv_end = e < Skv ? e : Skv;
   }
 
-  float m_i = -INFINITY, l_i = 0.f;
+  float m_i = -INFINITY, l_i = 0.f;                       // running max in log2 units (see the softmax below)
+  const float sl2 = p.scale * 1.4426950408889634f;
   f32x16_t o[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
@@ -144,20 +155,72 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     const int e = kv_begin + p.split_len;
     kv_end = e < kv_end ? e : kv_end;
   }
-  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
-    __syncthreads();
-    for (int idx = tid; idx < BKV * CPR; idx += NT) {
-      const int row = idx / CPR, c = idx - row * CPR;
-      const int key = kv0 + row;
-      u32x4_t kv = zero4, vv = zero4;
-      if (key < Skv && c * KPC < D) {
-        kv = *(const u32x4_t*)(Kg + (int64_t)key * p.k_ss + c * KPC);
-        vv = *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC);
-      }
-      *(u32x4_t*)(Ks + row * RS + c * 16) = kv;
-      *(u32x4_t*)(Vs + row * RS + c * 16) = vv;
+  // K/V staging: a tile is fetched into registers one iteration ahead (the loads of tile t+1 are in flight while
+  // tile t is multiplied), then written to LDS — K as padded rows, V (bf16) transposed for pv_step_bf16t
+  constexpr bool VT = sizeof(T) == 2;
+  static_assert(!VT || BKV == 64, "the transposed V image assumes 64-key tiles");
+  constexpr int NKI = (BKV * CPR + NT - 1) / NT;                 // K chunks per thread per tile
+  constexpr int NVI = VT ? (16 * CPR + NT - 1) / NT : NKI;       // V items per thread: (key quad, chunk) | chunks
+  u32x4_t kreg[NKI], vreg[VT ? NVI * 4 : NVI];
+  auto fetch = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int idx = tid + i * NT, row = idx / CPR, c = idx - row * CPR, key = kv0 + row;
+      kreg[i] = (idx < BKV * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Kg + (int64_t)key * p.k_ss + c * KPC) : zero4;
+      if constexpr (!VT)
+        vreg[i] = (idx < BKV * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
     }
+    if constexpr (VT) {
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int item = tid + i * NT, kq = item & 15, c = item >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = kv0 + kq * 4 + j;
+          vreg[i * 4 + j] = (item < 16 * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
+        }
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int idx = tid + i * NT, row = idx / CPR, c = idx - row * CPR;
+      if (idx < BKV * CPR) {
+        *(u32x4_t*)(Ks + row * RS + c * 16) = kreg[i];
+        if constexpr (!VT) *(u32x4_t*)(Vs + row * RS + c * 16) = vreg[i];
+      }
+    }
+    if constexpr (VT) {
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int item = tid + i * NT, kq = item & 15, c = item >> 4;
+        if (item < 16 * CPR) {
+          const int b4 = (kq * 4) & 15;
+          const int pos = ((kq * 4) & ~15) + (b4 == 4 ? 8 : (b4 == 8 ? 4 : b4));   // key permutation inside a 16-block
+          const int grp = pos >> 3, half = (pos >> 2) & 1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int d = c * 8 + e, w = e >> 1, sh = (e & 1) * 16;
+            const uint32_t lo = ((vreg[i * 4 + 0][w] >> sh) & 0xffffu) | (((vreg[i * 4 + 1][w] >> sh) & 0xffffu) << 16);
+            const uint32_t hi = ((vreg[i * 4 + 2][w] >> sh) & 0xffffu) | (((vreg[i * 4 + 3][w] >> sh) & 0xffffu) << 16);
+            uint2 val;
+            val.x = lo;
+            val.y = hi;
+            *(uint2*)(Vs + d * 128 + ((grp ^ ((d >> 1) & 7)) << 4) + half * 8) = val;
+          }
+        }
+      }
+    }
+  };
+  constexpr bool PF = VG_ATTN_PREFETCH;
+  if (PF && kv_begin < kv_end) fetch(kv_begin);
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
+    if (!PF) fetch(kv0);
     __syncthreads();
+    stage();
+    __syncthreads();
+    if (PF && kv0 + BKV < kv_end) fetch(kv0 + BKV);
 
     f32x16_t s[NKT];
 #pragma unroll
@@ -173,27 +236,42 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       }
     }
 
+    // softmax in the exp2 domain: t = s * (scale * log2 e), so every score costs one fma + one v_exp_f32; m_i and the
+    // partials keep natural-log units (m = max(t) / log2 e) for the split-KV merge.  The mask arithmetic only runs on
+    // tiles that need it (sequence end, causal diagonal, window edges): the inner loop is VALU-bound, not MFMA-bound.
+    const bool need_mask = kv0 + BKV > Skv || p.causal < 0 || (p.causal > 0 && kv0 + BKV - 1 > (p.fold ? 0 : q0) + off);
     float mx = -INFINITY;
+    if (need_mask) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kt * 32 + mfma32_row(r, h);
-        const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi;
-        const float v = ok ? s[kt][r] * p.scale : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kt * 32 + mfma32_row(r, h);
+          const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi;
+          const float v = ok ? s[kt][r] * sl2 : -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = s[kt][r] * sl2;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);
+    const float m_new = fmaxf(m_i, mx);                       // log2 units
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_i - m_safe);
+    const float alpha = exp2f(m_i - m_safe);
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(s[kt][r] - m_safe);
+        const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_safe);
         s[kt][r] = pv;
         rs += pv;
       }
@@ -210,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       const char* vs = Vs + kt * 32 * RS;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        if constexpr (sizeof(T) == 2) pv_step_bf16<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+        if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kt, h, s[kt], o[dt]);
         else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
       }
     }
@@ -226,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
           const int d = dt * 32 + mfma32_row(r, h);
           if (d < D) pp[d] = o[dt][r];
         }
-      if (h == 0) { pp[D] = m_i; pp[D + 1] = l_i; }
+      if (h == 0) { pp[D] = m_i * 0.6931471805599453f; pp[D + 1] = l_i; }
     }
     return;
   }
@@ -246,7 +324,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 template <typename T, int DP, int BKV, int NW>
 static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RS = DP * sizeof(T) + 16;
-  constexpr int lds = (NW * 32 + 2 * BKV) * RS;
+  constexpr int vbytes = sizeof(T) == 2 ? DP * 128 : BKV * RS;   // bf16: transposed V image, DP rows of 64 keys
+  constexpr int lds = (NW * 32 + BKV) * RS + vbytes;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -15,12 +15,15 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #define VG_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer emulation it
+// replaces was ~5 VALU ops per value — a fifth of the flash-attention inner loop, which is VALU-bound)
+typedef __bf16 vg_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float vg_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+  const vg_f32x2_t x = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, vg_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 template <typename T> struct vg_elt;
 template <> struct vg_elt<float> {

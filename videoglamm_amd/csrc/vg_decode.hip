@@ -26,7 +26,7 @@ template <> __device__ __forceinline__ u32x4_t dec_pack<float>(const float* f) {
 template <> __device__ __forceinline__ u32x4_t dec_pack<bf16_t>(const float* f) {
   u32x4_t v;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (uint32_t)f2bf(f[2 * e]) | ((uint32_t)f2bf(f[2 * e + 1]) << 16);
+  for (int e = 0; e < 4; ++e) v[e] = f2bf2(f[2 * e], f[2 * e + 1]);
   return v;
 }
 template <typename T> __device__ __forceinline__ float dec_dot(const u32x4_t& a, const u32x4_t& b);

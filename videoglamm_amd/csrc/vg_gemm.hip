@@ -227,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
           }
           u32x4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
           *(u32x4_t*)cp = o;
         } else {
           if (rp) {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs p) {
             }
             u32x4_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
             *(u32x4_t*)cp = o;
           } else {
             if (rp) {

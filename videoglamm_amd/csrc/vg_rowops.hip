@@ -36,7 +36,7 @@ template <typename TO, int N> __device__ __forceinline__ void row_store(TO* p, c
   if constexpr (sizeof(TO) == 2 && N == 8) {
     u32x4_t r;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+    for (int e = 0; e < 4; ++e) r[e] = f2bf2(v[2 * e], v[2 * e + 1]);
     *(u32x4_t*)p = r;
   } else {
 #pragma unroll

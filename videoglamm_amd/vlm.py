@@ -101,8 +101,22 @@ class VisionTowers:
         images [Te,3,224,224], context [Te,3,336,336] -> visual tokens [Te*144 + Te*64, D] (context first)."""
         te = images.shape[0]
         assert te % 4 == 0, "the video encoder consumes 4-frame chunks (arch.py:133)"
-        vf = self.iv2(images.view(te // 4, 4, *images.shape[1:]))            # [nc, 4*L, Dv]
-        cf = self.clip(context_images)                                        # [Te, Lc, Dc]
+        video = images.view(te // 4, 4, *images.shape[1:])
+        if images.is_cuda and os.environ.get("VG_TOWERS_OVERLAP", "1") != "0":
+            # the two towers are independent and their GEMMs are small (M = 2050 / 4616 rows: ~1 round of tiles with a
+            # long tail each): InternVideo2 goes to a second stream so that the tails of one fill under the other
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=images.device)
+            main = torch.cuda.current_stream(images.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                vf = self.iv2(video)                                          # [nc, 4*L, Dv]
+            cf = self.clip(context_images)                                    # [Te, Lc, Dc]
+            main.wait_stream(self._side)
+            vf.record_stream(main)
+        else:
+            vf = self.iv2(video)
+            cf = self.clip(context_images)
         vf = self._projector("model.mm_projector", vf.contiguous())
         D = vf.shape[-1]
         g = int(round((vf.shape[1] // 4) ** 0.5))
