@@ -77,11 +77,24 @@ class GemmMeter:
             nbytes = (M * K + w.shape[0] * K) * es + M * N * y.element_size() * (2 if k.get("residual") is not None else 1)
             self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes))
             return y
+        def timed_window(x, w, bias, B, H, W, ws, scatter, **k):      # Hiera's window-folded projections: same kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig_window(x, w, bias, B, H, W, ws, scatter, **k)
+            e1.record()
+            M = B * (-(-H // ws)) * (-(-W // ws)) * ws * ws
+            N, K = w.shape
+            nbytes = (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size() * (2 if k.get("residual") is not None else 1)
+            self.rec.append((2.0 * M * N * K, e0, e1, nbytes))
+            return y
         self.ops.linear = timed
+        self.orig_window = self.ops.linear_window
+        self.ops.linear_window = timed_window
         return self
 
     def __exit__(self, *exc):
         self.ops.linear = self.orig
+        self.ops.linear_window = self.orig_window
 
     def summary(self):
         torch.cuda.synchronize()

@@ -278,10 +278,12 @@ __global__ __launch_bounds__(NW * 64, (DP <= 128 ? VG_ATTN_MINW : 1)) void attn_
     rs += __shfl_xor(rs, 32, 64);
     l_i = l_i * alpha + rs;
     m_i = m_new;
+    if (__any(alpha != 1.0f)) {      // the running max settles after a few tiles: skip the 16*NDT rescale multiplies then
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
 
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {

@@ -15,6 +15,17 @@ from . import ops
 NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
 
 
+def _stack_views(ts):
+    """cat(ts, 0) without the copy when ts are consecutive [1,...] slices of one batched tensor (what hiera_frames
+    hands out): 67 MB of FPN features per 8-frame chunk would otherwise take another trip through HBM."""
+    t0 = ts[0]
+    step = t0.stride(0) * t0.element_size()
+    if all(t.shape == t0.shape and t.stride() == t0.stride() and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr()
+           and t.data_ptr() == t0.data_ptr() + j * step for j, t in enumerate(ts)) and t0.shape[0] == 1:
+        return t0.as_strided((len(ts),) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(ts, dim=0)
+
+
 def hiera_layout(cfg):
     """(dim, dim_out, heads, window, q_stride) per block — R/modeling/backbones/hieradet.py:196-259."""
     stages, window_spec = cfg["stages"], cfg["window_spec"]
@@ -422,7 +433,7 @@ class SAM2:
             fr = frames[c0:c0 + self.frame_chunk]
             Tc = len(fr)
             if frame_feats is not None:
-                fpn = [torch.cat([frame_feats[t][lv] for t in fr], dim=0) for lv in range(3)]
+                fpn = [_stack_views([frame_feats[t][lv] for t in fr]) for lv in range(3)]
             else:
                 fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr])
             emb = ops.add(fpn[2].view(Tc, hw, 256), no_mem)
