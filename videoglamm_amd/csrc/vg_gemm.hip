@@ -177,6 +177,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 }
 
 // Epilogue shared by the 128x128-tile kernels: bias/activation/LayerScale, optional residual, store.
+// The wave's 64x64 fp32 accumulator tile is staged RAW through LDS (the K loop is done with it) so that every lane then
+// owns 8 consecutive columns of one row: residual loads and C stores become 16-byte accesses and 8 lanes write a full
+// 128-byte line, instead of 2-byte stores scattered over the MFMA accumulator layout.  Bias / activation / LayerScale
+// run on that row-major side (per-lane bias / gamma registers: a lane's 8 columns are the same in all 8 passes).
 template <typename TO>
 __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int m0w, int n0w, int bz,
                                                  int wave, int lane) {
@@ -184,9 +188,6 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
   const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
   if (p.vec_out) {
-    // Stage the wave's 64x64 fp32 tile through LDS (the K loop is done with it) so that every lane then owns 8
-    // consecutive columns of one row: residual loads and C stores become 16-byte accesses and 8 lanes write a
-    // full 128-byte line, instead of 2-byte stores scattered over the MFMA accumulator layout.
     constexpr int ES = 68;                       // fp32 row stride (64 + 4 pad)
     float* ws = (float*)smem + wave * 64 * ES;
 #pragma unroll
@@ -194,15 +195,18 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nl = j * 32 + l31;
-        const int n = n0w + nl;
-        const float bv = (p.bias && n < N) ? p.bias[n] : 0.f;
-        const float gv = (p.gamma && n < N) ? p.gamma[n] : 1.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ws[(i * 32 + mfma32_row(r, h)) * ES + nl] = vg_act(acc[i][j][r] + bv, p.act) * gv;
+        for (int r = 0; r < 16; ++r) ws[(i * 32 + mfma32_row(r, h)) * ES + nl] = acc[i][j][r];
       }
     __syncthreads();
     const int cg = lane & 7, rsub = lane >> 3;    // 8 column groups x 8 rows per pass
     const int n0 = n0w + cg * 8;
+    float bv[8], gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+      gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int ml = pass * 8 + rsub;
@@ -216,6 +220,8 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ws[ml * ES + cg * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(v[e] + bv[e], p.act) * gv[e];
       TO* cp = C + mo * p.ldc + n0;
       const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
       if (n0 + 8 <= N) {
@@ -859,6 +865,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
 
 // vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
 struct GemmWindow { int mode, H, W, ws; const void* zrow; };
