@@ -36,7 +36,7 @@ def close(a, b, **kw):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (257, 130, 72), (1, 512, 256), (7, 256, 2048), (16, 33, 64),
                                    (4096, 384, 144), (1025, 1408, 1408), (300, 4, 32), (17, 200, 8), (513, 96, 152),
-                                   (8192, 3072, 256), (5001, 4999 + 1, 72)])  # the last two take the 256x256-tile kernel
+                                   (8192, 3072, 256), (5001, 4999 + 1, 72)])  # the last two: many tiles, ragged M and N
 def test_gemm(cuda, dtype, M, N, K):
     from videoglamm_amd import ops
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)

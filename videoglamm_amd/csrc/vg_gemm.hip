@@ -504,167 +504,6 @@ __global__ __launch_bounds__(512) void gemm_tile_ring_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * 256 + wm * 64, bn * 128 + wn * 64, bz, wave, lane);
 }
 
-// 256x256 output tile / 512 threads (8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles).  Same
-// global -> registers -> padded-LDS double buffer as the 128x128 kernel, but every LDS byte written feeds 2x the
-// MFMAs and every fragment byte read 1.33x: the 128x128 kernel is LDS-bandwidth bound (per K step and CU:
-// ~830 cycles of ds_write + ~510 of ds_read against ~1020 of MFMA), this one is not.  Used when the grid of
-// 256x256 tiles still fills the chip (large-M Hiera / gate|up shapes).
-template <typename T, typename TO>
-__global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);
-  constexpr int BK = 128 / sizeof(T);
-  constexpr int ROWB = 144, TILEB = 256 * ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-
-  u32x4_t ra[4], rb[4];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i, row = c >> 3, kc = c & 7;
-      const int k = kt * BK + kc * KPC;
-      const int gm = bm * 256 + row, gn = bn * 256 + row;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      ra[i] = (gm < M && k < K) ? *(const u32x4_t*)(A + (int64_t)gm * p.lda + k) : z;
-      rb[i] = (gn < N && k < K) ? *(const u32x4_t*)(W + (int64_t)gn * p.ldw + k) : z;
-    }
-  };
-  auto swrite = [&](int buf) {
-    char* sa = smem + buf * 2 * TILEB;
-    char* sb = sa + TILEB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i, row = c >> 3, kc = c & 7;
-      *(u32x4_t*)(sa + row * ROWB + kc * 16) = ra[i];
-      *(u32x4_t*)(sb + row * ROWB + kc * 16) = rb[i];
-    }
-  };
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (K + BK - 1) / BK;
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const char* sa = smem + buf * 2 * TILEB + (wm * 128 + l31) * ROWB + h * 16;
-    const char* sb = smem + buf * 2 * TILEB + TILEB + (wn * 64 + l31) * ROWB + h * 16;
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-      const u32x4_t b0 = *(const u32x4_t*)(sb + g * 32);
-      const u32x4_t b1 = *(const u32x4_t*)(sb + 32 * ROWB + g * 32);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {   // one A fragment live at a time: 128 accumulators leave little room
-        const u32x4_t a = *(const u32x4_t*)(sa + i * 32 * ROWB + g * 32);
-        MmaOp<T>::run(a, b0, acc[i][0]);
-        MmaOp<T>::run(a, b1, acc[i][1]);
-      }
-    }
-    if (kt + 1 < nk) swrite(buf ^ 1);
-    __syncthreads();
-  }
-
-  // epilogue: two 64-row halves per wave through a 64x64 fp32 LDS staging tile (see the 128x128 kernel)
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 68;
-  float* ws = (float*)smem + wave * 64 * ES;
-  const int cg = lane & 7, rsub = lane >> 3;
-  const int n0 = bn * 256 + wn * 64 + cg * 8;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (p.vec_out) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nl = j * 32 + l31;
-          const int n = bn * 256 + wn * 64 + nl;
-          const float bv = (p.bias && n < N) ? p.bias[n] : 0.f;
-          const float gv = (p.gamma && n < N) ? p.gamma[n] : 1.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ws[(i * 32 + mfma32_row(r, h)) * ES + nl] = vg_act(acc[half * 2 + i][j][r] + bv, p.act) * gv;
-        }
-      __syncthreads();
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int ml = pass * 8 + rsub;
-        const int m = bm * 256 + wm * 128 + half * 64 + ml;
-        if (m >= M || n0 >= N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ws[ml * ES + cg * 8 + e];
-        TO* cp = C + (int64_t)m * p.ldc + n0;
-        const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
-        if (n0 + 8 <= N) {
-          if constexpr (sizeof(TO) == 2) {
-            if (rp) {
-              const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-            }
-            u32x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            *(u32x4_t*)cp = o;
-          } else {
-            if (rp) {
-              const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-            }
-            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-            *(f32x4_t*)cp = o0;
-            *(f32x4_t*)(cp + 4) = o1;
-          }
-        } else {
-          for (int e = 0; e < 8 && n0 + e < N; ++e) {
-            float o = v[e];
-            if (rp) o += vg_elt<TO>::ld(rp + e);
-            vg_elt<TO>::st(cp + e, o);
-          }
-        }
-      }
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = bn * 256 + wn * 64 + j * 32 + l31;
-          if (n >= N) continue;
-          const float bv = p.bias ? p.bias[n] : 0.f;
-          const float gv = p.gamma ? p.gamma[n] : 1.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = bm * 256 + wm * 128 + (half * 2 + i) * 32 + mfma32_row(r, h);
-            if (m >= M) continue;
-            float v = vg_act(acc[half * 2 + i][j][r] + bv, p.act) * gv;
-            if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
-            vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
-          }
-        }
-    }
-  }
-}
-
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& a, const u32x4_t& b);
 template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& a, const u32x4_t& b) {
   float s = 0.f;
@@ -814,21 +653,6 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
-    }
-    static int use256 = -1;
-    if (use256 < 0) {
-      const char* e = getenv("VG_GEMM_256");
-      use256 = e ? atoi(e) : 0;   // measured r01: hipcc spills 576 B/lane at the 256-register cap -> 133-160 TF/s (vs 500-830
-                                  // for the 128x128 kernel); kept behind VG_GEMM_256=1 until the staging moves to LDS-DMA
-      (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 144);
-    }
-    const int64_t g256 = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256) * batch;
-    if (use256 && !p.wmode && g256 >= 384) {   // >= 1.5 workgroups per CU even at 256x256: take the LDS-lean big tile
-      dim3 grid256((p.N + 255) / 256, (p.M + 255) / 256, batch);
-      q.gn = pick_gn((p.M + 255) / 256, (p.N + 255) / 256);
-      gemm_tile256_kernel<T, TO><<<grid256, 512, 4 * 256 * 144, st>>>(q);
-      VG_LAUNCH_CHECK();
-      return VG_OK;
     }
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
     // the fp32 epilogue staging needs 4 x 64 x 68 floats = 69632 B of LDS whatever the K step
