@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
+                    help="llama3-8b = BASELINE config C1 (default); phi3-mini = the released checkpoint's LLM")
     ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
     return ap.parse_args()
 
@@ -197,7 +199,7 @@ def main():
     from videoglamm_amd.model import VideoGLaMMForCausalLM
 
     torch.set_grad_enabled(False)
-    cfg = synth.videoglamm_llama3_8b()
+    cfg = synth.videoglamm_llama3_8b() if args.llm == "llama3-8b" else synth.videoglamm_phi3_mini()
     if args.tiny:
         cfg = dict(seg_token_idx=319, projector_depth=2,
                    iv2=dict(img_size=224, patch_size=14, embed_dim=128, depth=3, num_heads=4, mlp_hidden=256),
@@ -242,8 +244,8 @@ def main():
         "metric": "frames/sec end-to-end (text+masks)", "value": round(T * args.steps / dt, 3), "unit": "frames/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"C1: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
-                               f"Te={args.te}, Llama-3-8B bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
+        "config": {"workload": f"{'C1' if args.llm == 'llama3-8b' else 'C1 with the Phi-3-mini LLM'}: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
+                               f"Te={args.te}, {'Llama-3-8B' if args.llm == 'llama3-8b' else 'Phi-3-mini'} bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
                                f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),
                    "frames": T, "encoder_frames": args.te, "generated_tokens": int(out_ids.shape[1] - ids.shape[1]),
                    "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": f"frames sharded x{world}, LLM replicated",
@@ -273,7 +275,8 @@ def main():
         # only quoted for the workload it was measured on (C1 framewise, 1 GPU)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_glds.json")
-        if os.path.exists(pmc) and world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8:
+        if (os.path.exists(pmc) and world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8
+                and args.llm == "llama3-8b"):
             with open(pmc) as fh:
                 traffic = round(json.load(fh)["traffic_bytes_per_launch"])
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_glds_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,

@@ -147,9 +147,15 @@ def rotate_half(x):
 
 
 def llama_forward(sd, p, cfg, x):
-    """HF LlamaModel over inputs_embeds (causal, no cache) + final norm. x: [S,D] -> [S,D] normed hidden.
-    HF modeling_llama.py: LlamaDecoderLayer / LlamaAttention (repeat_kv GQA) / LlamaMLP / LlamaRMSNorm."""
+    """HF LlamaModel / Phi3Model over inputs_embeds (causal, no cache) + final norm. x: [S,D] -> [S,D] normed hidden.
+    HF modeling_llama.py: LlamaDecoderLayer / LlamaAttention (repeat_kv GQA) / LlamaMLP / LlamaRMSNorm; modeling_phi3.py is
+    the same arithmetic with fused qkv_proj / gate_up_proj weights (the LLM of the released checkpoint,
+    R/model/videogpt_plus/model/language_model/phi3.py:29-40) and a sliding window (2047 for Phi-3-mini-4k) that only
+    changes the mask of sequences longer than the window — rejected here and in the product rather than guessed at
+    (transformers 4.41 and 5.x disagree by one position on where the window ends)."""
     S, D = x.shape
+    if cfg.get("sliding_window") and S > cfg["sliding_window"]:
+        raise NotImplementedError("sequence longer than the sliding window")
     H, Hkv, eps = cfg["num_heads"], cfg["num_kv_heads"], cfg["rms_eps"]
     hd = D // H
     cos, sin = rope_tables(hd, S, cfg["rope_theta"])
@@ -157,9 +163,14 @@ def llama_forward(sd, p, cfg, x):
     for i in range(cfg["num_layers"]):
         l = f"{p}layers.{i}."
         h = rms_norm(x, sd[l + "input_layernorm.weight"], eps)
-        q = lin(sd, l + "self_attn.q_proj", h).view(S, H, hd).transpose(0, 1)
-        k = lin(sd, l + "self_attn.k_proj", h).view(S, Hkv, hd).transpose(0, 1)
-        v = lin(sd, l + "self_attn.v_proj", h).view(S, Hkv, hd).transpose(0, 1)
+        if l + "self_attn.qkv_proj.weight" in sd:   # HF Phi3Attention: one fused projection, rows q | k | v
+            qkv = lin(sd, l + "self_attn.qkv_proj", h)
+            q, k, v = qkv[:, : H * hd], qkv[:, H * hd:(H + Hkv) * hd], qkv[:, (H + Hkv) * hd:]
+        else:
+            q, k, v = (lin(sd, l + f"self_attn.{n}_proj", h) for n in "qkv")
+        q = q.reshape(S, H, hd).transpose(0, 1)
+        k = k.reshape(S, Hkv, hd).transpose(0, 1)
+        v = v.reshape(S, Hkv, hd).transpose(0, 1)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
         k = k.repeat_interleave(H // Hkv, dim=0)
@@ -167,7 +178,11 @@ def llama_forward(sd, p, cfg, x):
         a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5 + mask, dim=-1)
         x = x + lin(sd, l + "self_attn.o_proj", (a @ v).transpose(0, 1).reshape(S, D))
         h = rms_norm(x, sd[l + "post_attention_layernorm.weight"], eps)
-        x = x + lin(sd, l + "mlp.down_proj", F.silu(lin(sd, l + "mlp.gate_proj", h)) * lin(sd, l + "mlp.up_proj", h))
+        if l + "mlp.gate_up_proj.weight" in sd:     # HF Phi3MLP: gate, up = gate_up_proj(h).chunk(2, -1); down(up * silu(gate))
+            gate, up = lin(sd, l + "mlp.gate_up_proj", h).chunk(2, dim=-1)
+        else:
+            gate, up = lin(sd, l + "mlp.gate_proj", h), lin(sd, l + "mlp.up_proj", h)
+        x = x + lin(sd, l + "mlp.down_proj", F.silu(gate) * up)
     return rms_norm(x, sd[p + "norm.weight"], eps)
 
 

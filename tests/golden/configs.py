@@ -22,3 +22,6 @@ E2E = dict(
     clip=dict(img_size=336, patch_size=14, hidden=1024, mlp=512, num_layers=2, num_heads=16),
     llm=dict(vocab=320, hidden=64, ffn=176, num_layers=2, num_heads=4, num_kv_heads=2, rms_eps=1e-5, rope_theta=10000.0),
 )
+# Phi-3-mini shape family (the LLM of the released VideoGLaMM checkpoint): fused qkv_proj / gate_up_proj, MHA
+PHI3_TINY = dict(vocab=320, hidden=64, ffn=176, num_layers=2, num_heads=4, num_kv_heads=4, rms_eps=1e-5, rope_theta=10000.0,
+                 sliding_window=2047)

@@ -174,6 +174,24 @@ def gen_vlm():
     save("vlm_tiny.npz", **out)
 
 
+def gen_phi3():
+    """HF Phi3Model (the decoder the reference's VideoGPTPlusPhi3ForCausalLM wraps, language_model/phi3.py:29-40) on a tiny
+    config with the released checkpoint's structure: fused qkv_proj / gate_up_proj, MHA, sliding_window 2047."""
+    ri.install()
+    from transformers import Phi3Config, Phi3Model
+    from configs import PHI3_TINY
+
+    c = PHI3_TINY
+    llm = Phi3Model(Phi3Config(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["ffn"], num_hidden_layers=c["num_layers"],
+                               num_attention_heads=c["num_heads"], num_key_value_heads=c["num_kv_heads"], rms_norm_eps=c["rms_eps"],
+                               rope_theta=c["rope_theta"], max_position_embeddings=4096, original_max_position_embeddings=4096,
+                               sliding_window=c["sliding_window"], pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                               attn_implementation="eager")).eval()
+    load_seeded(llm, 5, None, "phi3_tiny_manifest.json")
+    emb = rnd((1, 45, c["hidden"]), 34)
+    save("phi3_tiny.npz", phi3_out=llm(inputs_embeds=emb).last_hidden_state[0])
+
+
 def build_ref_e2e(use_video_branch):
     """Compose VideoGLaMM_SAM2 with the Llama wrapper exactly the way R/model/VideoGLaMM.py:155-173,882-903
     composes it with Phi-3 (the reference ships no Llama composition — SURVEY headline 3)."""
@@ -317,6 +335,8 @@ if __name__ == "__main__":
         gen_sam2()
     if what in ("vlm", "all"):
         gen_vlm()
+    if what in ("phi3", "all"):
+        gen_phi3()
     if what in ("e2e", "all"):
         gen_e2e()
 

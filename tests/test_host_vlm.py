@@ -17,6 +17,15 @@ def towers(device, sd, cfg):
     return VisionTowers(Params(sd, device, torch.float32), cfg)
 
 
+def ops_decode_row(dec, xrow):
+    """one decode step on a given embedding row through the fused decode kernels (what the captured graph runs)."""
+    from videoglamm_amd import ops
+    h = dec._layers_decode(xrow.contiguous()) if dec.fused_decode else dec._layers(xrow, 0, dec.pos_dev)
+    ops.add_int_(dec.pos_dev, 1)
+    dec.pos += 1
+    return h
+
+
 def check_modules(device, tol):
     fx = G.fixture("vlm_tiny.npz")
     c = G.configs.IV2_TINY
@@ -42,6 +51,25 @@ def check_modules(device, tol):
     dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
     rows = [dec.forward(x[:40])] + [dec.forward(x[i:i + 1]) for i in range(40, 45)]
     torch.testing.assert_close(torch.cat(rows).cpu(), fx["llama_out"], **tol)
+
+    # Phi-3 layout (the released checkpoint's LLM): fused qkv_proj / gate_up_proj tensors, MHA — vs HF Phi3Model
+    c = G.configs.PHI3_TINY
+    sd = {"model." + k: v for k, v in G.weights("phi3_tiny_manifest.json", 5).items()}
+    x = G.rnd((1, 45, c["hidden"]), 34)[0].to(device)
+    ref = G.fixture("phi3_tiny.npz")["phi3_out"]
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    torch.testing.assert_close(dec.forward(x).cpu(), ref, **tol)
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    rows = [dec.forward(x[:40])]
+    if device.type == "cuda":      # the graph-replayed fused decode kernels (norm+GEMV, rope+append+attention+merge)
+        for i in range(40, 45):
+            hid = ops_decode_row(dec, x[i:i + 1])
+            rows.append(hid)
+    else:
+        rows += [dec.forward(x[i:i + 1]) for i in range(40, 45)]
+    torch.testing.assert_close(torch.cat(rows).cpu(), ref, **tol)
+    with pytest.raises(NotImplementedError):
+        LlamaDecoder(Params(sd, device, torch.float32), c, 4096)   # beyond the sliding window
 
 
 def check_e2e(device, branch):

@@ -92,7 +92,7 @@ def test_decode_step_kernels(cuda):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("N,K", [(96, 64), (6144, 4096), (33, 176), (4096, 14336), (257, 2048)])
+@pytest.mark.parametrize("N,K", [(96, 64), (6144, 4096), (33, 176), (4096, 14336), (257, 2048), (9216, 3072), (3072, 8192)])
 def test_decode_gemv(cuda, dtype, N, K):
     """fused [RMSNorm ->] GEMV [-> SwiGLU] [+ residual] of one row vs the fp32 statement, and vs the unfused HIP path."""
     from videoglamm_amd import ops

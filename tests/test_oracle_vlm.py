@@ -34,3 +34,11 @@ def test_llama():
     sd = G.weights("llama_tiny_manifest.json", 4)
     out = O.llama_forward(sd, "", c | dict(num_layers=c["num_layers"]), G.rnd((1, 45, c["hidden"]), 33)[0])
     torch.testing.assert_close(out, fx["llama_out"], **TOL)
+
+
+def test_phi3():
+    """fused qkv_proj / gate_up_proj decoder (the released checkpoint's LLM) vs HF Phi3Model, tests/golden/phi3_tiny.npz"""
+    c = G.configs.PHI3_TINY
+    sd = G.weights("phi3_tiny_manifest.json", 5)
+    out = O.llama_forward(sd, "", c, G.rnd((1, 45, c["hidden"]), 34)[0])
+    torch.testing.assert_close(out, G.fixture("phi3_tiny.npz")["phi3_out"], **TOL)

@@ -82,7 +82,7 @@ __device__ __forceinline__ void dec_gemv_store(const DecGemvArgs& p, int pi, flo
   }
 }
 
-// Fast path, K = NB * 256 16-byte chunks.  A wave owns `ppw` consecutive pairs and walks them as one flat sequence of
+// Fast path, K = a whole number of batches of chunks.  A wave owns `ppw` consecutive pairs and walks them as one flat sequence of
 // batches (2 rows x 4 chunks per lane), software-pipelined two batches deep = 16 x 16-byte loads in flight per lane.
 // Everything the kernel must wait for is requested up front, oldest-needed first (vmcnt retires in order): x, the norm
 // weights, then both pipeline stages of W — the norm runs underneath the HBM round trip.  The loop body is branch-free
@@ -90,13 +90,17 @@ __device__ __forceinline__ void dec_gemv_store(const DecGemvArgs& p, int pi, flo
 // because on gfx9 a pending store makes every later vmcnt wait a full drain.
 constexpr int DEC_MAX_PPW = 64;
 
-template <typename T, typename TO, bool GLU, int NB>
+// NB batches per row pair, CPB 16-byte chunks per lane per row per batch: K = NB * CPB * 64 chunks (CPB = 4 unless K only
+// divides by 128 chunks, e.g. Phi-3's hidden 3072 = 3 x 2 x 64 x 8).
+template <typename T, typename TO, bool GLU, int NB, int CPB = 4>
 __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dec_smem[];
   __shared__ float red[4];
   __shared__ float res[4][DEC_MAX_PPW][2];
   constexpr int KPC = 16 / sizeof(T);
   constexpr int NWV = KPC / 4;     // float4 loads of norm weight per chunk
+  constexpr int NCH = NB * CPB * 64;             // 16-byte chunks of x / of a weight row
+  constexpr int XN = (NCH + 255) / 256;          // chunks of x per thread (the last one may be partial: NCH % 256 == 128)
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t* xs = (u32x4_t*)dec_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,26 +112,26 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
   const int total = np * NB;
 
   // ---- 1. every load up front
-  u32x4_t xr[NB];
+  u32x4_t xr[XN];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) xr[i] = ((const u32x4_t*)p.x)[tid + 256 * i];
-  f32x4_t nwr[NB][NWV];
+  for (int i = 0; i < XN; ++i) xr[i] = ((const u32x4_t*)p.x)[min(tid + 256 * i, NCH - 1)];
+  f32x4_t nwr[XN][NWV];
   if (p.nw) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < XN; ++i)
 #pragma unroll
-      for (int j = 0; j < NWV; ++j) nwr[i][j] = ((const f32x4_t*)p.nw)[(tid + 256 * i) * NWV + j];
+      for (int j = 0; j < NWV; ++j) nwr[i][j] = ((const f32x4_t*)p.nw)[min(tid + 256 * i, NCH - 1) * NWV + j];
   }
   int ipi = p0, icb = 0;           // issue cursor (pair, batch within the pair)
-  u32x4_t va0[4], va1[4], vb0[4], vb1[4];
-  auto issue = [&](u32x4_t (&v0)[4], u32x4_t (&v1)[4]) {
+  u32x4_t va0[CPB], va1[CPB], vb0[CPB], vb1[CPB];
+  auto issue = [&](u32x4_t (&v0)[CPB], u32x4_t (&v1)[CPB]) {
     const int pc = min(ipi, npair - 1);                      // clamped: the two prologue issues are unconditional
     const int n0 = GLU ? pc : 2 * pc;
     const int n1 = GLU ? p.N + pc : min(2 * pc + 1, p.N - 1);
-    const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw) + icb * 256 + lane;
-    const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw) + icb * 256 + lane;
+    const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw) + icb * (64 * CPB) + lane;
+    const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw) + icb * (64 * CPB) + lane;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CPB; ++u) {
       v0[u] = __builtin_nontemporal_load(w0 + u * 64);
       v1[u] = __builtin_nontemporal_load(w1 + u * 64);
     }
@@ -142,18 +146,20 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
     if (p.nw) {
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int i = 0; i < XN; ++i) {
         float f[KPC];
         dec_unpack<T>(xr[i], f);
+        if (tid + 256 * i < NCH) {
 #pragma unroll
-        for (int e = 0; e < KPC; ++e) ss += f[e] * f[e];
+          for (int e = 0; e < KPC; ++e) ss += f[e] * f[e];
+        }
       }
       ss = wave_sum(ss);
       if (lane == 0) red[wave] = ss;
       __syncthreads();
       rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int i = 0; i < XN; ++i) {
         float f[KPC];
         dec_unpack<T>(xr[i], f);
 #pragma unroll
@@ -162,17 +168,18 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) xs[tid + 256 * i] = xr[i];
+    for (int i = 0; i < XN; ++i)
+      if (tid + 256 * i < NCH) xs[tid + 256 * i] = xr[i];
     __syncthreads();
   }
 
   // ---- 3. the stream
   float a0 = 0.f, a1 = 0.f;
   int cpl = 0, ccb = 0;            // consume cursor (local pair, batch within the pair)
-  auto consume = [&](const u32x4_t (&v0)[4], const u32x4_t (&v1)[4]) {
+  auto consume = [&](const u32x4_t (&v0)[CPB], const u32x4_t (&v1)[CPB]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const u32x4_t xv = xs[ccb * 256 + u * 64 + lane];
+    for (int u = 0; u < CPB; ++u) {
+      const u32x4_t xv = xs[ccb * (64 * CPB) + u * 64 + lane];
       a0 += dec_dot<T>(v0[u], xv);
       a1 += dec_dot<T>(v1[u], xv);
     }
@@ -298,6 +305,11 @@ static int launch_decode_gemv(DecGemvArgs p, hipStream_t st) {
   p.ppw = ppw;
   const size_t lds = (size_t)p.K * sizeof(T);
   const int nch = p.K / KPC;
+  if (nch == 384) {        // Phi-3-mini hidden size: three batches of two chunks per lane
+    decode_gemv_fast_kernel<T, TO, GLU, 3, 2><<<blocks, 256, lds, st>>>(p);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   const int nb = nch % 256 == 0 ? nch / 256 : 0;
   switch (nb) {
     case 1: decode_gemv_fast_kernel<T, TO, GLU, 1><<<blocks, 256, lds, st>>>(p); break;

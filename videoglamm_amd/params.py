@@ -52,8 +52,12 @@ class Params:
         dt = dtype or self.dtype
         return self._get(("t", name, dt), lambda: self.sd[name].to(device=self.device, dtype=dt).contiguous())
 
-    def fused(self, names):
-        """row-concatenation of several [N_i, K] weights (qkv, gate|up) -> ([sum N_i, Kpad], fp32 bias or None)."""
+    def fused(self, names, stored=None):
+        """row-concatenation of several [N_i, K] weights (qkv, gate|up) -> ([sum N_i, Kpad], fp32 bias or None).
+        stored: name of a checkpoint tensor that already IS that concatenation (Phi-3's qkv_proj / gate_up_proj)."""
+        if stored is not None and stored + ".weight" in self.sd:
+            return self.w(stored), self.b(stored)
+
         def make():
             w = torch.cat([self.sd[n + ".weight"] for n in names], dim=0)
             bs = [self.sd.get(n + ".bias") for n in names]

@@ -22,6 +22,17 @@ CLIP_L_336 = dict(img_size=336, patch_size=14, hidden=1024, mlp=4096, num_layers
 LLAMA3_8B = dict(vocab=128257, hidden=4096, ffn=14336, num_layers=32, num_heads=32, num_kv_heads=8, rms_eps=1e-5, rope_theta=500000.0)
 
 
+# the LLM of the released VideoGLaMM checkpoint (microsoft/Phi-3-mini-4k-instruct + [SEG], R/chat.py:31): fused
+# qkv_proj / gate_up_proj tensors, MHA with head_dim 96, sliding window 2047
+PHI3_MINI = dict(vocab=32065, hidden=3072, ffn=8192, num_layers=32, num_heads=32, num_kv_heads=32, rms_eps=1e-5, rope_theta=10000.0,
+                 sliding_window=2047, fused_proj=True)
+
+
+def videoglamm_phi3_mini():
+    """the released composition: Phi-3-mini (+[SEG]) + InternVideo2-1B + CLIP-L/336 + SAM2-L."""
+    return dict(seg_token_idx=32064, iv2=IV2_1B, clip=CLIP_L_336, llm=PHI3_MINI, sam2=SAM2_L, projector_depth=2)
+
+
 def videoglamm_llama3_8b():
     """BASELINE configs C1-C3: Llama-3-8B (+[SEG]) + InternVideo2-1B + CLIP-L/336 + SAM2-L, mlp2x_gelu adapters."""
     return dict(seg_token_idx=128256, iv2=IV2_1B, clip=CLIP_L_336, llm=LLAMA3_8B, sam2=SAM2_L, projector_depth=2)
@@ -211,12 +222,16 @@ def vlm_manifest(cfg):
     m["model.embed_tokens.weight"] = [c["vocab"], D]
     for i in range(c["num_layers"]):
         l = f"model.layers.{i}."
-        m[l + "self_attn.q_proj.weight"] = [c["num_heads"] * hd, D]
-        m[l + "self_attn.k_proj.weight"] = [c["num_kv_heads"] * hd, D]
-        m[l + "self_attn.v_proj.weight"] = [c["num_kv_heads"] * hd, D]
+        if c.get("fused_proj"):      # Phi-3 checkpoint layout
+            m[l + "self_attn.qkv_proj.weight"] = [(c["num_heads"] + 2 * c["num_kv_heads"]) * hd, D]
+            m[l + "mlp.gate_up_proj.weight"] = [2 * c["ffn"], D]
+        else:
+            m[l + "self_attn.q_proj.weight"] = [c["num_heads"] * hd, D]
+            m[l + "self_attn.k_proj.weight"] = [c["num_kv_heads"] * hd, D]
+            m[l + "self_attn.v_proj.weight"] = [c["num_kv_heads"] * hd, D]
+            m[l + "mlp.gate_proj.weight"] = [c["ffn"], D]
+            m[l + "mlp.up_proj.weight"] = [c["ffn"], D]
         m[l + "self_attn.o_proj.weight"] = [D, c["num_heads"] * hd]
-        m[l + "mlp.gate_proj.weight"] = [c["ffn"], D]
-        m[l + "mlp.up_proj.weight"] = [c["ffn"], D]
         m[l + "mlp.down_proj.weight"] = [D, c["ffn"]]
         m[l + "input_layernorm.weight"] = [D]
         m[l + "post_attention_layernorm.weight"] = [D]

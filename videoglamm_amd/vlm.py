@@ -131,7 +131,10 @@ class VisionTowers:
 
 
 class LlamaDecoder:
-    """HF LlamaModel arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache.
+    """HF LlamaModel / Phi3Model arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache.  Phi-3 (the
+    released checkpoint's LLM, R/model/videogpt_plus/model/language_model/phi3.py:29-40) is the same graph with the
+    q|k|v and gate|up projections already fused in the checkpoint; its sliding window (cfg["sliding_window"], 2047 for
+    Phi-3-mini-4k) only matters past that many positions, which this path rejects instead of attending differently.
 
     Prefill runs eagerly (sequence length varies per clip).  A decode step is fully static — the token id, the
     cache position and the KV length all live in device memory (tok_dev / pos_dev) — so it is captured ONCE into
@@ -144,6 +147,8 @@ class LlamaDecoder:
         self.D, self.H, self.Hkv = c["hidden"], c["num_heads"], c["num_kv_heads"]
         self.hd = self.D // self.H
         self.max_len = max_len
+        if c.get("sliding_window") and max_len > c["sliding_window"] + 1:
+            raise NotImplementedError(f"sequence budget {max_len} exceeds the sliding window {c['sliding_window']} of this LLM")
         dev, dt = params.device, params.dtype
         self.kc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
         self.vc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
@@ -176,7 +181,7 @@ class LlamaDecoder:
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
             h = ops.rmsnorm(x, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
-            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"])
+            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
             qkv = ops.linear(h, wqkv)
             ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, pos0, pos_dev)
             q = qkv[:, : self.H * self.hd].view(1, S, self.H, self.hd)
@@ -187,7 +192,7 @@ class LlamaDecoder:
                 o = ops.attention_decode(q, self.kc[i], self.vc[i], pos_dev, self.hd ** -0.5)
             x = ops.linear(o.view(S, self.D), P.w(l + "self_attn.o_proj"), residual=x)
             h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
-            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
+            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
             # gate|up in one GEMM; for the decode step the SwiGLU runs in that GEMV's epilogue (ops.linear(glu=True))
             x = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
@@ -200,12 +205,12 @@ class LlamaDecoder:
             self.attn_ws = ops.decode_attention_workspace(self.H, self.Hkv, self.hd, self.max_len, x.device)
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
-            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"])
+            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
             qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
             o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
                                      self.pos_dev, self.hd ** -0.5, self.attn_ws)
             x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
-            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"])
+            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
             a = ops.decode_gemv(x, wgu, norm_w=P.f32(l + "post_attention_layernorm.weight"), eps=c["rms_eps"], glu=True)
             x = ops.decode_gemv(a, P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
