@@ -189,6 +189,12 @@ def llama_forward(sd, p, cfg, x):
 # ----------------------------------------------------------------------------- generate + L6 [SEG]
 def encode_visual(sd, cfg, images, context_images):
     """encode_videos + project — arch.py:121-151,164-191.  images [Te,3,224,224], context [Te,3,336,336]."""
+    if context_images is None:
+        # image prompt (arch.py:110-119,243-245,393-397): CLIP patch features of the image(s) -> image_mm_projector, NO
+        # pooling, tokens of all images concatenated ([t, 576, D] -> [t*576, D])
+        cf = clip_forward(sd, "model.image_vision_tower.vision_tower.", cfg["clip"], images)
+        pf = projector(sd, "model.image_mm_projector", cf)
+        return pf.reshape(-1, pf.shape[-1])
     te = images.shape[0]
     chunks = images.reshape(te // 4, 4, *images.shape[1:])
     vf = iv2_forward(sd, "model.vision_tower.vision_encoder.", cfg["iv2"], chunks)[:, 1:]

@@ -329,8 +329,47 @@ def gen_e2e():
     save("e2e_tiny.npz", **fixtures)
 
 
+def gen_e2e_image():
+    """single-image prompt: inference(images=[img], context_images=None, ...) — the reference then takes the image path
+    of prepare_inputs_labels_for_multimodal (arch.py:243-245,393-397: encode_images + project(input_type="image"): CLIP
+    patch features -> image_mm_projector, no pooling, one <image> placeholder) and one SAM frame, framewise branch."""
+    from configs import E2E
+
+    m = build_ref_e2e(False)
+    load_seeded(m, 5, seeded.sam2_overrides("model.visual_model."), None)
+    S, H, W = SAM2_E2E["image_size"], 40, 56
+    img = rnd((1, 3, 336, 336), 51)
+    sam = rnd((1, 3, S, S), 52)
+    g = torch.Generator().manual_seed(53)
+    ids = torch.cat([torch.tensor([1, 5, 6, -200]), torch.randint(3, E2E["llm"]["vocab"], (12,), generator=g)])[None]
+    ctower = m.get_model().get_image_vision_tower()
+    assert len(ctower.vision_tower(img, output_hidden_states=True).hidden_states) == E2E["clip"]["num_layers"] + 1
+    feats = ctower(img, select_feature="patch")           # 4.41 semantics pinned (see gen_e2e)
+    ctower.forward = lambda imgs, select_feature="patch", batch_size=128: feats if imgs.shape == img.shape else (_ for _ in ()).throw(RuntimeError("unexpected CLIP input"))
+    fixtures = {}
+    with torch.no_grad():
+        probe = m.generate(images=[img], context_images=None, input_ids=ids, max_new_tokens=E2E["max_new_tokens"], num_beams=1, use_cache=False)
+        gen = probe[0, ids.shape[1]:].tolist()
+        seg_idx = gen[1]
+        m.config.seg_token_idx = seg_idx
+        print("generated", gen, "-> seg_token_idx", seg_idx)
+        out_ids, segs = m.inference(images=[img], context_images=None, images_for_sam=[sam], input_ids=ids, resize_list=[(S, S)],
+                                    original_size_list=[(H, W)], max_new_tokens=E2E["max_new_tokens"], use_sam2_video_branch=False)
+    seg = segs[0]
+    frames = sorted(seg.keys())
+    objs = sorted(seg[frames[0]].keys())
+    fixtures["seg_token_idx"] = np.array(seg_idx)
+    fixtures["input_ids"] = ids[0].numpy()
+    fixtures["output_ids"] = out_ids[0].numpy()
+    fixtures["masks"] = np.stack([np.stack([seg[t][k] for k in objs]) for t in frames])
+    print("image mode: output_ids", out_ids[0].tolist(), "n_seg", len(objs), "mask px", [int(seg[t][k].sum()) for t in frames for k in objs])
+    save("e2e_image.npz", **fixtures)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("e2e_image", "all"):
+        gen_e2e_image()
     if what in ("sam2", "all"):
         gen_sam2()
     if what in ("vlm", "all"):

@@ -111,3 +111,30 @@ def test_modules_hip_fp32(cuda):
 @pytest.mark.parametrize("branch", [False, True])
 def test_e2e_hip_fp32(cuda, branch):
     check_e2e(cuda, branch)
+
+
+def check_e2e_image(device):
+    """single-image prompt (context_images=None) vs the reference's own inference() — tests/golden/e2e_image.npz"""
+    from test_oracle_e2e import image_setup
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    fx, sd, cfg, inp = image_setup()
+    m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device)
+    out_ids, segs = m.inference([inp["images"]], None, [inp["images_for_sam"]], inp["input_ids"][None], [(1024, 1024)],
+                                [inp["original_size"]], max_new_tokens=inp["max_new_tokens"])
+    assert out_ids[0].tolist() == fx["output_ids"].long().tolist()
+    seg = segs[0]
+    got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
+    ref = fx["masks"].numpy() > 0.5
+    assert got.shape == ref.shape and (got & ref).sum() / (got | ref).sum() > 0.999
+
+
+def test_e2e_image_cpu(cpu_ops, monkeypatch):
+    from videoglamm_amd import _lib
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    check_e2e_image(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_e2e_image_hip_fp32(cuda):
+    check_e2e_image(cuda)

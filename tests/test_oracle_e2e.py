@@ -43,3 +43,23 @@ def test_e2e_framewise():
 
 def test_e2e_video_branch():
     _check(True)
+
+
+def image_setup():
+    fx = G.fixture("e2e_image.npz")
+    _, sd, cfg, _ = e2e_setup()
+    cfg = dict(cfg, seg_token_idx=int(fx["seg_token_idx"]))
+    S = G.configs.SAM2_E2E["image_size"]
+    inputs = dict(images=G.rnd((1, 3, 336, 336), 51), context_images=None, images_for_sam=G.rnd((1, 3, S, S), 52),
+                  input_ids=fx["input_ids"].long(), original_size=(40, 56), max_new_tokens=G.configs.E2E["max_new_tokens"])
+    return fx, sd, cfg, inputs
+
+
+def test_e2e_image_prompt():
+    """single-image prompt (context_images=None): CLIP -> image_mm_projector without pooling, one SAM frame"""
+    fx, sd, cfg, inputs = image_setup()
+    ids, seg = pipeline.inference(sd, cfg, use_sam2_video_branch=False, **inputs)
+    assert ids.tolist() == fx["output_ids"].long().tolist()
+    ref = fx["masks"].numpy() > 0.5
+    got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
+    assert got.shape == ref.shape and (got & ref).sum() / (got | ref).sum() > 0.9995

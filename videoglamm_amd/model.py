@@ -101,10 +101,9 @@ class VideoGLaMMForCausalLM:
 
     def _text_side(self, images, context_images, input_ids, max_new_tokens, after_prefill=None):
         assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
+        # context_images=None: single-image prompt (CLIP -> image_mm_projector without pooling, arch.py:243-245,393-397)
         ctx = context_images[0] if context_images is not None else None
-        if ctx is None:
-            raise NotImplementedError("single-image prompts (context_images=None) are outside the video hot path")
-        out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), ctx.to(self.device),
+        out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
                                 forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill)
         return out_ids.unsqueeze(0), emb

@@ -98,7 +98,13 @@ class VisionTowers:
 
     def encode(self, images, context_images):
         """encode_videos + project(input_type='video') — R/model/videogpt_plus/model/arch.py:121-151,164-191.
-        images [Te,3,224,224], context [Te,3,336,336] -> visual tokens [Te*144 + Te*64, D] (context first)."""
+        images [Te,3,224,224], context [Te,3,336,336] -> visual tokens [Te*144 + Te*64, D] (context first);
+        context_images None: images [t,3,336,336] -> [t*576, D]."""
+        if context_images is None:
+            # image prompt (encode_images + project(input_type="image"), arch.py:110-119,393-397): CLIP patch features of
+            # the image(s) -> image_mm_projector, no pooling, all tokens concatenated
+            cf = self._projector("model.image_mm_projector", self.clip(images).contiguous())
+            return cf.view(-1, cf.shape[-1])
         te = images.shape[0]
         assert te % 4 == 0, "the video encoder consumes 4-frame chunks (arch.py:133)"
         video = images.view(te // 4, 4, *images.shape[1:])
