@@ -63,8 +63,9 @@ int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, 
             void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
             const void* R, int64_t ldr, int64_t sR, int M, int N, int K, int batch,
             int in_dtype, int out_dtype, int act, int a_op, vg_stream_t stream);
-/* a_op = 1 (M <= 16 only): W holds 2N rows, gate rows then up rows; C[:, n] = silu(A·W[n]) * (A·W[N+n]) —
- * HF LlamaMLP act(gate_proj(x)) * up_proj(x) with the SwiGLU done in the GEMV epilogue (decode path). */
+/* a_op = 1: W holds 2N rows, gate rows then up rows; C[:, n] = silu(A·W[n] + b[n]) * (A·W[N+n] + b[N+n]) —
+ * HF LlamaMLP act(gate_proj(x)) * up_proj(x) with the SwiGLU done in the epilogue (gate / up / act rounded to the
+ * output dtype like the separate modules do).  M > 16 additionally needs 16-byte aligned C rows, no R / gamma / act. */
 
 /* The same contraction with Hiera's window_partition / window_unpartition (backbones/utils.py:16-38,41-60, called from
  * hieradet.py:128-136,147-148) folded into it.  GEMM row m is the WINDOW-order row index (window (b,wy,wx), token (r,c)),

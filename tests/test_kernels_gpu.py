@@ -53,15 +53,19 @@ def test_gemm(cuda, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M", [1, 3, 40])
-def test_gemm_glu_epilogue(cuda, dtype, M):
-    """silu(x.gate^T) * (x.up^T) with the SwiGLU in the skinny kernel's epilogue (M <= 16) or GEMM + vg_swiglu (M > 16)."""
+@pytest.mark.parametrize("M,K,F_", [(1, 328, 96), (3, 328, 96), (40, 328, 96), (300, 256, 200), (1697, 512, 1408), (129, 64, 176), (77, 72, 36)])
+def test_gemm_glu_epilogue(cuda, dtype, M, K, F_):
+    """silu(x.gate^T + b_g) * (x.up^T + b_u) with the SwiGLU in the epilogue: skinny kernel (M <= 16), tile kernel with the
+    gate | up halves of a tile gathered by row pointers (M > 16), GEMM + vg_swiglu for widths the fused form skips (36)."""
     from videoglamm_amd import ops
-    K, F_ = 328, 96
-    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(2 * F_, K, dtype=dtype, seed=2)
-    y = ops.linear(x.to(cuda), w.to(cuda), glu=True)
-    assert y.shape == (M, F_)
-    close(y, ref.linear(x, w, glu=True), **tol(dtype, K))
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(2 * F_, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias = rnd(2 * F_, seed=3)
+    for b in (None, bias):
+        y = ops.linear(x.to(cuda), w.to(cuda), None if b is None else b.to(cuda), glu=True)
+        assert y.shape == (M, F_)
+        close(y, ref.linear(x, w, b, glu=True), **tol(dtype, K))
+        if M > 16:   # same roundings as the two-kernel path, bit for bit
+            assert torch.equal(y, ops.swiglu(ops.linear(x.to(cuda), w.to(cuda), None if b is None else b.to(cuda))))
 
 
 def test_decode_step_kernels(cuda):

@@ -201,6 +201,51 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
     __syncthreads();
     const int cg = lane & 7, rsub = lane >> 3;    // 8 column groups x 8 rows per pass
     const int n0 = n0w + cg * 8;
+    if (p.a_op == 1) {
+      // SwiGLU: waves (wm,0) / (wm,1) staged the gate / up halves of the same 64 outputs; each of the two finishes 32
+      // of the 64 rows: y = round(silu(round(gate + b_g))) * round(up + b_u)  (HF LlamaMLP in the activation dtype,
+      // the arithmetic of vg_swiglu on the rounded GEMM outputs)
+      const int wm = wave >> 1, wn = wave & 1;
+      const float* wg = (const float*)smem + (wm * 2) * 64 * ES;
+      const float* wu = wg + 64 * ES;
+      float bg[8], bu[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bg[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+        bu[e] = (p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ml = wn * 32 + pass * 8 + rsub;
+        const int m = m0w + ml;                    // m0w = bm*128 + wm*64: both waves of the pair share the row band
+        if (m >= M || n0 >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g = wg[ml * ES + cg * 8 + e] + bg[e], u = wu[ml * ES + cg * 8 + e] + bu[e];
+          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+          g = g / (1.0f + __expf(-g));
+          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
+          v[e] = g * u;
+        }
+        TO* cp = C + (int64_t)m * p.ldc + n0;
+        if (n0 + 8 <= N) {
+          if constexpr (sizeof(TO) == 2) {
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+            *(u32x4_t*)cp = o;
+          } else {
+            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *(f32x4_t*)cp = o0;
+            *(f32x4_t*)(cp + 4) = o1;
+          }
+        } else {
+          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+        }
+      }
+      return;
+    }
     float bv[8], gv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -313,7 +358,15 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     } else {
       asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
     }
-    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+    if (p.a_op == 1) {
+      // fused SwiGLU (M > 16): the 128 W rows of a tile are 64 gate rows followed by the 64 up rows of the SAME 64 outputs
+      // (W = [gate; up], 2N rows): the interleave exists only in these row pointers, the checkpoint layout is untouched
+      const int o = bn * 64 + (row & 63);
+      const int oc = o < N ? o : N - 1;
+      wsrc[i] = W + (int64_t)(row < 64 ? oc : N + oc) * p.ldw + chunk * KPC;
+    } else {
+      wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+    }
   }
   auto issue = [&](int kt, int buf) {
     char* sa = smem + buf * 2 * TILEB + wave * 32 * 128;
@@ -405,7 +458,7 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
+  gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, p.a_op == 1 ? bn * 64 : bn * GBN + wn * 64, bz, wave, lane);
 }
 
 // 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
@@ -673,7 +726,11 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
     }
     const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
-    if (p.wmode) {
+    if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
+      dim3 gridg((p.N + 63) / 64, (p.M + GBM - 1) / GBM, batch);
+      q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + 63) / 64);
+      gemm_tile_glds_kernel<T, TO, true><<<gridg, 256, lds128, st>>>(q);
+    } else if (p.wmode) {
       gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
     } else if ((variant == 1283 || variant == 1284) && ring == 2 && p.K % (128 / (int)sizeof(T)) == 0 && p.M > 128 && tiles_ring >= 200) {
       dim3 gridr((p.N + 127) / 128, (p.M + 255) / 256, batch);
@@ -702,7 +759,7 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   VG_CHECK(A && W && C, VG_ERR_ARG, "vg_gemm: null pointer");
   VG_CHECK(M >= 0 && N > 0 && K > 0 && batch >= 1, VG_ERR_ARG, "vg_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   if (M == 0) return VG_OK;
-  VG_CHECK(a_op == 0 || (a_op == 1 && M <= 16), VG_ERR_ARG, "vg_gemm: a_op=1 (fused SwiGLU epilogue) needs M <= 16");
+  VG_CHECK(a_op == 0 || a_op == 1, VG_ERR_ARG, "vg_gemm: bad a_op %d", a_op);
   const int kpc = in_dtype == VG_BF16 ? 8 : 4;
   VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_gemm: bad in_dtype %d", in_dtype);
   VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && sA % kpc == 0 && sW % kpc == 0, VG_ERR_ARG,
@@ -711,6 +768,8 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   const int ovec = out_dtype == VG_BF16 ? 8 : 4;
   const int vec_out = (ldc % ovec == 0) && (sC % ovec == 0) && (((uintptr_t)C & 15) == 0) &&
                       (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
+  VG_CHECK(a_op == 0 || M <= 16 || (vec_out && !R && !gamma && batch == 1 && act == VG_ACT_NONE), VG_ERR_UNSUPPORTED,
+           "vg_gemm: a_op=1 with M > 16 needs 16-byte aligned C rows and no residual / LayerScale / activation / batch");
   GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1, 0, 0, 0, 0, 0, 0, nullptr};
   if (g_window.mode) {
     VG_CHECK(g_window.mode != 2 || vec_out, VG_ERR_UNSUPPORTED, "vg_gemm_window: scattered C/R rows must be 16-byte aligned (ldc=%lld ldr=%lld)",

@@ -61,8 +61,8 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     glu: w is [2N, K] = gate rows | up rows and y = silu(x @ gate^T) * (x @ up^T) — done in the GEMV epilogue for
     <= 16 rows (decode), as GEMM + vg_swiglu otherwise."""
     lib = _lib.load()
-    if glu and x.numel() // x.shape[-1] > 16:
-        return swiglu(linear(x, w, bias))
+    if glu and x.numel() // x.shape[-1] > 16 and ((w.shape[0] // 2) % 8 != 0 or residual is not None or gamma is not None or out is not None):
+        return swiglu(linear(x, w, bias))     # shapes the fused epilogue does not take (odd widths)
     x2, M, lda = _rows2d(x)
     N, K = w.shape
     if glu:
