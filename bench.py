@@ -262,16 +262,18 @@ def main():
         # with the Hiera/LLM stream overlap switched off: an event pair on one of two concurrently fed streams also
         # brackets the time the launch waits behind the other stream's kernels, which is not kernel time
         # (the rocprofv3 summary under profiles/ is taken on the timed, overlapped configuration)
-        prev = os.environ.get("VG_HIERA_START")
-        os.environ["VG_HIERA_START"] = "serial"
+        knobs = {"VG_HIERA_START": "serial", "VG_TOWERS_OVERLAP": "0"}
+        prev = {k: os.environ.get(k) for k in knobs}
+        os.environ.update(knobs)
         try:
             with GemmMeter(ops) as gm, DecodeMeter() as dm:
                 step()
         finally:
-            if prev is None:
-                os.environ.pop("VG_HIERA_START", None)
-            else:
-                os.environ["VG_HIERA_START"] = prev
+            for k, v in prev.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         flops, ms, n, nbytes = gm.summary()
         dec_ms, dec_n = dm.summary()
         peak = 2500.0
