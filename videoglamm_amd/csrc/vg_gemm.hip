@@ -461,6 +461,187 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, p.a_op == 1 ? bn * 64 : bn * GBN + wn * 64, bz, wave, lane);
 }
 
+// 128x128 tile with 64-BYTE K steps and a 35 KB LDS footprint: FOUR workgroups (16 waves) per CU instead of two.
+// The SQ counters of the 128-byte-step kernel show its waves parked on the DMA wait / barrier a third of the time with
+// only two waves per SIMD to cover for each other (profiles/r01_pmc_gemm_sq_stalls.json); this variant trades half the
+// MFMAs per barrier for twice the resident waves.  LDS rows are 64 B (4 chunks): slot = chunk ^ ((row >> 2) & 3) keeps
+// the 16 rows of a ds_read_b128 lane group on distinct bank slots.  The epilogue stages 32 rows per wave at a time.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 64 / sizeof(T);
+  constexpr int TILEB = 128 * 64;         // bytes per operand per stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // wave w stages rows [32w, 32w+32) of each operand in 2 DMA instructions of 16 rows (4 lanes per 64-byte row)
+  const T* asrc[2];
+  const T* wsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 32 + i * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    int gm = bm * GBM + row, gn = bn * GBN + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    if (p.wmode == 1) {
+      const int64_t r = gemm_window_row(p, gm);
+      asrc[i] = (r >= 0 ? A + r * p.lda : (const T*)p.zrow) + chunk * KPC;
+    } else {
+      asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    }
+    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    char* sa = smem + buf * 2 * TILEB + wave * 32 * 64;
+    char* sb = sa + TILEB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_tail = [&](int kt, int buf) {
+    char* sa = smem + buf * 2 * TILEB + wave * 32 * 64 + lane * 16;
+    char* sb = sa + TILEB;
+    u32x4_t va[2], vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wave * 32 + i * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      const bool ok = kt * BK + chunk * KPC < K;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      va[i] = ok ? *(const u32x4_t*)(asrc[i] + (int64_t)kt * BK) : z;
+      vb[i] = ok ? *(const u32x4_t*)(wsrc[i] + (int64_t)kt * BK) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(u32x4_t*)(sa + i * 1024) = va[i];
+      *(u32x4_t*)(sb + i * 1024) = vb[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
+  const int swa = (ra >> 2) & 3, swb = (rb >> 2) & 3;       // rows r and r+32 share the key: 32 >> 2 = 8 = 0 mod 4
+  const int nkf = K / BK, nk = (K + BK - 1) / BK;
+  if (nkf > 0) issue(0, 0);
+  else issue_tail(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkf) issue(kt + 1, buf ^ 1);
+    else if (kt + 1 < nk) issue_tail(kt + 1, buf ^ 1);
+    const char* sa = smem + buf * 2 * TILEB + ra * 64;
+    const char* sb = smem + buf * 2 * TILEB + TILEB + rb * 64;
+    u32x4_t fa0[2], fa1[2], fb0[2], fb1[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c = 2 * g + h;
+      fa0[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+      fb0[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+      fa1[g] = *(const u32x4_t*)(sa + 32 * 64 + ((c ^ swa) << 4));
+      fb1[g] = *(const u32x4_t*)(sb + 32 * 64 + ((c ^ swb) << 4));
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+      MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+      MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+      MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 68;
+  float* ws = (float*)smem + wave * 32 * ES;
+  const int cg = lane & 7, rsub = lane >> 3;
+  const int n0 = bn * GBN + wn * 64 + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ml = pass * 8 + rsub;
+      const int m = bm * GBM + wm * 64 + i * 32 + ml;
+      if (m >= M || n0 >= N) continue;
+      int64_t mo = m;
+      if (p.wmode == 2) {
+        mo = gemm_window_row(p, m);
+        if (mo < 0) continue;
+      }
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      TO* cp = C + mo * p.ldc + n0;
+      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N && p.vec_out) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+  }
+}
+
 // 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
 // by LDS-DMA two K-steps ahead.  The 128x128 kernels drain their DMA queue at every barrier (vmcnt(0) inside
 // __syncthreads) with only one K-step (~0.2 us of MFMA) of prefetch distance against ~1-2 us of L2/HBM latency; here
@@ -726,7 +907,17 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
     }
     const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
-    if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
+    // few K-steps per tile (K <= 1536 B... elements x size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
+    // (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
+    static int k64 = -1;
+    if (k64 < 0) {
+      const char* e = getenv("VG_GEMM_K64B");
+      k64 = e ? atoi(e) : 1;
+    }
+    const bool small_k = k64 && (variant == 1283 || variant == 1284) && (int64_t)p.K * (int)sizeof(T) <= 3072 && p.a_op == 0;
+    if (small_k) {
+      gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
+    } else if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
       dim3 gridg((p.N + 63) / 64, (p.M + GBM - 1) / GBM, batch);
       q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + 63) / 64);
       gemm_tile_glds_kernel<T, TO, true><<<gridg, 256, lds128, st>>>(q);
@@ -738,6 +929,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       gemm_tile_ring_kernel<T, TO><<<gridr, 512, 3 * 384 * 128, st>>>(q);
     } else if (variant == 1283) gemm_tile_glds_kernel<T, TO><<<grid, 256, lds128, st>>>(q);
     else if (variant == 1284) gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
+    else if (variant == 644) gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     else if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(q);
     else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(q);
     else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(q);
