@@ -65,6 +65,12 @@ class GemmMeter:
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.linear, []
 
+    @staticmethod
+    def kernel_of(row_bytes, glu):
+        """the launcher's shape rule (vg_gemm.hip launch_tile): rows of K <= 3072 B without the GLU epilogue run on the
+        64-byte-step kernel, everything else on the 128-byte-step LDS-DMA kernel"""
+        return "k64b" if (row_bytes <= 3072 and not glu and os.environ.get("VG_GEMM_K64B", "1") != "0") else "glds"
+
     def __enter__(self):
         def timed(x, w, *a, **k):
             M = x.numel() // x.shape[-1]
@@ -77,7 +83,7 @@ class GemmMeter:
             N, K = w.shape[0] // (2 if k.get("glu") else 1), w.shape[1]
             es = x.element_size()
             nbytes = (M * K + w.shape[0] * K) * es + M * N * y.element_size() * (2 if k.get("residual") is not None else 1)
-            self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes))
+            self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes, self.kernel_of(K * es, k.get("glu"))))
             return y
         def timed_window(x, w, bias, B, H, W, ws, scatter, **k):      # Hiera's window-folded projections: same kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -87,7 +93,7 @@ class GemmMeter:
             M = B * (-(-H // ws)) * (-(-W // ws)) * ws * ws
             N, K = w.shape
             nbytes = (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size() * (2 if k.get("residual") is not None else 1)
-            self.rec.append((2.0 * M * N * K, e0, e1, nbytes))
+            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(K * x.element_size(), False)))
             return y
         self.ops.linear = timed
         self.orig_window = self.ops.linear_window
@@ -98,11 +104,12 @@ class GemmMeter:
         self.ops.linear = self.orig
         self.ops.linear_window = self.orig_window
 
-    def summary(self):
+    def summary(self, kernel):
         torch.cuda.synchronize()
-        flops = sum(r[0] for r in self.rec)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
-        return flops, ms, len(self.rec), sum(r[3] for r in self.rec)
+        rec = [r for r in self.rec if r[4] == kernel]
+        flops = sum(r[0] for r in rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        return flops, ms, len(rec), sum(r[3] for r in rec)
 
 
 class DecodeMeter:
@@ -274,24 +281,31 @@ def main():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        flops, ms, n, nbytes = gm.summary()
         dec_ms, dec_n = dm.summary()
         peak = 2500.0
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summary):
         # only quoted for the workload it was measured on (C1 framewise, 1 GPU)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_glds.json")
-        if (os.path.exists(pmc) and world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8
-                and args.llm == "llama3-8b"):
-            with open(pmc) as fh:
-                traffic = round(json.load(fh)["traffic_bytes_per_launch"])
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_tile_glds_kernel<bf16> (vg_gemm)", "achieved": round(ach, 1), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                           "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
-                           "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
-                           "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
-                           "kernel_ms_per_step": round(ms, 2)}
+        pmc_ok = (world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8
+                  and args.llm == "llama3-8b")
+
+        def roof(kernel, label, pmc_file):
+            flops, ms, n, nbytes = gm.summary(kernel)
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", pmc_file)
+            if pmc_ok and os.path.exists(pmc):
+                with open(pmc) as fh:
+                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
+            return {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
+                    "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
+                    "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                    "kernel_ms_per_step": round(ms, 2)}
+        # the dominant kernel (most GPU time per step): the 128-byte-K-step LDS-DMA tile GEMM; its small-K sibling is
+        # reported beside it
+        res["roofline"] = roof("glds", "gemm_tile_glds_kernel<bf16> (vg_gemm, K*2 > 3072 B or GLU epilogue)", "r01_pmc_gemm_glds.json")
+        res["roofline_small_k"] = roof("k64b", "gemm_tile_k64b_kernel<bf16> (vg_gemm / vg_gemm_window, K*2 <= 3072 B)", "r01_pmc_gemm_k64b.json")
         if dec_n and not args.tiny:
             c = cfg["llm"]
             hd = c["hidden"] // c["num_heads"]

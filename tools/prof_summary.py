@@ -13,7 +13,7 @@ print(f"{'ms/step':>10} {'launches/step':>14} {'avg us':>10}  kernel")
 for r in rows[:30]:
     print(f"{r[2] / steps:10.2f} {r[1] / steps:14.1f} {r[3]:10.1f}  {r[0][:110]}")
 try:
-    pm = list(cur.execute("select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
+    pm = list(cur.execute("select k.name, p.counter_name, count(*), sum(p.counter_value), avg(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
                           "group by k.name, p.counter_name order by 4 desc limit 20"))
     if pm:
         print("\nPMC (sum over dispatches, avg per dispatch):")

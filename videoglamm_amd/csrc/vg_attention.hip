@@ -78,9 +78,12 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #ifndef VG_ATTN_MINW
 #define VG_ATTN_MINW 2
 #endif
+#ifndef VG_ATTN_MINW96
+#define VG_ATTN_MINW96 2
+#endif
 
 template <typename T, int DP, int BKV, int NW>
-__global__ __launch_bounds__(NW * 64, (DP <= 128 ? VG_ATTN_MINW : 1)) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? VG_ATTN_MINW : 1))) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int KPC = 16 / ES;
