@@ -219,6 +219,38 @@ int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int 
 int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C,
                      int dtype, vg_stream_t stream);
 
+/* ---- mask post-processing and evaluation counts: integer / byte work ---- */
+/* Connected components of N binary images [N,H,W] (uint8, foreground = nonzero), connectivity 4 or 8.
+ * labels: 0 on background, 1 + the smallest linear pixel index (y*W + x) of the component on foreground;
+ * counts: area of the pixel's component, 0 on background.  Replaces _C.get_connected_componnets
+ * (R/model/segment_anything_2/sam2/csrc/connected_components.cu:213-282, 8-connectivity; called from
+ * R/model/segment_anything_2/sam2/utils/misc.py:47-63): same partition and areas; the reference's label VALUES are an
+ * artefact of its 2x2-block union-find, only labels > 0 and the areas are consumed (misc.py:223-224).
+ * Odd H / W are accepted (the reference asserts even sizes, connected_components.cu:226-227). */
+int vg_connected_components(const uint8_t* mask, int32_t* labels, int32_t* counts, int N, int H, int W,
+                            int connectivity, vg_stream_t stream);
+/* out = mask with every 4-connected component of fewer than min_size pixels cleared (uint8 0/1).
+ * remove_small_blobs, R/eval_gcg_infer.py:20-29 (skimage.morphology.remove_small_objects on a bool image).
+ * ws_labels / ws_counts: int32 [N,H,W] scratch. */
+int vg_remove_small_blobs(const uint8_t* mask, uint8_t* out, int32_t* ws_labels, int32_t* ws_counts, int N, int H,
+                          int W, int min_size, vg_stream_t stream);
+/* out = scores with every 8-connected background (score <= 0) component of area <= max_area set to 0.1
+ * fill_holes_in_mask_scores, R/model/segment_anything_2/sam2/utils/misc.py:216-227 (switched off in the reference's
+ * predictor, sam2_video_predictor.py:971-975: a flag on this side too). */
+int vg_fill_holes(const float* scores, float* out, int32_t* ws_labels, int32_t* ws_counts, int N, int H, int W,
+                  int max_area, vg_stream_t stream);
+/* inter[p,g] = |a_p & b_g|, uni[p,g] = |a_p | b_g| over L pixels; a:[P,L], b:[G,L] uint8 (nonzero = set).
+ * diagonal != 0 (P == G): only the pairs (i, i), outputs [P] — the per-frame Jaccard of one object.
+ * compute_iou R/eval_gcg_metrics.py:26-37; db_eval_iou R/eval_referdavis_metrics.py:147-176 (no void pixels). */
+int vg_mask_pair_counts(const uint8_t* a, const uint8_t* b, int64_t* inter, int64_t* uni, int P, int G, int64_t L,
+                        int diagonal, vg_stream_t stream);
+/* out[n] = {n_fg, n_gt, fg_match, gt_match}: pixels of the two 1-pixel boundary maps (_seg2bmap,
+ * R/eval_referdavis_metrics.py:262-305, same-size case) and how many of each lie within the disk of the given radius
+ * (skimage disk: dx^2 + dy^2 <= r^2; cv2.dilate border = ignore) of the other one — the integer part of f_measure,
+ * R/eval_referdavis_metrics.py:194-259.  fg, gt: uint8 [N,H,W]. */
+int vg_boundary_counts(const uint8_t* fg, const uint8_t* gt, int64_t* out, int N, int H, int W, int radius,
+                       vg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

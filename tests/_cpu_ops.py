@@ -289,4 +289,45 @@ def upsample2_add(lateral, top):
     return (lateral.float() + up).to(lateral.dtype)
 
 
+# ---- mask post-processing / evaluation counts: the numpy restatement (oracle/postproc.py) behind the same signatures
+def _np_mask(m):
+    return m.detach().cpu().numpy().astype(bool)
+
+
+def connected_components(mask, connectivity=8):
+    from oracle import postproc as _op
+    m = _np_mask(mask)
+    lab, cnt = _op.connected_components(m.reshape(-1, *m.shape[-2:]), connectivity)
+    return torch.from_numpy(lab.reshape(m.shape)), torch.from_numpy(cnt.reshape(m.shape))
+
+
+def remove_small_blobs(mask, min_size):
+    from oracle import postproc as _op
+    import numpy as _n
+    m = _np_mask(mask)
+    out = _n.stack([_op.remove_small_blobs(x, min_size) for x in m.reshape(-1, *m.shape[-2:])]).reshape(m.shape)
+    return torch.from_numpy(out.astype(_n.uint8))
+
+
+def fill_holes(scores, max_area):
+    from oracle import postproc as _op
+    return torch.from_numpy(_op.fill_holes_in_mask_scores(scores.detach().cpu().numpy(), max_area))
+
+
+def mask_pair_counts(a, b, diagonal=False):
+    a, b = _np_mask(a), _np_mask(b)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    if diagonal:
+        return torch.from_numpy((a & b).sum(1)), torch.from_numpy((a | b).sum(1))
+    return torch.from_numpy((a[:, None] & b[None]).sum(-1)), torch.from_numpy((a[:, None] | b[None]).sum(-1))
+
+
+def boundary_counts(fg, gt, radius):
+    from oracle import postproc as _op
+    import numpy as _n
+    f, g = _np_mask(fg), _np_mask(gt)
+    f, g = f.reshape(-1, *f.shape[-2:]), g.reshape(-1, *g.shape[-2:])
+    return torch.from_numpy(_n.array([_op.boundary_counts(x, y, radius) for x, y in zip(f, g)], dtype=_n.int64))
+
+
 ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]

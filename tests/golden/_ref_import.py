@@ -125,3 +125,20 @@ def build_sam2(cfg):
     m = instantiate(cfg)
     m.eval()
     return m
+
+
+def functions(relpath, names, namespace):
+    """Run selected top-level function definitions of a reference script WITHOUT executing the script's module-level
+    code (the eval scripts parse arguments / import absent packages at import time).  The definitions are compiled from
+    the file where it lies and executed in `namespace`; nothing of them is written anywhere."""
+    import ast
+
+    path = os.path.join(R, relpath)
+    with open(path) as f:
+        tree = ast.parse(f.read(), path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in picked}
+    if missing:
+        raise KeyError(f"{relpath}: no top-level function(s) {sorted(missing)}")
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), namespace)
+    return [namespace[n] for n in names]

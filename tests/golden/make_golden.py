@@ -428,3 +428,32 @@ def gen_host():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("host", "all")):
     gen_host()
+
+
+def gen_postproc():
+    """mask post-processing / evaluation metrics: outputs of the reference's OWN functions on seeded masks.
+    compute_iou / compute_miou (eval_gcg_metrics.py), db_eval_iou / _seg2bmap (eval_referdavis_metrics.py) are plain numpy
+    and run here; remove_small_blobs / f_measure need scikit-image + OpenCV (absent) and stay unpinned (oracle/postproc.py)."""
+    import math
+
+    from oracle import postproc as op
+
+    ns = {"np": np, "math": math}
+    compute_iou, compute_miou = ri.functions("eval_gcg_metrics.py", ["compute_iou", "compute_miou"], ns)
+    db_eval_iou, seg2bmap = ri.functions("eval_referdavis_metrics.py", ["db_eval_iou", "_seg2bmap"], ns)
+    T, H, W = 3, 46, 83                       # odd width, not a multiple of the 64-pixel wave segment
+    pred = np.stack([op.blobs((T, H, W), 100 + i, density=0.35 + 0.1 * i) for i in range(3)])     # [P,T,H,W]
+    gt = np.stack([op.blobs((T, H, W), 200 + i, density=0.4) for i in range(2)])                   # [G,T,H,W]
+    gt[1] = pred[0] ^ op.blobs((T, H, W), 300, density=0.05, smooth=1)                              # one good match
+    pred[2, 1] = False                                                                             # an empty frame
+    gt[0, 1] = False
+    iou = np.array([[compute_iou(p, g) for g in gt] for p in pred])
+    miou = compute_miou(list(pred), list(gt))
+    jac = np.stack([np.asarray(db_eval_iou(gt[j], pred[i]), np.float64) for i in range(3) for j in range(2)]).reshape(3, 2, T)
+    bmap = np.stack([np.stack([seg2bmap(pred[i, t].copy()) for t in range(T)]) for i in range(3)])
+    save("postproc.npz", pred=pred.astype(np.uint8), gt=gt.astype(np.uint8), iou=iou, miou=np.float64(miou), jaccard=jac,
+         bmap=bmap.astype(np.uint8))
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("postproc", "all")):
+    gen_postproc()

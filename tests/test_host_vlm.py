@@ -91,6 +91,37 @@ def check_e2e(device, branch):
     assert iou > 0.999, iou
 
 
+def check_e2e_min_blob(device):
+    """min_blob_size: the device-side remove_small_blobs of the thresholded masks == the reference's host-side
+    post-processing (eval_gcg_infer.py:182) applied to the reference's own masks."""
+    from oracle import postproc as OP
+    from test_oracle_e2e import e2e_setup
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    fx, sd, cfg, inp = e2e_setup()
+    m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device, min_blob_size=20)
+    _, segs = m.inference([inp["images"]], [inp["context_images"]], [inp["images_for_sam"]], inp["input_ids"][None],
+                          [(1024, 1024)], [inp["original_size"]], max_new_tokens=inp["max_new_tokens"])
+    seg = segs[0]
+    got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
+    ref = fx["framewise_masks"].numpy() > 0.5
+    want = np.stack([np.stack([OP.remove_small_blobs(x, 20) for x in fr]) for fr in ref])
+    assert got.shape == want.shape
+    assert (got & want).sum() / max((got | want).sum(), 1) > 0.999
+    assert not (got & ~(ref | (got ^ want))).any()          # nothing is added by the blob filter
+
+
+def test_e2e_min_blob_cpu(cpu_ops, monkeypatch):
+    from videoglamm_amd import _lib
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    check_e2e_min_blob(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_e2e_min_blob_hip_fp32(cuda):
+    check_e2e_min_blob(cuda)
+
+
 def test_modules_cpu(cpu_ops):
     check_modules(torch.device("cpu"), dict(rtol=1e-4, atol=1e-4))
 

@@ -56,6 +56,11 @@ def _sig(lib):
         "vg_window_unpartition": ([P, P, I, I, I, I, I, I, P], c_int),
         "vg_bilinear": ([P, P, I, I, I, I, I, P], c_int),
         "vg_upsample2_add": ([P, P, P, I, I, I, I, I, P], c_int),
+        "vg_connected_components": ([P, P, P, I, I, I, I, P], c_int),
+        "vg_remove_small_blobs": ([P, P, P, P, I, I, I, I, P], c_int),
+        "vg_fill_holes": ([P, P, P, P, I, I, I, I, P], c_int),
+        "vg_mask_pair_counts": ([P, P, P, P, I, I, L, I, P], c_int),
+        "vg_boundary_counts": ([P, P, P, I, I, I, I, P], c_int),
     }
     for name, (args, res) in S.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -40,13 +40,14 @@ class FrameSharder:
         """all-gather of the [N,256] [SEG] embeddings; every rank adopts rank 0's copy."""
         return self._all_gather(emb)[0]
 
-    def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None):
+    def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None, binarize=None):
         """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W].
-        frame_feats: optional precomputed Hiera features of THIS rank's frames ({frame: [3 levels]})."""
+        frame_feats: optional precomputed Hiera features of THIS rank's frames ({frame: [3 levels]});
+        binarize: logits -> uint8 masks of this rank's frames (per-frame work, so it shards with them); default logit > 0."""
         emb = self.sync_seg_embeddings(emb)
         frames = self.my_frames(images_for_sam.shape[0])
         logits, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats)
-        local = ops.threshold(logits)                      # [T/world, N, H, W] uint8, on device
+        local = (binarize or ops.threshold)(logits)                        # [T/world, N, H, W] uint8, on device
         return torch.cat(self._all_gather(local), dim=0).cpu()
 
     def gather_frame_feats(self, local_feats, T):

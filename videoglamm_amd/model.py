@@ -39,6 +39,10 @@ class VideoGLaMMForCausalLM:
         self.towers = VisionTowers(self.P, self.cfg)
         self.sam2 = SAM2(self.P, "model.visual_model.", self.cfg["sam2"])
         self.comm = comm
+        # > 0: clear 4-connected blobs smaller than this from the thresholded masks ON THE DEVICE, before they cross PCIe —
+        # what the reference's evaluation does on the host afterwards (remove_small_blobs(min_size=20),
+        # R/eval_gcg_infer.py:20-29,182).  0 = the reference's inference() behaviour.
+        self.min_blob_size = int(kwargs.get("min_blob_size", 0))
 
     @classmethod
     def from_pretrained(cls, path, config=None, **kwargs):
@@ -133,6 +137,11 @@ class VideoGLaMMForCausalLM:
         box["join"]()
         return out_ids, emb, box["feats"]
 
+    def _binarize(self, logits):
+        """[T,N,H,W] fp32 logits -> uint8 masks (logit > 0), small blobs removed when min_blob_size is set."""
+        masks = ops.threshold(logits)
+        return ops.remove_small_blobs(masks, self.min_blob_size) if self.min_blob_size > 0 else masks
+
     @staticmethod
     def _segments(mask_u8):
         """[T,N,H,W] uint8 on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875)."""
@@ -169,10 +178,10 @@ class VideoGLaMMForCausalLM:
             raise AttributeError("'tuple' object has no attribute 'shape'")
         hw = tuple(original_size_list[0])
         if self.comm is not None:
-            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats)
+            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=self._binarize)
         else:
             logits, _ = self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats)
-            masks = ops.threshold(logits).cpu()
+            masks = self._binarize(logits).cpu()
         return out_ids, [self._segments(masks)]
 
     def inference_video_branch(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
@@ -187,4 +196,4 @@ class VideoGLaMMForCausalLM:
             emb = self.comm.sync_seg_embeddings(emb)
             feats = self.comm.gather_frame_feats(feats, sam.shape[0])
         logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
-        return out_ids, [self._segments(ops.threshold(logits).cpu())]
+        return out_ids, [self._segments(self._binarize(logits).cpu())]

@@ -521,3 +521,74 @@ def upsample2_add(lateral, top):
     out = torch.empty_like(lateral)
     _lib.check(lib.vg_upsample2_add(_p(lateral), _p(top), _p(out), B, H, W, C, _dt(top), _stream()), "vg_upsample2_add")
     return out
+
+
+# ---------------------------------------------------------------- mask post-processing / evaluation counts (§8f-2, §8f-4)
+def _u8(x):
+    """bool / uint8 device tensor -> contiguous uint8 view (bool shares its storage)."""
+    if x.dtype == torch.bool:
+        x = x.view(torch.uint8)
+    assert x.dtype == torch.uint8, f"masks are bool / uint8, got {x.dtype}"
+    return x.contiguous()
+
+
+def connected_components(mask, connectivity=8):
+    """mask [..., H, W] bool/uint8 -> (labels, areas) int32 of the same shape (labels: 1 + smallest pixel index)."""
+    lib = _lib.load()
+    m = _u8(mask)
+    H, W = m.shape[-2:]
+    N = m.numel() // (H * W)
+    labels = torch.empty(m.shape, dtype=torch.int32, device=m.device)
+    counts = torch.empty(m.shape, dtype=torch.int32, device=m.device)
+    _lib.check(lib.vg_connected_components(_p(m), _p(labels), _p(counts), N, H, W, int(connectivity), _stream()), "vg_connected_components")
+    return labels, counts
+
+
+def remove_small_blobs(mask, min_size):
+    lib = _lib.load()
+    m = _u8(mask)
+    H, W = m.shape[-2:]
+    N = m.numel() // (H * W)
+    ws = torch.empty((2,) + tuple(m.shape), dtype=torch.int32, device=m.device)
+    out = torch.empty_like(m)
+    _lib.check(lib.vg_remove_small_blobs(_p(m), _p(out), _p(ws[0]), _p(ws[1]), N, H, W, int(min_size), _stream()), "vg_remove_small_blobs")
+    return out
+
+
+def fill_holes(scores, max_area):
+    lib = _lib.load()
+    x = scores.contiguous()
+    assert x.dtype == torch.float32
+    H, W = x.shape[-2:]
+    N = x.numel() // (H * W)
+    ws = torch.empty((2,) + tuple(x.shape), dtype=torch.int32, device=x.device)
+    out = torch.empty_like(x)
+    _lib.check(lib.vg_fill_holes(_p(x), _p(out), _p(ws[0]), _p(ws[1]), N, H, W, int(max_area), _stream()), "vg_fill_holes")
+    return out
+
+
+def mask_pair_counts(a, b, diagonal=False):
+    """a [P, ...], b [G, ...] bool/uint8 with equal trailing shapes -> (inter, union) int64 [P, G]
+    ([P] of the pairs (i, i) when diagonal)."""
+    lib = _lib.load()
+    a, b = _u8(a), _u8(b)
+    P, G = a.shape[0], b.shape[0]
+    L = a.numel() // P
+    assert b.numel() // G == L, "masks of a pair must have the same number of pixels"
+    shape = (P,) if diagonal else (P, G)
+    inter = torch.empty(shape, dtype=torch.int64, device=a.device)
+    uni = torch.empty(shape, dtype=torch.int64, device=a.device)
+    _lib.check(lib.vg_mask_pair_counts(_p(a), _p(b), _p(inter), _p(uni), P, G, L, int(bool(diagonal)), _stream()), "vg_mask_pair_counts")
+    return inter, uni
+
+
+def boundary_counts(fg, gt, radius):
+    """fg, gt [..., H, W] bool/uint8 -> int64 [N, 4] = (n_fg, n_gt, fg_match, gt_match) per image."""
+    lib = _lib.load()
+    fg, gt = _u8(fg), _u8(gt)
+    assert fg.shape == gt.shape
+    H, W = fg.shape[-2:]
+    N = fg.numel() // (H * W)
+    out = torch.empty((N, 4), dtype=torch.int64, device=fg.device)
+    _lib.check(lib.vg_boundary_counts(_p(fg), _p(gt), _p(out), N, H, W, int(radius), _stream()), "vg_boundary_counts")
+    return out
