@@ -251,6 +251,23 @@ int vg_mask_pair_counts(const uint8_t* a, const uint8_t* b, int64_t* inter, int6
 int vg_boundary_counts(const uint8_t* fg, const uint8_t* gt, int64_t* out, int N, int H, int W, int radius,
                        vg_stream_t stream);
 
+/* ---- image pre-processing: uint8 frames in HBM -> the three model inputs ---- */
+/* One 8-bit pass of Pillow's separable resampler over in:[N,H,W,C] uint8 (C <= 4): axis 1 resizes W -> out_size
+ * (out:[N,H,out_size,C]), axis 0 resizes H -> out_size (out:[N,out_size,W,C]).  bounds:[out_size,2] = (first input
+ * index, tap count), coeffs:[out_size,ksize] = 22-bit fixed-point weights (Pillow src/libImaging/Resample.c:
+ * precompute_coeffs + normalize_coeffs_8bpc; computed on the host by videoglamm_amd/preproc.py).
+ * out = clip8((2^21 + sum_k in[first + k] * coeff[k]) >> 22): bit-exact with PIL.Image.resize — what
+ * torchvision's resize(to_pil_image(x), size) runs at R/utils/sam_transforms.py:44-49 and the CLIP processor's
+ * bicubic resize at R/utils/enc_preprocessors.py:120-166. */
+int vg_resample_u8(const uint8_t* in, uint8_t* out, int N, int H, int W, int C, int out_size, int axis,
+                   const int32_t* bounds, const int32_t* coeffs, int ksize, vg_stream_t stream);
+/* in:[N,H,W,3] uint8, crop (top,left,h,w) -> out:[N,3,h,w] planar.  mean / std: three doubles each on the HOST.
+ * mode 0: fp32 (x - mean) / std on 0..255 values (SAM: R/utils/sam_transforms.py:50-55);
+ * mode 1: (x / 255 - mean) / std evaluated in fp64, rounded once (the encoder processors' numpy arithmetic,
+ * R/model/videogpt_plus/model/internvideo/utils.py:105-143, R/utils/enc_preprocessors.py:120-166). */
+int vg_normalize_u8(const uint8_t* in, void* out, int N, int H, int W, int top, int left, int h, int w,
+                    const double* mean, const double* std, int mode, int out_dtype, vg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -330,4 +330,29 @@ def boundary_counts(fg, gt, radius):
     return torch.from_numpy(_n.array([_op.boundary_counts(x, y, radius) for x, y in zip(f, g)], dtype=_n.int64))
 
 
+# ---- image pre-processing: numpy statements of the two kernels (integer taps / IEEE normalisation)
+def resample_u8(x, out_size, axis, bounds, coeffs):
+    import numpy as _n
+    a = _n.moveaxis(x.numpy().astype(_n.int64), 2 if axis == 1 else 1, 0)          # resized axis first
+    b, k = bounds.numpy(), coeffs.numpy().astype(_n.int64)
+    out = _n.empty((out_size,) + a.shape[1:], _n.uint8)
+    for o in range(out_size):
+        acc = _n.full(a.shape[1:], 1 << 21, _n.int64)
+        for t in range(b[o, 1]):
+            acc += a[b[o, 0] + t] * k[o, t]
+        out[o] = _n.clip(acc >> 22, 0, 255)
+    return torch.from_numpy(_n.ascontiguousarray(_n.moveaxis(out, 0, 2 if axis == 1 else 1)))
+
+
+def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
+    import numpy as _n
+    top, left, h, w = crop if crop is not None else (0, 0, x.shape[1], x.shape[2])
+    a = x.numpy()[:, top:top + h, left:left + w]
+    if mode == 0:
+        y = (a.astype(_n.float32) - _n.asarray(mean, _n.float32)) / _n.asarray(std, _n.float32)
+    else:
+        y = ((a.astype(_n.float64) / 255.0 - _n.asarray(mean, _n.float64)) / _n.asarray(std, _n.float64)).astype(_n.float32)
+    return torch.from_numpy(_n.ascontiguousarray(_n.transpose(y, (0, 3, 1, 2)))).to(out_dtype)
+
+
 ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]

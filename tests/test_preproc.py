@@ -1,0 +1,112 @@
+"""Image pre-processing on the device: Pillow's 8-bit resampler restated (oracle/preproc.py) and
+pinned against Pillow itself; the product's coefficient tables; the device pipeline (videoglamm_amd/preproc.py) against
+the host pipeline (videoglamm_amd/host.py, whose SAM branch is pinned to the reference by tests/test_host_rows.py) —
+bit-exact for everything that is integer or a single IEEE operation, 1e-5 for the fp32 bilinear stretch of non-square
+SAM inputs."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import preproc as OP
+
+PIL_FILTER = {"bilinear": Image.BILINEAR, "bicubic": Image.BICUBIC}
+SIZES = [((37, 53), (64, 80)), ((64, 80), (37, 53)), ((48, 64), (96, 128)), ((50, 70), (17, 23)), ((33, 33), (33, 50)),
+         ((120, 90), (224, 224)), ((7, 5), (3, 9)), ((1, 9), (4, 4))]
+
+
+def image(hw, seed, smooth=False):
+    rng = np.random.RandomState(seed)
+    x = rng.randint(0, 256, hw + (3,)).astype(np.uint8)
+    if smooth:      # a natural-looking picture: low-pass filtered noise (PIL's own upscale of a tiny random image)
+        small = rng.randint(0, 256, (max(2, hw[0] // 16), max(2, hw[1] // 16), 3)).astype(np.uint8)
+        x = np.array(Image.fromarray(small).resize((hw[1], hw[0]), Image.BICUBIC))
+    return x
+
+
+def clip(T, hw, seed):
+    return [image(hw, seed + t, smooth=True) for t in range(T)]
+
+
+# ------------------------------------------------------------------------------------------------ oracle / tables (CPU)
+@pytest.mark.parametrize("filt", ["bilinear", "bicubic"])
+def test_oracle_resampler_is_pillow(filt):
+    for i, (src, dst) in enumerate(SIZES):
+        img = image(src, i)
+        ref = np.array(Image.fromarray(img).resize((dst[1], dst[0]), PIL_FILTER[filt]))
+        np.testing.assert_array_equal(OP.pil_resize(img, dst, filt), ref)
+
+
+def test_product_coefficient_tables():
+    from videoglamm_amd import preproc as PP
+    for i, o in [(37, 64), (64, 37), (50, 17), (120, 224), (512, 1024), (854, 1024), (480, 576), (1080, 224), (3, 7), (5, 1)]:
+        for filt in ("bilinear", "bicubic"):
+            b, k = OP.precompute_coeffs(i, o, filt)
+            b2, k2 = PP.resample_coeffs(i, o, filt)
+            np.testing.assert_array_equal(b, b2)
+            np.testing.assert_array_equal(k, k2)
+
+
+# ------------------------------------------------------------------------------------------------ pipeline vs host.py
+def check_pipeline(device, hw, T, num_frames):
+    from videoglamm_amd import host, preproc as PP
+    frames = clip(T, hw, 40)
+    ref = host.preprocess_vision(frames, num_frames)
+    got = PP.preprocess_vision(torch.from_numpy(np.stack(frames)).to(device), num_frames)
+    assert got[3] == ref[3] and got[4] == ref[4]                                  # resize_list, original_size_list
+    for name, g, r in zip(("images", "context_images"), got[:2], ref[:2]):
+        assert g[0].shape == r[0].shape and g[0].dtype == torch.float32
+        assert torch.equal(g[0].cpu(), r[0]), (name, (g[0].cpu() - r[0]).abs().max())
+    g, r = got[2][0].cpu(), ref[2][0]
+    assert g.shape == r.shape
+    if ref[3][0] == (1024, 1024):
+        assert torch.equal(g, r)                                                   # no stretch: bit-exact
+    else:
+        torch.testing.assert_close(g, r, rtol=1e-5, atol=1e-5)                     # fp32 bilinear stretch
+
+
+def test_pipeline_cpu(cpu_ops, monkeypatch):
+    from videoglamm_amd import preproc as PP
+    monkeypatch.setattr(PP, "DEVICE", "cpu")
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))     # CPU tensors stand in for device tensors
+    check_pipeline(torch.device("cpu"), (64, 64), 3, 4)                            # square: SAM 1024^2 bit-exact
+    check_pipeline(torch.device("cpu"), (45, 80), 2, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,T,nf", [((64, 64), 3, 4), ((45, 80), 5, 4), ((90, 60), 2, 8), ((512, 512), 8, 8), ((480, 854), 4, 4)])
+def test_pipeline_hip(cuda, hw, T, nf):
+    check_pipeline(cuda, hw, T, nf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt", ["bilinear", "bicubic"])
+def test_resize_u8_hip_is_pillow(cuda, filt):
+    from videoglamm_amd import preproc as PP
+    for i, (src, dst) in enumerate(SIZES + [((300, 200), (336, 504)), ((256, 256), (1024, 1024))]):
+        imgs = np.stack([image(src, 10 * i + n, smooth=n == 1) for n in range(2)])
+        got = PP.resize_u8(torch.from_numpy(imgs).to(cuda), dst, filt).cpu().numpy()
+        for n in range(2):
+            ref = np.array(Image.fromarray(imgs[n]).resize((dst[1], dst[0]), PIL_FILTER[filt]))
+            np.testing.assert_array_equal(got[n], ref)
+    # extremes: saturated images stay saturated through the negative bicubic lobes (clip8)
+    sat = np.zeros((1, 40, 40, 3), np.uint8)
+    sat[:, ::2] = 255
+    got = PP.resize_u8(torch.from_numpy(sat).to(cuda), (23, 61), filt).cpu().numpy()[0]
+    np.testing.assert_array_equal(got, np.array(Image.fromarray(sat[0]).resize((61, 23), PIL_FILTER[filt])))
+
+
+@pytest.mark.gpu
+def test_normalize_u8_hip(cuda):
+    import _cpu_ops
+    from videoglamm_amd import host, ops
+    x = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (2, 19, 23, 3)).astype(np.uint8))
+    for mode, mean, std in ((0, host.SAM_MEAN.flatten().tolist(), host.SAM_STD.flatten().tolist()), (1, host.CLIP_MEAN, host.CLIP_STD)):
+        for crop in (None, (3, 5, 11, 13)):
+            got = ops.normalize_u8(x.to(cuda), mean, std, mode, crop=crop)
+            assert torch.equal(got.cpu(), _cpu_ops.normalize_u8(x, mean, std, mode, crop=crop))
+    bf = ops.normalize_u8(x.to(cuda), host.CLIP_MEAN, host.CLIP_STD, 1, out_dtype=torch.bfloat16)
+    assert torch.equal(bf.cpu(), _cpu_ops.normalize_u8(x, host.CLIP_MEAN, host.CLIP_STD, 1).to(torch.bfloat16))
+    from videoglamm_amd import _lib
+    with pytest.raises(_lib.VGKernelError):
+        ops.normalize_u8(x.to(cuda), host.CLIP_MEAN, host.CLIP_STD, 1, crop=(10, 10, 11, 13))

@@ -61,6 +61,8 @@ def _sig(lib):
         "vg_fill_holes": ([P, P, P, P, I, I, I, I, P], c_int),
         "vg_mask_pair_counts": ([P, P, P, P, I, I, L, I, P], c_int),
         "vg_boundary_counts": ([P, P, P, I, I, I, I, P], c_int),
+        "vg_resample_u8": ([P, P, I, I, I, I, I, I, P, P, I, P], c_int),
+        "vg_normalize_u8": ([P, P, I, I, I, I, I, I, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), I, I, P], c_int),
     }
     for name, (args, res) in S.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

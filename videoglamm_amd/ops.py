@@ -592,3 +592,34 @@ def boundary_counts(fg, gt, radius):
     out = torch.empty((N, 4), dtype=torch.int64, device=fg.device)
     _lib.check(lib.vg_boundary_counts(_p(fg), _p(gt), _p(out), N, H, W, int(radius), _stream()), "vg_boundary_counts")
     return out
+
+
+# ---------------------------------------------------------------- image pre-processing on the device (§8f-1)
+def resample_u8(x, out_size, axis, bounds, coeffs):
+    """one pass of Pillow's 8-bit resampler over x [N,H,W,C] uint8; bounds [out,2] / coeffs [out,ksize] int32 on device."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.uint8 and x.dim() == 4
+    assert bounds.dtype == torch.int32 and coeffs.dtype == torch.int32 and bounds.shape == (out_size, 2) and coeffs.shape[0] == out_size
+    N, H, W, C = x.shape
+    shape = (N, H, out_size, C) if axis == 1 else (N, out_size, W, C)
+    out = torch.empty(shape, dtype=torch.uint8, device=x.device)
+    rc = lib.vg_resample_u8(_p(x), _p(out), N, H, W, C, int(out_size), int(axis), _p(bounds.contiguous()), _p(coeffs.contiguous()),
+                            coeffs.shape[1], _stream())
+    _lib.check(rc, "vg_resample_u8")
+    return out
+
+
+def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
+    """x [N,H,W,3] uint8 -> [N,3,h,w]; crop = (top, left, h, w); mode 0: fp32 (x - mean) / std, 1: fp64 (x / 255 - mean) / std."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] == 3
+    N, H, W, _ = x.shape
+    top, left, h, w = crop if crop is not None else (0, 0, H, W)
+    out = torch.empty((N, 3, h, w), dtype=out_dtype, device=x.device)
+    m = (ctypes.c_double * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_double * 3)(*[float(v) for v in std])
+    rc = lib.vg_normalize_u8(_p(x), _p(out), N, H, W, int(top), int(left), int(h), int(w), m, sd, int(mode), _dt(out), _stream())
+    _lib.check(rc, "vg_normalize_u8")
+    return out
