@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--te", type=int, default=8, help="encoder frames (NUM_FRAMES)")
     ap.add_argument("--src", type=int, default=512, help="source (output mask) resolution")
     ap.add_argument("--max-new-tokens", type=int, default=32)
+    ap.add_argument("--objects", type=int, default=1, help="[SEG] objects (multi-object GCG: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
@@ -219,7 +220,9 @@ def main():
                    llm=dict(vocab=320, hidden=128, ffn=256, num_layers=2, num_heads=4, num_kv_heads=2, rms_eps=1e-5, rope_theta=10000.0),
                    sam2=dict(image_size=1024, trunk=dict(embed_dim=16, num_heads=1, stages=[1, 2, 3, 1], global_att_blocks=[4, 5],
                                                          window_spec=[8, 4, 8, 4], window_pos_embed_bkg_spatial_size=[7, 7])))
-    cfg["forced_tokens"] = {8: cfg["seg_token_idx"]}          # exactly one [SEG] object (config C1)
+    # exactly --objects [SEG] tokens (C1: one, at decode step 8; multi-object GCG: every third step from 4)
+    assert 1 <= args.objects and 4 + 3 * (args.objects - 1) < args.max_new_tokens
+    cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
     t0 = time.time()
     sd = synth.device_state_dict(synth.manifest(cfg), device, torch.bfloat16)
     model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=device, comm=comm)
@@ -252,11 +255,15 @@ def main():
         dt = float(tt[0])
     out_ids, segs = out
     n_obj = len(segs[0][0]) if segs[0] else 0
+    name = "C1" if (args.frames_per_gpu, args.src, args.objects) == (8, 512, 1) else "C2" if (args.frames_per_gpu, args.src, args.objects) == (32, 1024, 1) \
+        else "C4 share of one GPU (64 frames / 8)" if (args.frames_per_gpu, args.src, args.objects) == (8, 1024, 8) else "custom"
+    if args.llm != "llama3-8b":
+        name += " with the Phi-3-mini LLM"
     res = {
         "metric": "frames/sec end-to-end (text+masks)", "value": round(T * args.steps / dt, 3), "unit": "frames/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{'C1' if args.llm == 'llama3-8b' else 'C1 with the Phi-3-mini LLM'}: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
+        "config": {"workload": f"{name}: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
                                f"Te={args.te}, {'Llama-3-8B' if args.llm == 'llama3-8b' else 'Phi-3-mini'} bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
                                f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),
                    "frames": T, "encoder_frames": args.te, "generated_tokens": int(out_ids.shape[1] - ids.shape[1]),
