@@ -45,22 +45,18 @@ class VideoGLaMMForCausalLM:
         self.min_blob_size = int(kwargs.get("min_blob_size", 0))
 
     @classmethod
-    def from_pretrained(cls, path, config=None, **kwargs):
-        """HF directory with *.safetensors shards (+ config.json carrying the keys above under "videoglamm_amd")."""
-        import glob
-        import json
-        import os
+    def from_pretrained(cls, path, config=None, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None,
+                        seg_token_idx=None, **kwargs):
+        """The released artefact layout (R/chat.py:277-319): an HF directory (*.safetensors or pytorch_model*.bin shards +
+        config.json) with the LLM, the projectors, text_hidden_fcs and SAM2; the InternVideo2 .pt and the CLIP directory
+        the config names under mm_vision_tower / image_mm_vision_tower (or given here); optionally a stand-alone SAM2
+        checkpoint.  The architecture config is derived from config.json + tensor shapes (videoglamm_amd/ingest.py) unless
+        `config` — or a "videoglamm_amd" section in config.json — gives it explicitly."""
+        from . import ingest
 
-        from safetensors.torch import load_file
-
-        sd = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            sd.update(load_file(f))
-        if not sd:
-            raise FileNotFoundError(f"no *.safetensors under {path}")
+        sd, hf = ingest.load_state_dict(path, vision_tower, image_vision_tower, sam2_checkpoint)
         if config is None:
-            with open(os.path.join(path, "config.json")) as fh:
-                config = json.load(fh)["videoglamm_amd"]
+            config = (hf or {}).get("videoglamm_amd") or ingest.derive_config(sd, hf, seg_token_idx)
         return cls(sd, config, **kwargs)
 
     def eval(self):
