@@ -219,6 +219,11 @@ int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int 
 int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C,
                      int dtype, vg_stream_t stream);
 
+/* Which kernel an (M, N, K) GEMM of vg_gemm / vg_gemm_window is routed to with the current knobs (measurement aid:
+ * bench.py attributes per-launch times to kernels with it): 0 gemm_skinny_kernel (M <= 16), 1 gemm_tile_glds_kernel,
+ * 2 gemm_tile_k64b_kernel, 3 gemm_tile_w128_kernel.  N = output columns (F for a_op == 1).  Launches nothing. */
+int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed);
+
 /* ---- mask post-processing and evaluation counts: integer / byte work ---- */
 /* Connected components of N binary images [N,H,W] (uint8, foreground = nonzero), connectivity 4 or 8.
  * labels: 0 on background, 1 + the smallest linear pixel index (y*W + x) of the component on foreground;

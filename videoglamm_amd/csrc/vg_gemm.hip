@@ -738,6 +738,229 @@ __global__ __launch_bounds__(512) void gemm_tile_ring_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * 256 + wm * 64, bn * 128 + wn * 64, bz, wave, lane);
 }
 
+// 256x256 output tile / 256 threads: FOUR waves, each owning 128x128 (4x4 MFMA tiles, 256 accumulator registers), one
+// workgroup per CU.  Two measurements shape it (tools/mfma_peak.hip, tools/dma_peak.hip, r01):
+//   * the inner loop of this kernel alone (16 MFMAs + 8 ds_read_b128 per group, no global memory) runs at 2.2 PFLOP/s,
+//     the register-only MFMA ceiling of the part: fragment reads are not what holds the GEMMs near 1 PFLOP/s;
+//   * the CU's global->LDS path moves ~one 128-byte line per two cycles: 105-136 GB/s per CU when a lane group fetches
+//     whole lines (128-byte rows), but only 60-68 GB/s with 64-byte row pieces (half of every line is thrown away).
+//     A 128x128 tile per workgroup needs 32 KB per 512 MFMA cycles (64 B/clk: the whole path), a 256x256 tile half that.
+// So: 128-byte K steps (whole lines), two 64 KB stages, and the 16 DMA instructions of the next stage are issued ONE AT A
+// TIME between MFMAs over the first three quarters of a step — a wave issues in order, so a burst of DMAs that backs up
+// the address path stalls the MFMAs queued behind it.  The fragments of the next MFMA group are read while the current
+// group issues; only the first group after the barrier waits for its reads.
+// Needs K % (128 / sizeof(T)) == 0, no GLU epilogue, no window maps; the launcher sends only shapes that fill the chip.
+#ifndef VG_W128_PLAN
+#define VG_W128_PLAN 1
+#endif
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 1) void gemm_tile_w128_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int TA = 256 * 128, STAGE = 2 * TA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // wave w stages rows [64w, 64w+64) of each operand: 8 DMA instructions of 8 rows (8 lanes per 128-byte row) each
+  const T* src[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wave * 64 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * 256 + row, gn = bn * 256 + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
+      const int o = bn * 128 + (row & 127);
+      gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
+    }
+    src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    src[8 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto dma = [&](int kt, int buf, int i) {      // instruction i of stage kt: 0..7 A pieces, 8..15 W pieces
+    char* dst = smem + buf * STAGE + (i >> 3) * TA + wave * 64 * 128 + (i & 7) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ra = wm * 128 + l31, rb = wn * 128 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r + 32 i share the key
+  const int nk = K / BK;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  u32x4_t fa[2][4], fb[2][4];          // fragment sets of two consecutive MFMA groups
+  // fragment x (0..3 = A row tiles, 4..7 = W row tiles) of group g of the stage in `buf`
+  auto frag = [&](int buf, int g, int x) -> u32x4_t {
+    const int c = 2 * g + h;
+    if (x < 4) return *(const u32x4_t*)(smem + buf * STAGE + (ra + x * 32) * 128 + ((c ^ swa) << 4));
+    return *(const u32x4_t*)(smem + buf * STAGE + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
+  };
+#pragma unroll
+  for (int x = 0; x < 8; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(0, 0, x);
+
+  // one K step = 4 groups x 8 slots; a slot = 2 MFMAs, then one fragment read of the next group, then (first three
+  // groups, while a next stage exists) at most one DMA instruction of the next stage.  sched_barrier pins the order.
+  auto step = [&](int kt, int buf, bool has_next) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g == 0) __builtin_amdgcn_s_waitcnt(0xC07F);       // the first group's fragments (read after the barrier)
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        MmaOp<T>::run(fa[cur][(2 * sl) >> 2], fb[cur][(2 * sl) & 3], acc[(2 * sl) >> 2][(2 * sl) & 3]);
+        MmaOp<T>::run(fa[cur][(2 * sl + 1) >> 2], fb[cur][(2 * sl + 1) & 3], acc[(2 * sl + 1) >> 2][(2 * sl + 1) & 3]);
+        if (g < 3) {
+          const u32x4_t v = frag(buf, g + 1, sl);
+          if (sl < 4) fa[nxt][sl] = v; else fb[nxt][sl - 4] = v;
+        }
+#if VG_W128_PLAN == 1
+        const int di = g * 8 + sl;                          // 8 + 8 DMA instructions over groups 0..1
+        if (has_next && g < 2) dma(kt + 1, buf ^ 1, di);
+#else
+        const int di = g * 6 + sl;                          // 6 + 6 + 4 DMA instructions over groups 0..2
+        if (has_next && g < 3 && sl < (g < 2 ? 6 : 4)) dma(kt + 1, buf ^ 1, di);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g < 3) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // next group's fragments: requested >= 2 MFMAs ago
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int buf = kt & 1;
+    step(kt, buf, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage kt+1 landed ...
+    __builtin_amdgcn_s_barrier();                           // ... everyone's did, and everyone is done with stage kt
+#pragma unroll
+    for (int x = 0; x < 8; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  step(kt, kt & 1, false);
+  __syncthreads();   // the epilogue reuses the ring as fp32 staging: 4 waves x 32 rows x 132 floats
+
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 132;
+  float* ws = (float*)smem + wave * 32 * ES;
+  const int cg = lane & 15, rsub = lane >> 4;
+  const int n0 = (p.a_op == 1 ? bn * 128 : bn * 256 + wn * 128) + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    if (p.a_op == 1) {
+      // SwiGLU: waves (wm,0) / (wm,1) staged the gate / up halves of the same 32 rows x 128 outputs; each finishes 16
+      // of the rows: y = round(silu(round(gate + b_g))) * round(up + b_u)  (the arithmetic of gemm_epilogue128's GLU)
+      const float* wg = (const float*)smem + (wm * 2) * 32 * ES;
+      const float* wu = wg + 32 * ES;
+#pragma unroll 1
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ml = wn * 16 + pass * 4 + rsub;
+        const int m = bm * 256 + wm * 128 + i * 32 + ml;
+        if (m >= M || n0 >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g = wg[ml * ES + cg * 8 + e] + bv[e];
+          float u = wu[ml * ES + cg * 8 + e] + ((p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f);
+          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+          g = g / (1.0f + __expf(-g));
+          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
+          v[e] = g * u;
+        }
+        TO* cp = C + (int64_t)m * p.ldc + n0;
+        if (n0 + 8 <= N) {
+          if constexpr (sizeof(TO) == 2) {
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+            *(u32x4_t*)cp = o;
+          } else {
+            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *(f32x4_t*)cp = o0;
+            *(f32x4_t*)(cp + 4) = o1;
+          }
+        } else {
+          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+        }
+      }
+      continue;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {     // not unrolled: nothing in here indexes the accumulators
+      const int ml = pass * 4 + rsub;
+      const int m = bm * 256 + wm * 128 + i * 32 + ml;
+      if (m >= M || n0 >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      TO* cp = C + (int64_t)m * p.ldc + n0;
+      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N && p.vec_out) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+  }
+}
+
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& a, const u32x4_t& b);
 template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& a, const u32x4_t& b) {
   float s = 0.f;
@@ -857,6 +1080,36 @@ static void launch_skinny(const GemmArgs& p, int batch, hipStream_t st) {
   else gemm_skinny_kernel<T, TO, 16, GLU><<<grid, 256, 0, st>>>(p);
 }
 
+// ---- routing of an M > 16 GEMM to a tile kernel (shared by the launcher and vg_gemm_route, which bench.py uses to
+// attribute launches to kernels).  Knobs are read once.
+static int env_knob(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int knob_variant() { static const int v = env_knob("VG_GEMM_VARIANT", 1284); return v; }
+static int knob_k64b() { static const int v = env_knob("VG_GEMM_K64B", 1); return v; }
+static int knob_w128() { static const int v = env_knob("VG_GEMM_W128", 1); return v; }
+// few K-steps per tile (K x element size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
+// (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
+static bool route_small_k(int64_t K, int es, int a_op) {
+  const int v = knob_variant();
+  return knob_k64b() && (v == 1283 || v == 1284) && K * es <= 3072 && a_op == 0;
+}
+// 256x256 tile, 128x128 per wave: bf16, whole 128-byte K steps, and the 256-tiles must use the chip well: (useful
+// fraction of the tiles' area) x (fill of the rounds of 256 workgroups) >= 0.7 — Hiera's N = 576 outputs or 168-tile
+// grids stay on the 128x128 kernels (measured r01, tools/bench_gemm.py).  a_op == 1: a tile is 256 rows x 128 outputs
+static bool route_w128(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch, int* ntw_out, int* mtw_out) {
+  const int ntw = (int)(a_op == 1 ? (N + 127) / 128 : (N + 255) / 256), mtw = (int)((M + 255) / 256);
+  if (ntw_out) { *ntw_out = ntw; *mtw_out = mtw; }
+  const int w = knob_w128();
+  if (!w || es != 2 || route_small_k(K, es, a_op) || wmode || K % (128 / es) != 0 || !vec_out) return false;
+  if (w == 2) return true;
+  const int64_t t256 = (int64_t)ntw * mtw * batch;
+  const double useful = (double)M * N / ((double)mtw * 256 * ntw * (a_op == 1 ? 128 : 256));
+  const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+  return t256 >= 128 && useful * fill >= 0.7;
+}
+
 template <typename T, typename TO>
 static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
   if (p.M <= 16) {
@@ -879,10 +1132,10 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     // main-loop variant (A/B knob, the default is the measured best): VG_GEMM_VARIANT = 1284 LDS-DMA staging with all 16
     // fragment reads of a K-step requested up front (default), 1283 the same with reads group by group;
     // "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} = the register-staged kernel
-    static int variant = -1;
-    if (variant < 0) {
-      const char* e = getenv("VG_GEMM_VARIANT");
-      variant = e ? atoi(e) : 1284;
+    const int variant = knob_variant();
+    static bool tile_attr = false;
+    if (!tile_attr) {
+      tile_attr = true;
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
       (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
@@ -907,15 +1160,19 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
     }
     const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
-    // few K-steps per tile (K <= 1536 B... elements x size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
-    // (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
-    static int k64 = -1;
-    if (k64 < 0) {
-      const char* e = getenv("VG_GEMM_K64B");
-      k64 = e ? atoi(e) : 1;
+    const bool small_k = route_small_k(p.K, (int)sizeof(T), p.a_op);
+    static bool w128_attr = false;
+    if (!w128_attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_tile_w128_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
+      w128_attr = true;
     }
-    const bool small_k = k64 && (variant == 1283 || variant == 1284) && (int64_t)p.K * (int)sizeof(T) <= 3072 && p.a_op == 0;
-    if (small_k) {
+    int ntw, mtw;
+    const bool big = route_w128(p.M, p.N, p.K, (int)sizeof(T), p.a_op, p.wmode, p.vec_out, batch, &ntw, &mtw);
+    if (big) {
+      dim3 gridw(ntw, mtw, batch);
+      q.gn = pick_gn(mtw, ntw);
+      gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
+    } else if (small_k) {
       gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
       dim3 gridg((p.N + 63) / 64, (p.M + GBM - 1) / GBM, batch);
@@ -943,6 +1200,14 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
 // vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
 struct GemmWindow { int mode, H, W, ws; const void* zrow; };
 static thread_local GemmWindow g_window{0, 0, 0, 0, nullptr};
+
+extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed) {
+  if (M <= 16) return 0;
+  const int es = in_dtype == VG_BF16 ? 2 : 4;
+  if (route_w128(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
+  if (route_small_k(K, es, a_op)) return 2;
+  return 1;
+}
 
 extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, int64_t sW,
                        void* C, int64_t ldc, int64_t sC, const float* bias, const float* gamma,
