@@ -70,7 +70,7 @@ class GemmMeter:
     def kernel_of(M, N, K, glu, windowed):
         """the launcher's own routing (vg_gemm_route, videoglamm_amd/csrc/vg_gemm.hip): which tile kernel runs this shape"""
         from videoglamm_amd import _lib
-        return {1: "glds", 2: "k64b", 3: "w128"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
+        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
 
     def __enter__(self):
         def timed(x, w, *a, **k):
@@ -304,7 +304,8 @@ def main():
                    "weights": "random-init (synthetic)"},
         "load_s": round(t_load, 1),
     }
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # (every rank runs these extra steps — a step contains the frame-sharding collectives — rank 0 reports)
         # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream.  It runs
         # with the Hiera/LLM stream overlap switched off: an event pair on one of two concurrently fed streams also
         # brackets the time the launch waits behind the other stream's kernels, which is not kernel time
@@ -346,8 +347,9 @@ def main():
                     "kernel_ms_per_step": round(ms, 2)}
         # one object per tile kernel; "roofline" is the one with the most GPU time in the step (gemm_tile_glds_kernel on C1)
         labels = {"glds": ("gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)", "r01_pmc_gemm_glds.json"),
-                  "k64b": ("gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 <= 3072 B)", "r01_pmc_gemm_k64b.json"),
-                  "w128": ("gemm_tile_w128_kernel<bf16> (256x256 tile, 128x128 per wave: grids that fill the chip)", "r01_pmc_gemm_w128.json")}
+                  "k64b": ("gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)", "r01_pmc_gemm_k64b.json"),
+                  "w128": ("gemm_tile_w128_kernel<bf16> (256x256 tile, 128x128 per wave: grids that fill the chip)", "r01_pmc_gemm_w128.json"),
+                  "s128": ("gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)", "r01_pmc_gemm_s128.json")}
         roofs = {k: roof(k, *labels[k]) for k in labels}
         roofs = {"gemm_" + k: v for k, v in roofs.items() if v["launches"]}
         gv = None if args.tiny else meter_decode_gemv(model, ops)
@@ -384,6 +386,7 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # rank 0 may still be in its CPU-baseline leg: leave together
         torch.distributed.destroy_process_group()
 
 

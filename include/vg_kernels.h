@@ -221,7 +221,8 @@ int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H
 
 /* Which kernel an (M, N, K) GEMM of vg_gemm / vg_gemm_window is routed to with the current knobs (measurement aid:
  * bench.py attributes per-launch times to kernels with it): 0 gemm_skinny_kernel (M <= 16), 1 gemm_tile_glds_kernel,
- * 2 gemm_tile_k64b_kernel, 3 gemm_tile_w128_kernel.  N = output columns (F for a_op == 1).  Launches nothing. */
+ * 2 gemm_tile_k64b_kernel, 3 gemm_tile_w128_kernel, 4 gemm_tile_s128_kernel.  N = output columns (F for a_op == 1).
+ * Launches nothing. */
 int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed);
 
 /* ---- mask post-processing and evaluation counts: integer / byte work ---- */

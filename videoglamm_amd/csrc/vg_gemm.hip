@@ -642,6 +642,182 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
   }
 }
 
+// 128x128 tile, 128-BYTE K steps, ONE 32 KB stage (the epilogue staging aliases it: 35 KB in all): four workgroups per
+// CU like the 64-byte-step kernel, but every DMA lane group fetches a whole 128-byte line — the CU's global->LDS path
+// moves about one line per two clocks whether half of it is used or all of it (tools/dma_peak.hip).  A workgroup does
+// not overlap its own loads with its MFMAs (load, barrier, 16 MFMAs per wave, barrier); the other three do.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int TILEB = 128 * 128;        // bytes per operand (single stage)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // wave w stages rows [32w, 32w+32) of each operand in 4 DMA instructions of 8 rows (8 lanes per 128-byte row)
+  const T* asrc[4];
+  const T* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * GBM + row, gn = bn * GBN + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    if (p.wmode == 1) {
+      const int64_t r = gemm_window_row(p, gm);
+      asrc[i] = (r >= 0 ? A + r * p.lda : (const T*)p.zrow) + chunk * KPC;
+    } else {
+      asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    }
+    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto issue = [&](int kt) {
+    char* sa = smem + wave * 32 * 128;
+    char* sb = sa + TILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_tail = [&](int kt) {
+    char* sa = smem + wave * 32 * 128 + lane * 16;
+    char* sb = sa + TILEB;
+    u32x4_t va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const bool ok = kt * BK + chunk * KPC < K;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      va[i] = ok ? *(const u32x4_t*)(asrc[i] + (int64_t)kt * BK) : z;
+      vb[i] = ok ? *(const u32x4_t*)(wsrc[i] + (int64_t)kt * BK) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4_t*)(sa + i * 1024) = va[i];
+      *(u32x4_t*)(sb + i * 1024) = vb[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r and r+32 share the key
+  const int nkf = K / BK, nk = (K + BK - 1) / BK;
+  const char* sa = smem + ra * 128;
+  const char* sb = smem + TILEB + rb * 128;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt < nkf) issue(kt);
+    else issue_tail(kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    u32x4_t fa0[4], fa1[4], fb0[4], fb1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 2 * g + h;
+      fa0[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+      fb0[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+      fa1[g] = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
+      fb1[g] = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+      MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+      MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+      MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
+    }
+    __syncthreads();           // everyone has its fragments in registers: the stage may be overwritten
+  }
+
+  // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 68;
+  float* ws = (float*)smem + wave * 32 * ES;
+  const int cg = lane & 7, rsub = lane >> 3;
+  const int n0 = bn * GBN + wn * 64 + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ml = pass * 8 + rsub;
+      const int m = bm * GBM + wm * 64 + i * 32 + ml;
+      if (m >= M || n0 >= N) continue;
+      int64_t mo = m;
+      if (p.wmode == 2) {
+        mo = gemm_window_row(p, m);
+        if (mo < 0) continue;
+      }
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      TO* cp = C + mo * p.ldc + n0;
+      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N && p.vec_out) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+  }
+}
+
 // 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
 // by LDS-DMA two K-steps ahead.  The 128x128 kernels drain their DMA queue at every barrier (vmcnt(0) inside
 // __syncthreads) with only one K-step (~0.2 us of MFMA) of prefetch distance against ~1-2 us of L2/HBM latency; here
@@ -1088,12 +1264,19 @@ static int env_knob(const char* name, int dflt) {
 }
 static int knob_variant() { static const int v = env_knob("VG_GEMM_VARIANT", 1284); return v; }
 static int knob_k64b() { static const int v = env_knob("VG_GEMM_K64B", 1); return v; }
+static int env_knob_s128() { static const int v = env_knob("VG_GEMM_S128", 1); return v; }
 static int knob_w128() { static const int v = env_knob("VG_GEMM_W128", 1); return v; }
 // few K-steps per tile (K x element size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
 // (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
 static bool route_small_k(int64_t K, int es, int a_op) {
   const int v = knob_variant();
   return knob_k64b() && (v == 1283 || v == 1284) && K * es <= 3072 && a_op == 0;
+}
+// single-stage 128-byte-row kernel: the small-K shapes with at least four whole-line K steps (measured r01: +16...18 % on
+// Hiera stage 3 / 4 and +7...14 % on the tower shapes over the 64-byte-row kernel; K = 144 / 288 stay there)
+static bool route_s128(int64_t K, int es, int a_op) {
+  const int k = env_knob_s128();
+  return (k == 1 && route_small_k(K, es, a_op) && K * es >= 1024) || (k == 2 && a_op == 0);
 }
 // 256x256 tile, 128x128 per wave: bf16, whole 128-byte K steps, and the 256-tiles must use the chip well: (useful
 // fraction of the tiles' area) x (fill of the rounds of 256 workgroups) >= 0.7 — Hiera's N = 576 outputs or 168-tile
@@ -1172,6 +1355,8 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       dim3 gridw(ntw, mtw, batch);
       q.gn = pick_gn(mtw, ntw);
       gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
+    } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
+      gemm_tile_s128_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (small_k) {
       gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
@@ -1205,6 +1390,7 @@ extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int 
   if (M <= 16) return 0;
   const int es = in_dtype == VG_BF16 ? 2 : 4;
   if (route_w128(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
+  if (route_s128(K, es, a_op)) return 4;
   if (route_small_k(K, es, a_op)) return 2;
   return 1;
 }
