@@ -41,7 +41,20 @@ def _worker(rank, world, port, q):
     masks = comm.framewise(m, images, text + 0.01 * rank, hw)
     feats = comm.hiera_all_frames(m, images)
     vid = m.video_branch(images, emb, hw, frame_feats=feats)
+    # vision towers sharded by CLIP frame / InternVideo2 chunk (Te = 4: one chunk -> rank 1 has none; two frames each)
+    from test_oracle_e2e import e2e_setup
+    from videoglamm_amd.vlm import VisionTowers
+    _, esd, ecfg, inp = e2e_setup()
+    towers = VisionTowers(Params(esd, "cpu", torch.float32), ecfg)
+    vis = towers.encode(inp["images"], inp["context_images"], comm)
+    both = [torch.empty_like(vis) for _ in range(world)]
+    dist.all_gather(both, vis)
+    same_everywhere = all(torch.equal(b, vis) for b in both)
+    vis_ref = towers.encode(inp["images"], inp["context_images"])
+    ok_towers = same_everywhere and vis.shape == vis_ref.shape and bool(torch.allclose(vis, vis_ref, rtol=1e-5, atol=1e-5))
+    assert comm.block(5) == ((0, 3) if rank == 0 else (3, 2)) and comm.block(1) == ((0, 1) if rank == 0 else (1, 0))
     if rank == 0:
+        q.put(("towers", ok_towers, tuple(vis.shape)))
         ref_logits, _ = m.framewise_branch(images, text, hw)
         ref_vid = m.video_branch(images, text, hw)
         q.put((bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))), bool(torch.equal(vid, ref_vid)), tuple(masks.shape)))
@@ -56,6 +69,8 @@ def test_frame_sharding_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
+    tag, ok_towers, vshape = q.get(timeout=300)
+    assert tag == "towers" and ok_towers, f"sharded vision towers differ from the single-process result {vshape}"
     ok_fw, ok_vid, shape = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)

@@ -8,6 +8,9 @@ What shards naturally and what does not:
     rank (identical greedy ids by construction).  The only exchange the decode needs is the tiny
     [N,256] [SEG] embedding: one all-gather, rank 0's copy is used everywhere so all ranks decode with
     bit-identical prompts (<= 8 KB: latency-bound, one-shot, never a ring of buckets).
+  * The two vision towers are independent per CLIP frame / per 4-frame InternVideo2 chunk: each rank encodes and
+    projects its block of frames / chunks, the projected, pooled tokens (a few MB) are all-gathered, so the replicated LLM
+    sees identical visual tokens everywhere and the towers cost 1/world of a clip instead of a whole one per rank.
   * Results: uint8 masks of the local frames, all-gathered so that rank 0 (and everyone) holds the clip.
   * Video-branch propagation is a recurrence over frames (memory of t-1..t-6): only the per-frame Hiera
     features shard; they are all-gathered (8.4 MB bf16 per frame at SAM2-L) and the recurrence runs replicated.
@@ -30,6 +33,25 @@ class FrameSharder:
         assert T % self.world == 0, f"T={T} frames must be a multiple of world_size={self.world}"
         per = T // self.world
         return list(range(self.rank * per, (self.rank + 1) * per))
+
+    def block(self, n):
+        """contiguous block of n units for this rank (sizes differ by at most one; ranks beyond n get none) -> (start, count)."""
+        base, extra = divmod(n, self.world)
+        start = self.rank * base + min(self.rank, extra)
+        return start, base + (1 if self.rank < extra else 0)
+
+    def gather_rows(self, local, n, rows_per_unit, tail_shape, dtype, device):
+        """all-gather of per-unit row blocks of unequal count: `local` holds this rank's units ([count*rows_per_unit, *tail] or
+        None when it has none); every rank gets all n units in order.  Blocks are padded to the largest count so that the
+        collective is regular."""
+        base, extra = divmod(n, self.world)
+        most = base + (1 if extra else 0)
+        buf = torch.zeros((most * rows_per_unit,) + tuple(tail_shape), dtype=dtype, device=device)
+        if local is not None and local.shape[0]:
+            buf[:local.shape[0]].copy_(local)
+        parts = self._all_gather(buf)
+        counts = [base + (1 if r < extra else 0) for r in range(self.world)]
+        return torch.cat([parts[r][:counts[r] * rows_per_unit] for r in range(self.world) if counts[r]], dim=0)
 
     def _all_gather(self, t):
         bufs = [torch.empty_like(t) for _ in range(self.world)]

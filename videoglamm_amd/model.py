@@ -105,7 +105,7 @@ class VideoGLaMMForCausalLM:
         ctx = context_images[0] if context_images is not None else None
         out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
-                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill)
+                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm)
         return out_ids.unsqueeze(0), emb
 
     def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens):

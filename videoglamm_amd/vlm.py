@@ -96,10 +96,12 @@ class VisionTowers:
             i += 2
         return ops.linear(x, self.P.w(f"{name}.{i}"), self.P.b(f"{name}.{i}"))
 
-    def encode(self, images, context_images):
+    def encode(self, images, context_images, comm=None):
         """encode_videos + project(input_type='video') — R/model/videogpt_plus/model/arch.py:121-151,164-191.
         images [Te,3,224,224], context [Te,3,336,336] -> visual tokens [Te*144 + Te*64, D] (context first);
-        context_images None: images [t,3,336,336] -> [t*576, D]."""
+        context_images None: images [t,3,336,336] -> [t*576, D].
+        comm (dist.FrameSharder, world > 1): this rank encodes only its block of CLIP frames and of 4-frame InternVideo2
+        chunks; the projected, pooled tokens are all-gathered (every op up to there is per frame / per chunk)."""
         if context_images is None:
             # image prompt (encode_images + project(input_type="image"), arch.py:110-119,393-397): CLIP patch features of
             # the image(s) -> image_mm_projector, no pooling, all tokens concatenated
@@ -108,7 +110,35 @@ class VisionTowers:
         te = images.shape[0]
         assert te % 4 == 0, "the video encoder consumes 4-frame chunks (arch.py:133)"
         video = images.view(te // 4, 4, *images.shape[1:])
-        if images.is_cuda and os.environ.get("VG_TOWERS_OVERLAP", "1") != "0":
+        sharded = comm is not None and comm.world > 1
+        if sharded:
+            c0, cn = comm.block(te)
+            v0, vn = comm.block(te // 4)
+            context_images, video = context_images[c0:c0 + cn], video[v0:v0 + vn]
+        else:
+            cn, vn = te, te // 4
+
+        def video_tokens():
+            if vn == 0:
+                return None
+            vf = self._projector("model.mm_projector", self.iv2(video).contiguous())      # [nc, 4*L, D]
+            D = vf.shape[-1]
+            g = int(round((vf.shape[1] // 4) ** 0.5))
+            # arch.py:173,177-178 hard-code 8x8 / 12x12 outputs; with the 16x16 / 24x24 token grids of the shipped
+            # towers adaptive_avg_pool2d is exactly a 2x2 mean
+            assert g == 16, "the video token grid must be 16x16"
+            return ops.pool2(vf.view(vn * 4, g, g, D), False).view(-1, D)                 # 16x16 -> 8x8 per frame
+
+        def context_tokens():
+            if cn == 0:
+                return None
+            cf = self._projector("model.image_mm_projector", self.clip(context_images).contiguous())   # [Te, Lc, D]
+            D = cf.shape[-1]
+            g = int(round(cf.shape[1] ** 0.5))
+            assert g == 24, "the context token grid must be 24x24"
+            return ops.pool2(cf.view(cn, g, g, D), False).view(-1, D)                      # 24x24 -> 12x12 per frame
+
+        if images.is_cuda and os.environ.get("VG_TOWERS_OVERLAP", "1") != "0" and vn and cn:
             # the two towers are independent and their GEMMs are small (M = 2050 / 4616 rows: ~1 round of tiles with a
             # long tail each): InternVideo2 goes to a second stream so that the tails of one fill under the other
             if getattr(self, "_side", None) is None:
@@ -116,23 +146,17 @@ class VisionTowers:
             main = torch.cuda.current_stream(images.device)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                vf = self.iv2(video)                                          # [nc, 4*L, Dv]
-            cf = self.clip(context_images)                                    # [Te, Lc, Dc]
+                vf = video_tokens()
+            cf = context_tokens()
             main.wait_stream(self._side)
             vf.record_stream(main)
         else:
-            vf = self.iv2(video)
-            cf = self.clip(context_images)
-        vf = self._projector("model.mm_projector", vf.contiguous())
-        D = vf.shape[-1]
-        g = int(round((vf.shape[1] // 4) ** 0.5))
-        # arch.py:173,177-178 hard-code 8x8 / 12x12 outputs; with the 16x16 / 24x24 token grids of the shipped
-        # towers adaptive_avg_pool2d is exactly a 2x2 mean
-        assert g == 16 and int(round(cf.shape[1] ** 0.5)) == 24, "token grids must be 16x16 (video) and 24x24 (context)"
-        vf = ops.pool2(vf.view(te, g, g, D), False).view(-1, D)               # 16x16 -> 8x8 per frame
-        cf = self._projector("model.image_mm_projector", cf.contiguous())
-        g = int(round(cf.shape[1] ** 0.5))
-        cf = ops.pool2(cf.view(te, g, g, D), False).view(-1, D)               # 24x24 -> 12x12 per frame
+            vf = video_tokens()
+            cf = context_tokens()
+        if sharded:
+            D = self.P.sd["model.embed_tokens.weight"].shape[1]          # the projectors end in the LLM width
+            cf = comm.gather_rows(cf, te, 144, (D,), self.P.dtype, images.device)
+            vf = comm.gather_rows(vf, te // 4, 4 * 64, (D,), self.P.dtype, images.device)
         return torch.cat([cf, vf], dim=0)
 
 
@@ -283,7 +307,7 @@ def splice(params, input_ids, visual):
 
 
 def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
-             forced_tokens=None, after_prefill=None):
+             forced_tokens=None, after_prefill=None, comm=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
@@ -292,7 +316,7 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
     seg_idx = cfg["seg_token_idx"]
     if visual is None:
-        visual = towers.encode(images, context_images)
+        visual = towers.encode(images, context_images, comm)
     x = splice(params, input_ids, visual)
     need = x.shape[0] + max_new_tokens + 1
     dec = getattr(params, "_decoder", None)
