@@ -53,8 +53,22 @@ def _worker(rank, world, port, q):
     vis_ref = towers.encode(inp["images"], inp["context_images"])
     ok_towers = same_everywhere and vis.shape == vis_ref.shape and bool(torch.allclose(vis, vis_ref, rtol=1e-5, atol=1e-5))
     assert comm.block(5) == ((0, 3) if rank == 0 else (3, 2)) and comm.block(1) == ((0, 1) if rank == 0 else (1, 0))
+    # sequence-parallel prefill: rows split over the ranks, K/V all-gathered per layer; decode replicated afterwards
+    from videoglamm_amd.vlm import LlamaDecoder
+    lc = G.configs.LLAMA_TINY
+    lsd = {"model." + k: v for k, v in G.weights("llama_tiny_manifest.json", 4).items()}
+    xs = G.rnd((1, 45, lc["hidden"]), 33)[0]
+    d1 = LlamaDecoder(Params(lsd, "cpu", torch.float32), lc, 64, use_graph=False)
+    last = d1.forward_sharded(xs, comm)
+    d0 = LlamaDecoder(Params(lsd, "cpu", torch.float32), lc, 64, use_graph=False)
+    ref_h = d0.forward(xs)
+    ok_sp = bool(torch.allclose(last, ref_h[-1:], rtol=1e-5, atol=1e-5)) and d1.pos == 45 and int(d1.pos_dev[0]) == 45
+    ok_sp = ok_sp and all(bool(torch.allclose(d1.kc[i][:45], d0.kc[i][:45], rtol=1e-5, atol=1e-5)) and
+                          bool(torch.allclose(d1.vc[i][:45], d0.vc[i][:45], rtol=1e-5, atol=1e-5)) for i in range(lc["num_layers"]))
+    step1, step0 = d1.forward(xs[:1] * 0.5), d0.forward(xs[:1] * 0.5)          # one more row through both caches
+    ok_sp = ok_sp and bool(torch.allclose(step1, step0, rtol=1e-5, atol=1e-5))
     if rank == 0:
-        q.put(("towers", ok_towers, tuple(vis.shape)))
+        q.put(("towers", ok_towers and ok_sp, (tuple(vis.shape), ok_towers, ok_sp)))
         ref_logits, _ = m.framewise_branch(images, text, hw)
         ref_vid = m.video_branch(images, text, hw)
         q.put((bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))), bool(torch.equal(vid, ref_vid)), tuple(masks.shape)))
@@ -70,7 +84,7 @@ def test_frame_sharding_world2():
     for p in procs:
         p.start()
     tag, ok_towers, vshape = q.get(timeout=300)
-    assert tag == "towers" and ok_towers, f"sharded vision towers differ from the single-process result {vshape}"
+    assert tag == "towers" and ok_towers, f"sharded vision towers / sequence-parallel prefill differ from the single-process result {vshape}"
     ok_fw, ok_vid, shape = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)

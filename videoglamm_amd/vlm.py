@@ -255,6 +255,56 @@ class LlamaDecoder:
         self.pos_dev.fill_(self.pos)
         return h
 
+    def forward_sharded(self, x, comm):
+        """sequence-parallel prefill over comm.world ranks (every rank holds the whole prompt x [S,D] and the whole model):
+        rank r runs rows [r*m, (r+1)*m) (m = ceil(S/world)) through every layer; per layer the new K/V rows are all-gathered
+        straight into every rank's KV cache (S/world x 2 x Hkv x hd elements per rank: ~0.9 MB at S = 1697, world = 8) and a
+        row attends causally to the keys [0, its position].  The projections of a row do not depend on the other rows, so the
+        prefill costs 1/world per rank (plus one weight pass) instead of a whole one on every rank; the last row's final-norm
+        state — what the replicated decode continues from — is broadcast by its owner."""
+        import torch.distributed as dist
+
+        P, c = self.P, self.c
+        S, W, r = x.shape[0], comm.world, comm.rank
+        m = -(-S // W)
+        a = min(r * m, S)
+        n = max(min(m, S - a), 0)                       # this rank's rows [a, a+n)
+        assert self.pos == 0 and W * m <= self.max_len
+        xl = x[a:a + n].contiguous()
+        send = torch.zeros(m, 2, self.Hkv, self.hd, dtype=x.dtype, device=x.device)
+        recv = torch.empty(W * m, 2, self.Hkv, self.hd, dtype=x.dtype, device=x.device)
+        for i in range(c["num_layers"]):
+            l = f"model.layers.{i}."
+            if n:
+                h = ops.rmsnorm(xl, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
+                wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
+                qkv = ops.linear(h, wqkv)
+                ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, a, None)
+                send[:n, 0].copy_(self.kc[i][a:a + n])
+                send[:n, 1].copy_(self.vc[i][a:a + n])
+            dist.all_gather(list(recv.chunk(W)), send, group=comm.group)
+            self.kc[i][:W * m].copy_(recv[:, 0])        # rows >= S are padding: never read, overwritten by the decode appends
+            self.vc[i][:W * m].copy_(recv[:, 1])
+            if n:
+                q = qkv[:, : self.H * self.hd].view(1, n, self.H, self.hd)
+                o = ops.attention(q, self.kc[i][:a + n].unsqueeze(0), self.vc[i][:a + n].unsqueeze(0), self.hd ** -0.5, causal=True)
+                xl = ops.linear(o.view(n, self.D), P.w(l + "self_attn.o_proj"), residual=xl)
+                h = ops.rmsnorm(xl, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
+                wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
+                xl = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=xl)
+        last = torch.zeros(1, self.D, dtype=x.dtype, device=x.device)
+        owner = (S - 1) // m
+        if n:
+            hl = ops.rmsnorm(xl, P.f32("model.norm.weight"), c["rms_eps"])
+            self.hid_all[a:a + n].copy_(hl)
+            if r == owner:
+                last.copy_(hl[-1:])
+        dist.broadcast(last, src=dist.get_global_rank(comm.group, owner) if comm.group is not None else owner, group=comm.group)
+        self.hid_all[S - 1:S].copy_(last)
+        self.pos = S
+        self.pos_dev.fill_(S)
+        return last
+
     def next_token(self, hidden_row):
         """lm_head + argmax of one final-norm row -> tok_dev (device int64[1])."""
         logits = ops.linear(hidden_row, self.P.w("lm_head"), out_dtype=torch.float32)
@@ -324,7 +374,10 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
         dec = LlamaDecoder(params, cfg["llm"], -(-need // 1024) * 1024)
         params._decoder = dec          # KV cache + captured decode graph are reused across clips
     dec.reset()
-    hidden = dec.forward(x)[-1:]                # hid_all rows 0..S-1: final-norm states of the spliced prompt
+    if comm is not None and comm.world > 1 and x.shape[0] >= 64 * comm.world and os.environ.get("VG_PREFILL_SHARDED", "1") != "0":
+        hidden = dec.forward_sharded(x, comm)   # sequence-parallel prefill: 1/world of the rows per rank
+    else:
+        hidden = dec.forward(x)[-1:]            # hid_all rows 0..S-1: final-norm states of the spliced prompt
     added = x.shape[0] - input_ids.numel()      # "num_newly_added_tokens" (VideoGLaMM.py:613,786)
     ids = input_ids.tolist()
     if max_new_tokens > 0:
