@@ -122,6 +122,30 @@ def test_e2e_min_blob_hip_fp32(cuda):
     check_e2e_min_blob(cuda)
 
 
+def check_chunked_prefill(device, tol):
+    """prefill in two chunks == prefill at once: the second chunk's rows attend causally to keys [0, own position] with
+    Sq < Skv — on the MI355X this goes through the split-KV + merge path of vg_attention (few query tiles, long KV), which
+    the sequence-parallel multi-GPU prefill (LlamaDecoder.forward_sharded) relies on."""
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    c = G.configs.LLAMA_TINY
+    sd = {"model." + k: v for k, v in G.weights("llama_tiny_manifest.json", 4).items()}
+    x = G.rnd((1, 600, c["hidden"]), 35)[0].to(device)
+    full = LlamaDecoder(Params(sd, device, torch.float32), c, 1024, use_graph=False).forward(x)
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 1024, use_graph=False)
+    parts = torch.cat([dec.forward(x[:300]), dec.forward(x[300:520]), dec.forward(x[520:])])
+    torch.testing.assert_close(parts.cpu(), full.cpu(), **tol)
+
+
+def test_chunked_prefill_cpu(cpu_ops):
+    check_chunked_prefill(torch.device("cpu"), dict(rtol=1e-4, atol=1e-4))
+
+
+@pytest.mark.gpu
+def test_chunked_prefill_hip_fp32(cuda):
+    check_chunked_prefill(cuda, dict(rtol=1e-3, atol=1e-3))
+
+
 def test_modules_cpu(cpu_ops):
     check_modules(torch.device("cpu"), dict(rtol=1e-4, atol=1e-4))
 

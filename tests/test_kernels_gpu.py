@@ -192,6 +192,8 @@ ATT = [  # B, Hq, Hkv, Sq, Skv, D, causal
     (1, 8, 2, 1, 700, 128, True),     # Llama decode step
     (1, 4, 4, 100, 100, 96, True),    # Phi-3 head dim
     (1, 4, 4, 33, 160, 64, True),     # causal with offset
+    (1, 32, 8, 213, 1697, 128, True),  # sequence-parallel prefill chunk (world 8): few query tiles, long KV -> split-KV + merge, causal offset
+    (1, 32, 8, 849, 1697, 128, True),  # the same at world 2
 ]
 
 
