@@ -18,6 +18,8 @@ shapes = [("llm qkv/o", 1697, 4096, 4096), ("llm gate|up", 1697, 28672, 4096), (
           ("hiera s1 qkv", 524288, 432, 144), ("hiera s1 fc1", 524288, 576, 144), ("hiera s2 qkv", 131072, 864, 288),
           ("hiera s3 qkv", 32768, 1728, 576), ("hiera s3 fc1", 32768, 2304, 576), ("hiera s3 fc2", 32768, 576, 2304),
           ("hiera s4 fc1", 8192, 4608, 1152), ("square 4k", 4096, 4096, 4096), ("square 8k", 8192, 8192, 8192),
+          ("sp8 qkv", 213, 6144, 4096), ("sp8 o", 213, 4096, 4096), ("sp8 gate|up", 213, 28672, 4096), ("sp8 down", 213, 4096, 14336),
+          ("sp4 gate|up", 425, 28672, 4096), ("sp4 down", 425, 4096, 14336),
           ("c2 llm qkv", 3361, 6144, 4096), ("c2 llm o", 3361, 4096, 4096), ("c2 llm gate|up", 3361, 28672, 4096), ("c2 llm down", 3361, 4096, 14336)]
 if os.environ.get("VG_BENCH_SHAPES"):
     shapes = [s for s in shapes if any(t in s[0] for t in os.environ["VG_BENCH_SHAPES"].split(","))]
