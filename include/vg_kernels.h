@@ -219,6 +219,12 @@ int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int 
 int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C,
                      int dtype, vg_stream_t stream);
 
+/* vg_decode_gemv with fp8 weights (config C4's LLM path, decode side): W8:[N or 2N, K] bytes in OCP e4m3, one fp32
+ * scale per weight row (w ~ scale[n] * fp8); x, the norm and the epilogue are unchanged (bf16 activations, fp32
+ * accumulation): y[n] = scale[n] * sum_k fp8(W8[n,k]) * xn[k].  Halves the bytes a decode step streams.
+ * K in {3072, 4096, 8192, 14336}. */
+int vg_decode_gemv_w8(const void* x, const uint8_t* W8, int64_t ldw, const float* wscale, void* y, const float* norm_w,
+                      float eps, const void* R, int N, int K, int glu, int out_dtype, vg_stream_t stream);
 /* Which kernel an (M, N, K) GEMM of vg_gemm / vg_gemm_window is routed to with the current knobs (measurement aid:
  * bench.py attributes per-launch times to kernels with it): 0 gemm_skinny_kernel (M <= 16), 1 gemm_tile_glds_kernel,
  * 2 gemm_tile_k64b_kernel, 3 gemm_tile_w128_kernel, 4 gemm_tile_s128_kernel.  N = output columns (F for a_op == 1).

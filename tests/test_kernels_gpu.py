@@ -351,3 +351,38 @@ def test_errors_are_loud(cuda):
         ops.linear(torch.zeros(4, 12, device=cuda)[:, :6], torch.zeros(4, 12, device=cuda)[:, :6])  # K=6 not a multiple of 4
     with pytest.raises(_lib.VGKernelError):
         ops.linear(torch.zeros(4, 8), torch.zeros(4, 8))  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("N,K,glu,norm,res", [(4096, 4096, False, False, True), (6144, 4096, False, True, False), (14336, 4096, True, True, False),
+                                              (4096, 14336, False, False, True), (3072, 8192, False, False, False), (9216, 3072, False, True, False),
+                                              (1001, 4096, False, False, False)])
+def test_decode_gemv_w8(cuda, N, K, glu, norm, res):
+    """fp8 (OCP e4m3) weights with per-row scales: exact against the fp32 product with the DEQUANTISED weights (the only
+    difference to the bf16 kernel is the weight format), and within the quantisation error of the original weights."""
+    from videoglamm_amd import ops
+    rows = 2 * N if glu else N
+    w = rnd(rows, K, seed=1, scale=K ** -0.5)
+    x = rnd(1, K, dtype=torch.bfloat16, seed=2)
+    nw = (1.0 + 0.1 * rnd(K, seed=3)) if norm else None
+    r = rnd(1, N, dtype=torch.bfloat16, seed=4) if res else None
+    q, sc = ops.quantize_fp8_rows(w.to(cuda))
+    deq = q.view(torch.float8_e4m3fn).float().cpu() * sc.cpu()[:, None]
+    assert (deq - w).abs().max() <= 0.0625 * w.abs().amax(dim=1).max() + 1e-6          # e4m3: 3 mantissa bits
+    y = ops.decode_gemv_w8(x.to(cuda), q, sc, norm_w=None if nw is None else nw.to(cuda), eps=1e-5, residual=None if r is None else r.to(cuda), glu=glu)
+    want = ref.decode_gemv(x, deq.to(torch.bfloat16).float(), norm_w=nw, eps=1e-5, residual=r, glu=glu) if False else None
+    xf = x.float()
+    if nw is not None:
+        xf = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * nw).to(torch.bfloat16).float()
+    acc = xf @ deq.t()
+    if glu:
+        g, u = acc[:, :N].to(torch.bfloat16).float(), acc[:, N:].to(torch.bfloat16).float()
+        acc = torch.nn.functional.silu(g).to(torch.bfloat16).float() * u
+    if r is not None:
+        acc = acc + r.float()
+    close(y, acc.to(torch.bfloat16), rtol=2e-2, atol=2e-2)
+    yf = ops.decode_gemv_w8(x.to(cuda), q, sc, norm_w=None if nw is None else nw.to(cuda), eps=1e-5, glu=glu, out_dtype=torch.float32)
+    if not glu and r is None:
+        close(yf, acc, rtol=2e-3, atol=2e-3)
+    from videoglamm_amd import _lib
+    with pytest.raises(_lib.VGKernelError):
+        ops.decode_gemv_w8(x.to(cuda)[:, :1024].contiguous(), q[:, :1024].contiguous(), sc)

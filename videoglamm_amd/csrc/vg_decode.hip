@@ -6,6 +6,7 @@
 //                         workgroup to finish (no separate rope / combine launches)
 // Arithmetic mirrors the stand-alone kernels (vg_rmsnorm, vg_gemm skinny path, vg_rope_kv_append) step for step.
 #include "vg_common.h"
+#include <type_traits>
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -45,6 +46,21 @@ template <> __device__ __forceinline__ float dec_dot<bf16_t>(const u32x4_t& a, c
   }
   return s;
 }
+// 16 fp8 (OCP e4m3) weights of one 16-byte chunk against the 16 bf16 activations of two x chunks
+__device__ __forceinline__ float dec_dot_w8(const u32x4_t& w, const u32x4_t& x0, const u32x4_t& x1) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[e], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[e], true);
+    const uint32_t xa = e < 2 ? x0[2 * e] : x1[2 * e - 4], xb = e < 2 ? x0[2 * e + 1] : x1[2 * e - 3];
+    s = fmaf(lo[0], __uint_as_float(xa << 16), s);
+    s = fmaf(lo[1], __uint_as_float(xa & 0xffff0000u), s);
+    s = fmaf(hi[0], __uint_as_float(xb << 16), s);
+    s = fmaf(hi[1], __uint_as_float(xb & 0xffff0000u), s);
+  }
+  return s;
+}
 template <typename T> __device__ __forceinline__ float dec_round(float v) { return v; }
 template <> __device__ __forceinline__ float dec_round<bf16_t>(float v) { return bf2f(f2bf(v)); }
 
@@ -55,11 +71,16 @@ template <> __device__ __forceinline__ float dec_round<bf16_t>(float v) { return
 struct DecGemvArgs {
   const void* x; const void* W; void* y; const float* nw; const void* R;
   int N, K; int64_t ldw; float eps; int ppw;
+  const float* wscale;   // fp8 weights only: one fp32 scale per weight row
 };
 
 template <typename T, typename TO, bool GLU>
 __device__ __forceinline__ void dec_gemv_store(const DecGemvArgs& p, int pi, float a0, float a1) {
   const int n0 = GLU ? pi : 2 * pi, n1 = GLU ? p.N + pi : 2 * pi + 1;
+  if (p.wscale) {        // fp8 weights: the row scales leave the dot products
+    a0 *= p.wscale[n0];
+    a1 *= p.wscale[GLU ? n1 : min(n1, p.N - 1)];
+  }
   TO* y = (TO*)p.y;
   const TO* R = (const TO*)p.R;
   if constexpr (GLU) {
@@ -92,21 +113,25 @@ constexpr int DEC_MAX_PPW = 64;
 
 // NB batches per row pair, CPB 16-byte chunks per lane per row per batch: K = NB * CPB * 64 chunks (CPB = 4 unless K only
 // divides by 128 chunks, e.g. Phi-3's hidden 3072 = 3 x 2 x 64 x 8).
-template <typename T, typename TO, bool GLU, int NB, int CPB = 4>
+// W8: the weights are fp8 (OCP e4m3, one byte each) with a per-row scale; a weight chunk then covers 16 K elements = TWO
+// x chunks, and NB x CPB x 64 counts weight chunks (K = 16 x that).
+template <typename T, typename TO, bool GLU, int NB, int CPB = 4, bool W8 = false>
 __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dec_smem[];
   __shared__ float red[4];
   __shared__ float res[4][DEC_MAX_PPW][2];
   constexpr int KPC = 16 / sizeof(T);
   constexpr int NWV = KPC / 4;     // float4 loads of norm weight per chunk
-  constexpr int NCH = NB * CPB * 64;             // 16-byte chunks of x / of a weight row
+  static_assert(!W8 || sizeof(T) == 2, "fp8 weights pair with bf16 activations");
+  constexpr int NCH = NB * CPB * 64 * (W8 ? 2 : 1);   // 16-byte chunks of x (with W8 a weight row has half as many)
   constexpr int XN = (NCH + 255) / 256;          // chunks of x per thread (the last one may be partial: NCH % 256 == 128)
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t* xs = (u32x4_t*)dec_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npair = GLU ? p.N : (p.N + 1) / 2;
   const int gw = blockIdx.x * 4 + wave;
-  const T* W = (const T*)p.W;
+  typedef typename std::conditional<W8, uint8_t, T>::type WT;
+  const WT* W = (const WT*)p.W;
   const int p0 = gw * p.ppw;
   const int np = max(min(p0 + p.ppw, npair) - p0, 0);     // pairs of this wave
   const int total = np * NB;
@@ -179,9 +204,16 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
   auto consume = [&](const u32x4_t (&v0)[CPB], const u32x4_t (&v1)[CPB]) {
 #pragma unroll
     for (int u = 0; u < CPB; ++u) {
-      const u32x4_t xv = xs[ccb * (64 * CPB) + u * 64 + lane];
-      a0 += dec_dot<T>(v0[u], xv);
-      a1 += dec_dot<T>(v1[u], xv);
+      const int wc = ccb * (64 * CPB) + u * 64 + lane;
+      if constexpr (W8) {
+        const u32x4_t xa = xs[2 * wc], xb = xs[2 * wc + 1];
+        a0 += dec_dot_w8(v0[u], xa, xb);
+        a1 += dec_dot_w8(v1[u], xa, xb);
+      } else {
+        const u32x4_t xv = xs[wc];
+        a0 += dec_dot<T>(v0[u], xv);
+        a1 += dec_dot<T>(v1[u], xv);
+      }
     }
     if (++ccb == NB) {
       a0 = wave_sum(a0);
@@ -323,6 +355,50 @@ static int launch_decode_gemv(DecGemvArgs p, hipStream_t st) {
   return VG_OK;
 }
 
+template <typename TO, bool GLU>
+static int launch_decode_gemv_w8(DecGemvArgs p, hipStream_t st) {
+  static int bpc = -1;
+  if (bpc < 0) {
+    const char* e = getenv("VG_DEC_BPC");
+    bpc = e ? atoi(e) : 4;
+    if (bpc < 1) bpc = 1;
+  }
+  const int npair = GLU ? p.N : (p.N + 1) / 2;
+  const int maxw = 256 * bpc * 4;
+  int ppw = (npair + maxw - 1) / maxw;
+  for (int c = ppw; c <= 2 * ppw; ++c)
+    if (((npair + 4 * c - 1) / (4 * c)) % 256 == 0 && npair % (4 * c) == 0) { ppw = c; break; }
+  if (ppw > DEC_MAX_PPW) ppw = DEC_MAX_PPW;
+  const int blocks = (npair + 4 * ppw - 1) / (4 * ppw);
+  p.ppw = ppw;
+  const size_t lds = (size_t)p.K * 2;
+  const int nchw = p.K / 16;               // weight chunks per row
+  if (nchw % 256 == 0 && nchw / 256 == 1) decode_gemv_fast_kernel<bf16_t, TO, GLU, 1, 4, true><<<blocks, 256, lds, st>>>(p);
+  else if (nchw % 256 == 0 && nchw / 256 == 2) decode_gemv_fast_kernel<bf16_t, TO, GLU, 2, 4, true><<<blocks, 256, lds, st>>>(p);
+  else if (nchw == 7 * 128) decode_gemv_fast_kernel<bf16_t, TO, GLU, 7, 2, true><<<blocks, 256, lds, st>>>(p);
+  else if (nchw == 3 * 64) decode_gemv_fast_kernel<bf16_t, TO, GLU, 3, 1, true><<<blocks, 256, lds, st>>>(p);
+  else {
+    vg_set_error("vg_decode_gemv_w8: K=%d is not one of the supported row lengths (3072, 4096, 8192, 14336)", p.K);
+    return VG_ERR_UNSUPPORTED;
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_decode_gemv_w8(const void* x, const uint8_t* W8, int64_t ldw, const float* wscale, void* y, const float* norm_w,
+                                 float eps, const void* R, int N, int K, int glu, int out_dtype, vg_stream_t stream) {
+  VG_CHECK(x && W8 && wscale && y && N > 0 && K > 0, VG_ERR_ARG, "vg_decode_gemv_w8: bad args N=%d K=%d", N, K);
+  VG_CHECK(K % 16 == 0 && ldw % 16 == 0, VG_ERR_ARG, "vg_decode_gemv_w8: K/ldw must be multiples of 16 (K=%d ldw=%lld)", K, (long long)ldw);
+  VG_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W8 & 15) == 0 && ((uintptr_t)norm_w & 15) == 0, VG_ERR_ARG,
+           "vg_decode_gemv_w8: x/W/norm_w must be 16-byte aligned");
+  VG_CHECK((int64_t)K * 2 <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_decode_gemv_w8: K=%d does not fit the LDS staging", K);
+  VG_CHECK(out_dtype == VG_BF16 || out_dtype == VG_F32, VG_ERR_ARG, "vg_decode_gemv_w8: bad out_dtype %d", out_dtype);
+  DecGemvArgs p{x, W8, y, norm_w, R, N, K, ldw, eps, 1, wscale};
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == VG_BF16) return glu ? launch_decode_gemv_w8<bf16_t, true>(p, st) : launch_decode_gemv_w8<bf16_t, false>(p, st);
+  return glu ? launch_decode_gemv_w8<float, true>(p, st) : launch_decode_gemv_w8<float, false>(p, st);
+}
+
 extern "C" int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y, const float* norm_w, float eps,
                               const void* R, int N, int K, int glu, int in_dtype, int out_dtype, vg_stream_t stream) {
   VG_CHECK(x && W && y && N > 0 && K > 0, VG_ERR_ARG, "vg_decode_gemv: bad args N=%d K=%d", N, K);
@@ -332,7 +408,7 @@ extern "C" int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y
   VG_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_w & 15) == 0, VG_ERR_ARG,
            "vg_decode_gemv: x/W/norm_w must be 16-byte aligned");
   VG_CHECK((int64_t)K * es <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_decode_gemv: K=%d does not fit the LDS staging", K);
-  DecGemvArgs p{x, W, y, norm_w, R, N, K, ldw, eps, 1};
+  DecGemvArgs p{x, W, y, norm_w, R, N, K, ldw, eps, 1, nullptr};
   hipStream_t st = (hipStream_t)stream;
 #define VG_DEC_GEMV(TI, TOO) return glu ? launch_decode_gemv<TI, TOO, true>(p, st) : launch_decode_gemv<TI, TOO, false>(p, st)
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) VG_DEC_GEMV(bf16_t, bf16_t);

@@ -234,6 +234,32 @@ def decode_gemv(x, w, norm_w=None, eps=0.0, residual=None, glu=False, out_dtype=
     return y
 
 
+def quantize_fp8_rows(w):
+    """[N,K] weight -> (uint8 [N,K] holding OCP e4m3 codes, fp32 [N] scales): w ~ scale[n] * fp8.  One-time load work (torch)."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return q, scale
+
+
+def decode_gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, glu=False, out_dtype=None, out=None):
+    """decode_gemv with fp8 (e4m3) weights + per-row scales (vg_decode_gemv_w8): x bf16 [1,K]; w8 uint8 [N or 2N, K]."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    assert x.dtype == torch.bfloat16 and x.numel() == K and x.is_contiguous() and w8.dtype == torch.uint8 and w8.stride(1) == 1 and w8.shape[1] == K
+    assert wscale.dtype == torch.float32 and wscale.numel() == w8.shape[0] and wscale.is_contiguous()
+    N = w8.shape[0] // 2 if glu else w8.shape[0]
+    odt = out_dtype or x.dtype
+    y = out if out is not None else torch.empty(1, N, dtype=odt, device=x.device)
+    assert y.is_contiguous() and y.numel() == N
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == N and residual.dtype == y.dtype
+    rc = lib.vg_decode_gemv_w8(_p(x), _p(w8), w8.stride(0), _p(wscale), _p(y), _p(None if norm_w is None else _f32(norm_w)), float(eps),
+                               _p(residual), N, K, int(bool(glu)), _dt(y), _stream())
+    _lib.check(rc, "vg_decode_gemv_w8")
+    return y
+
+
 def decode_attention_workspace(H, Hkv, D, max_len, device):
     """zero-filled once: the workspace ends with per-KV-head arrival counters that the kernel resets itself."""
     n = _lib.load().vg_decode_attention_ws_floats(H, Hkv, D, max_len)

@@ -70,6 +70,19 @@ class Params:
             return self._padk(w), bias
         return self._get(("fused",) + tuple(names), make)
 
+    def fp8(self, names, stored=None):
+        """fused()/w() of the named weights quantised for the decode GEMVs: (uint8 [N,K] OCP-e4m3 codes, fp32 [N] row scales).
+        Made once from the packed model-dtype weight (so the bf16 prefill and the fp8 decode see the same rounding of the
+        checkpoint first); kept beside it — the prefill GEMMs stay bf16."""
+        from . import ops
+
+        names = [names] if isinstance(names, str) else list(names)
+
+        def make():
+            w = self.w(names[0]) if len(names) == 1 and stored is None else self.fused(names, stored=stored)[0]
+            return ops.quantize_fp8_rows(w)
+        return self._get(("fp8",) + tuple(names), make)
+
     # ---- convolutions as GEMMs
     def conv_w(self, name):
         """Conv2d [Cout,Cin,kh,kw] (or Conv3d with kt=1) -> [Cout, (ky*kw+kx)*Cin + c] padded (vg_im2col column order)."""

@@ -196,9 +196,15 @@ class LlamaDecoder:
         es = 2 if dt == torch.bfloat16 else 4
         ffn = c.get("ffn") or params.t("model.layers.0.mlp.down_proj.weight").shape[1]
         # the fused decode kernels' shape limits (vg_decode_gemv / vg_decode_attention); VG_DECODE_FUSED=0 = A/B knob
+        # fp8 (e4m3) weights with per-row scales in the decode step's MLP GEMVs and the lm_head (cfg["decode_weights"] == "fp8": the decode
+        # side of BASELINE config C4's "fp8 LLM path"; bf16 activations, fp32 accumulation; the prefill GEMMs stay bf16)
+        self.w8 = c.get("decode_weights") == "fp8"
+        if self.w8:
+            assert dt == torch.bfloat16 and self.D in (3072, 4096, 8192) and ffn in (8192, 14336), "fp8 decode weights: bf16 model, supported row lengths"
         self.fused_decode = (os.environ.get("VG_DECODE_FUSED", "1") != "0" and (self.H // self.Hkv) in (1, 2, 4, 8)
                              and self.hd % (16 // es) == 0 and self.hd * es <= 512 and max_len <= 8192
                              and max(self.D, ffn) * es <= 65536 and self.D % (16 // es) == 0 and ffn % (16 // es) == 0)
+        assert self.fused_decode or not self.w8, "fp8 decode weights need the fused decode kernels"
 
     def reset(self):
         self.pos = 0
@@ -235,14 +241,23 @@ class LlamaDecoder:
             self.attn_ws = ops.decode_attention_workspace(self.H, self.Hkv, self.hd, self.max_len, x.device)
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
-            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
+            qkv_names = [l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"]
+            gu_names = [l + "mlp.gate_proj", l + "mlp.up_proj"]
+            wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
             qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
             o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
                                      self.pos_dev, self.hd ** -0.5, self.attn_ws)
             x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
-            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
-            a = ops.decode_gemv(x, wgu, norm_w=P.f32(l + "post_attention_layernorm.weight"), eps=c["rms_eps"], glu=True)
-            x = ops.decode_gemv(a, P.w(l + "mlp.down_proj"), residual=x)
+            if self.w8:
+                # fp8 weights + row scales for the MLP (81 % of a layer's bytes) — the attention projections stay bf16: at K = 4096
+                # an fp8 row is a single batch of loads per lane and the per-row reduction eats the gain (10.4 vs 9.1 us measured)
+                a = ops.decode_gemv_w8(x, *P.fp8(gu_names, stored=l + "mlp.gate_up_proj"), norm_w=P.f32(l + "post_attention_layernorm.weight"),
+                                       eps=c["rms_eps"], glu=True)
+                x = ops.decode_gemv_w8(a, *P.fp8(l + "mlp.down_proj"), residual=x)
+            else:
+                wgu, _ = P.fused(gu_names, stored=l + "mlp.gate_up_proj")
+                a = ops.decode_gemv(x, wgu, norm_w=P.f32(l + "post_attention_layernorm.weight"), eps=c["rms_eps"], glu=True)
+                x = ops.decode_gemv(a, P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
 
     def forward(self, x):
@@ -307,7 +322,10 @@ class LlamaDecoder:
 
     def next_token(self, hidden_row):
         """lm_head + argmax of one final-norm row -> tok_dev (device int64[1])."""
-        logits = ops.linear(hidden_row, self.P.w("lm_head"), out_dtype=torch.float32)
+        if self.w8 and hidden_row.shape[0] == 1:
+            logits = ops.decode_gemv_w8(hidden_row.contiguous(), *self.P.fp8("lm_head"), out_dtype=torch.float32)
+        else:
+            logits = ops.linear(hidden_row, self.P.w("lm_head"), out_dtype=torch.float32)
         ops.argmax(logits.view(1, -1), out=self.tok_dev)
 
     def _decode_step(self):
