@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--src", type=int, default=512, help="source (output mask) resolution")
     ap.add_argument("--max-new-tokens", type=int, default=32)
     ap.add_argument("--objects", type=int, default=1, help="[SEG] objects (multi-object GCG: 8)")
+    ap.add_argument("--prefill", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the LLM prefill GEMMs on the fp8 MFMA path (per-token / per-channel scales); with --decode-weights fp8 = "
+                         "BASELINE config C4's fp8 LLM path (NOT the bf16 headline configuration)")
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 weights + row scales in the decode step's MLP GEMVs and the lm_head (decode side of BASELINE config C4's fp8 "
                          "LLM path; NOT the bf16 headline configuration)")
@@ -262,6 +265,8 @@ def main():
     assert 1 <= args.objects and 4 + 3 * (args.objects - 1) < args.max_new_tokens
     if args.decode_weights == "fp8":
         cfg["llm"] = dict(cfg["llm"], decode_weights="fp8")
+    if args.prefill == "fp8":
+        cfg["llm"] = dict(cfg["llm"], prefill_gemm="fp8")
     cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
     t0 = time.time()
     sd = synth.device_state_dict(synth.manifest(cfg), device, torch.bfloat16)
@@ -299,13 +304,14 @@ def main():
         else "C4 share of one GPU (64 frames / 8)" if (args.frames_per_gpu, args.src, args.objects) == (8, 1024, 8) else "custom"
     if args.llm != "llama3-8b":
         name += " with the Phi-3-mini LLM"
-    if args.decode_weights == "fp8":
-        name += " [fp8 decode-step weights: not the bf16 headline configuration]"
+    if args.decode_weights == "fp8" or args.prefill == "fp8":
+        name += f" [fp8 LLM path: prefill {args.prefill}, decode weights {args.decode_weights} — not the bf16 headline configuration]"
     res = {
         "metric": "frames/sec end-to-end (text+masks)", "value": round(T * args.steps / dt, 3), "unit": "frames/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.decode_weights == "bf16" else "bf16 activations / prefill, fp8 (e4m3) weights in the decode step", "data": "synthetic",
+        "dtype": "bf16" if (args.decode_weights, args.prefill) == ("bf16", "bf16") else
+                 f"bf16 model; LLM prefill GEMMs {args.prefill}, decode-step MLP / lm_head weights {args.decode_weights} (e4m3, row scales)", "data": "synthetic",
         "config": {"workload": f"{name}: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
                                f"Te={args.te}, {'Llama-3-8B' if args.llm == 'llama3-8b' else 'Phi-3-mini'} bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
                                f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),

@@ -225,6 +225,17 @@ int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H
  * K in {3072, 4096, 8192, 14336}. */
 int vg_decode_gemv_w8(const void* x, const uint8_t* W8, int64_t ldw, const float* wscale, void* y, const float* norm_w,
                       float eps, const void* R, int N, int K, int glu, int out_dtype, vg_stream_t stream);
+/* fp8 (OCP e4m3) prefill path of BASELINE config C4.
+ * vg_quantize_fp8_rows: q[m,:] = e4m3(x[m,:] / scale[m]) with scale[m] = absmax(x[m,:]) / 448 (round to nearest even, what
+ * torch's .to(float8_e4m3fn) does); x bf16 / fp32 [M,K], K % 4 == 0.
+ * vg_gemm_f8: C[m,n] = scale_a[m] * scale_w[n] * sum_k A8[m,k] * W8[n,k]  (+ bias[n]) (+ R[m,n]), fp32 accumulation on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate at half the operand bytes);
+ * a_op = 1: W8 = [gate; up] rows, C[m,n] = silu(gate)*up like vg_gemm.  M > 16 (prefill only), K % 16 == 0. */
+int vg_quantize_fp8_rows(const void* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int64_t M, int K, int dtype,
+                         vg_stream_t stream);
+int vg_gemm_f8(const uint8_t* A8, int64_t lda, const float* a_scale, const uint8_t* W8, int64_t ldw, const float* w_scale,
+               void* C, int64_t ldc, const float* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
+               int out_dtype, int a_op, vg_stream_t stream);
 /* Which kernel an (M, N, K) GEMM of vg_gemm / vg_gemm_window is routed to with the current knobs (measurement aid:
  * bench.py attributes per-launch times to kernels with it): 0 gemm_skinny_kernel (M <= 16), 1 gemm_tile_glds_kernel,
  * 2 gemm_tile_k64b_kernel, 3 gemm_tile_w128_kernel, 4 gemm_tile_s128_kernel.  N = output columns (F for a_op == 1).

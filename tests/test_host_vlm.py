@@ -171,6 +171,28 @@ def test_decode_fp8_weights_hip(cuda):
     assert cos > 0.998 and rel < 0.06, (cos, rel)     # e4m3 has 3 mantissa bits: ~3.6 % rms per weight, it does not average out of a dot product
 
 
+@pytest.mark.gpu
+def test_prefill_fp8_hip(cuda):
+    """fp8 MFMA prefill (per-token activation scales, per-channel weight scales) vs the bf16 prefill on a 2-layer decoder of
+    Llama-3-8B width: final-norm states within e4m3's noise, and the KV cache it leaves behind serves a bf16 decode step."""
+    from videoglamm_amd import synth
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    c = dict(synth.LLAMA3_8B, num_layers=2, vocab=4096)
+    man = {k: v for k, v in synth.vlm_manifest(dict(synth.videoglamm_llama3_8b(), llm=c)).items()
+           if k.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))}
+    sd = synth.device_state_dict(man, cuda, torch.bfloat16)
+    x = (torch.randn(300, c["hidden"], generator=torch.Generator().manual_seed(4)) * 0.5).to(cuda, torch.bfloat16)
+    hs = []
+    for mode in ("bf16", "fp8"):
+        dec = LlamaDecoder(Params(sd, cuda, torch.bfloat16), dict(c, prefill_gemm=mode), 1024, use_graph=False)
+        h = dec.forward(x[:299])
+        hs.append(torch.cat([h, ops_decode_row(dec, x[299:300])]).float().cpu())
+    cos = torch.nn.functional.cosine_similarity(hs[0], hs[1]).min().item()
+    rel = ((hs[0] - hs[1]).norm(dim=1) / hs[0].norm(dim=1)).max().item()
+    assert cos > 0.995 and rel < 0.10, (cos, rel)
+
+
 def test_modules_cpu(cpu_ops):
     check_modules(torch.device("cpu"), dict(rtol=1e-4, atol=1e-4))
 

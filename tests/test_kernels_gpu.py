@@ -386,3 +386,32 @@ def test_decode_gemv_w8(cuda, N, K, glu, norm, res):
     from videoglamm_amd import _lib
     with pytest.raises(_lib.VGKernelError):
         ops.decode_gemv_w8(x.to(cuda)[:, :1024].contiguous(), q[:, :1024].contiguous(), sc)
+
+
+@pytest.mark.parametrize("M,N,K,glu,res", [(200, 512, 256, False, False), (1697, 6144, 4096, False, False), (333, 4096, 4096, False, True),
+                                           (257, 1024, 4096, True, False), (640, 4096, 14336, False, True), (130, 264, 144, False, False)])
+def test_gemm_f8(cuda, M, N, K, glu, res):
+    """fp8 x fp8 GEMM with per-row scales on both operands: the device quantiser must give torch's e4m3 codes, and the
+    product must match the fp32 product of the DEQUANTISED operands (the MFMA sums exact products in fp32)."""
+    from videoglamm_amd import ops
+    x = rnd(M, K, dtype=torch.bfloat16, seed=1)
+    w = rnd((2 * N if glu else N), K, seed=2, scale=K ** -0.5)
+    r = rnd(M, N, dtype=torch.bfloat16, seed=3) if res else None
+    q, qs = ops.quantize_fp8(x.to(cuda))
+    sc_ref = (x.float().abs().amax(dim=1).clamp_min(1e-12) / 448.0)
+    torch.testing.assert_close(qs.cpu(), sc_ref, rtol=1e-6, atol=0)
+    q_ref = (x.float() / qs.cpu()[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), q_ref)
+    w8, ws = ops.quantize_fp8_rows(w.to(cuda))
+    y = ops.linear_f8(q, qs, w8, ws, residual=None if r is None else r.to(cuda), glu=glu)
+    xd = q.cpu().view(torch.float8_e4m3fn).float() * qs.cpu()[:, None]
+    wd = w8.cpu().view(torch.float8_e4m3fn).float() * ws.cpu()[:, None]
+    acc = xd @ wd.t()
+    if glu:
+        g, u = acc[:, :N].to(torch.bfloat16).float(), acc[:, N:].to(torch.bfloat16).float()
+        acc = torch.nn.functional.silu(g).to(torch.bfloat16).float() * u
+    if r is not None:
+        acc = acc + r.float()
+    close(y, acc.to(torch.bfloat16), rtol=2e-2, atol=2e-2)
+    if not glu and r is None:
+        close(ops.linear_f8(q, qs, w8, ws, out_dtype=torch.float32), acc, rtol=1e-3, atol=1e-3)

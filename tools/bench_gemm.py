@@ -29,7 +29,19 @@ for name, M, N, K in shapes:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ms = t(lambda: ops.linear(a, w, out=out))
     print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s")
-if os.environ.get('VG_BENCH_ONLY') == 'gemm':
+if os.environ.get('VG_BENCH_ONLY') in ('gemm', 'f8'):
+    for name, M, N, K, glu in [("llm qkv", 1697, 6144, 4096, False), ("llm o", 1697, 4096, 4096, False), ("llm gate|up+glu", 1697, 14336, 4096, True),
+                               ("llm down", 1697, 4096, 14336, False), ("c2 gate|up+glu", 3361, 14336, 4096, True), ("c2 down", 3361, 4096, 14336, False),
+                               ("square 8k", 8192, 8192, 8192, False)]:
+        a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        w = torch.randn((2 * N if glu else N), K, device="cuda", dtype=torch.bfloat16)
+        q, qs = ops.quantize_fp8(a)
+        w8, ws = ops.quantize_fp8_rows(w)
+        ms = t(lambda: ops.linear_f8(q, qs, w8, ws, glu=glu))
+        mq = t(lambda: ops.quantize_fp8(a))
+        mb = t(lambda: ops.linear(a, w, glu=glu))
+        fl = 2 * M * (2 * N if glu else N) * K
+        print(f"f8 gemm {name:16s} M={M:5d} N={N:6d} K={K:6d}  fp8 {ms*1e3:8.1f} us {fl/ms/1e9:8.1f} TF/s | bf16 {mb*1e3:8.1f} us {fl/mb/1e9:8.1f} TF/s | quantise A {mq*1e3:6.1f} us")
     sys.exit(0)
 for name, B, H, Hkv, Sq, Skv, D, causal in [("llm prefill", 1, 32, 8, 1697, 1697, 128, True), ("llm decode", 1, 32, 8, 1, 1730, 128, True),
                                             ("iv2", 2, 16, 16, 1025, 1025, 88, False), ("clip", 8, 16, 16, 577, 577, 64, False),

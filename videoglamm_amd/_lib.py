@@ -24,6 +24,8 @@ def _sig(lib):
         "vg_last_error": ([], c_char_p),
         "vg_init": ([I], c_int),
         "vg_gemm": ([P, L, L, P, L, L, P, L, L, P, P, P, L, L, I, I, I, I, I, I, I, I, P], c_int),
+        "vg_quantize_fp8_rows": ([P, L, P, L, P, L, I, I, P], c_int),
+        "vg_gemm_f8": ([P, L, P, P, L, P, P, L, P, P, L, L, L, L, I, I, P], c_int),
         "vg_gemm_route": ([L, L, L, I, I, I], c_int),
         "vg_gemm_window": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),

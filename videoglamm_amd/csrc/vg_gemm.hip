@@ -23,6 +23,8 @@ struct GemmArgs {
   // + residual add fused into the epilogue).  GEMM row m is always the window-order index.
   int wmode, wH, wW, wws, wnH, wnW;
   const void* zrow;   // K zeros: source of the padded window rows (the LDS-DMA cannot zero-fill)
+  // fp8 operands (vg_gemm_f8): C = (A8 . W8^T) * sa[m] * sw[n] — one fp32 scale per A row (token) and per W row (output)
+  const float* sa; const float* sw;
 };
 
 // window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
@@ -63,6 +65,12 @@ template <> struct MmaOp<float> {
       c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
   }
 };
+
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+__device__ __forceinline__ i32x8_t f8_operand(const u32x4_t& lo, const u32x4_t& hi) {
+  i32x8_t v = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  return v;
+}
 
 constexpr int GBM = 128, GBN = 128;
 
@@ -222,7 +230,14 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float g = wg[ml * ES + cg * 8 + e] + bg[e], u = wu[ml * ES + cg * 8 + e] + bu[e];
+          float g = wg[ml * ES + cg * 8 + e], u = wu[ml * ES + cg * 8 + e];
+          if (p.sa) {
+            const int nn = min(n0 + e, N - 1);
+            g *= p.sa[m] * p.sw[nn];
+            u *= p.sa[m] * p.sw[N + nn];
+          }
+          g += bg[e];
+          u += bu[e];
           if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
           g = g / (1.0f + __expf(-g));
           if (sizeof(TO) == 2) g = bf2f(f2bf(g));
@@ -265,6 +280,11 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ws[ml * ES + cg * 8 + e];
+      if (p.sa) {           // fp8 operands: the token and output-channel scales leave the integer-like dot products
+        const float sr = p.sa[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= sr * p.sw[min(n0 + e, N - 1)];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = vg_act(v[e] + bv[e], p.act) * gv[e];
       TO* cp = C + mo * p.ldc + n0;
@@ -434,12 +454,27 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
         fa1[g] = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
         fb1[g] = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
       }
+      if constexpr (sizeof(T) == 1) {
+        // fp8 (e4m3) operands: a K step is 128 elements = two v_mfma_scale_f32_32x32x64_f8f6f4 groups (unit scales); a lane
+        // half holds 32 of a group's 64 K bytes — chunks 4G+h and 4G+2+h, the same pair for A and W, which is all that the
+        // dot products need
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
-        MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
-        MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
-        MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
+        for (int G = 0; G < 2; ++G) {
+          const i32x8_t a0 = f8_operand(fa0[2 * G], fa0[2 * G + 1]), a1 = f8_operand(fa1[2 * G], fa1[2 * G + 1]);
+          const i32x8_t b0 = f8_operand(fb0[2 * G], fb0[2 * G + 1]), b1 = f8_operand(fb1[2 * G], fb1[2 * G + 1]);
+          acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b0, acc[0][0], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b1, acc[0][1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b0, acc[1][0], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc[1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b1, acc[1][1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+          MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+          MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+          MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
+        }
       }
     } else {
 #pragma unroll
@@ -1385,6 +1420,78 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
 // vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
 struct GemmWindow { int mode, H, W, ws; const void* zrow; };
 static thread_local GemmWindow g_window{0, 0, 0, 0, nullptr};
+
+// ---- fp8 path (config C4's LLM prefill): per-row quantisation of the activations and the fp8 x fp8 tile GEMM
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const T* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int K) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* xr = x + (int64_t)blockIdx.x * ldx;
+  float mx = 0.f;
+  for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(vg_elt<T>::ld(xr + k)));
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = fmaxf(mx, 1e-12f) / 448.0f;
+  if (tid == 0) scale[blockIdx.x] = sc;
+  uint8_t* qr = q + (int64_t)blockIdx.x * ldq;
+  for (int k = tid * 4; k < K; k += 1024) {         // K % 4 == 0: four values -> one dword of e4m3 codes (RNE, as torch rounds)
+    const float a = __fdiv_rn(vg_elt<T>::ld(xr + k), sc), b = __fdiv_rn(vg_elt<T>::ld(xr + k + 1), sc);
+    const float c = __fdiv_rn(vg_elt<T>::ld(xr + k + 2), sc), d = __fdiv_rn(vg_elt<T>::ld(xr + k + 3), sc);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    *(int*)(qr + k) = w;
+  }
+}
+
+extern "C" int vg_quantize_fp8_rows(const void* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int64_t M, int K, int dtype,
+                                    vg_stream_t stream) {
+  VG_CHECK(x && q && scale && M > 0 && K > 0 && K % 4 == 0 && ldq % 4 == 0, VG_ERR_ARG, "vg_quantize_fp8_rows: bad args M=%lld K=%d", (long long)M, K);
+  VG_CHECK(dtype == VG_BF16 || dtype == VG_F32, VG_ERR_ARG, "vg_quantize_fp8_rows: bad dtype %d", dtype);
+  VG_CHECK(M <= 0x7fffffff, VG_ERR_UNSUPPORTED, "vg_quantize_fp8_rows: too many rows");
+  if (dtype == VG_BF16) quantize_fp8_rows_kernel<bf16_t><<<(unsigned)M, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, q, ldq, scale, K);
+  else quantize_fp8_rows_kernel<float><<<(unsigned)M, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, q, ldq, scale, K);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+template <typename TO>
+static int launch_gemm_f8(const GemmArgs& p, hipStream_t st) {
+  static bool attr = false;
+  const int lds128 = 4 * 128 * 144;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<uint8_t, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+    attr = true;
+  }
+  GemmArgs q = p;
+  const int nt = p.a_op == 1 ? (p.N + 63) / 64 : (p.N + GBN - 1) / GBN, mt = (p.M + GBM - 1) / GBM;
+  q.gn = nt < 4 ? nt : 4;
+  gemm_tile_glds_kernel<uint8_t, TO, true><<<dim3(nt, mt, 1), 256, lds128, st>>>(q);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_gemm_f8(const uint8_t* A8, int64_t lda, const float* a_scale, const uint8_t* W8, int64_t ldw, const float* w_scale,
+                          void* C, int64_t ldc, const float* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                          int out_dtype, int a_op, vg_stream_t stream) {
+  VG_CHECK(A8 && W8 && C && a_scale && w_scale && M > 16 && N > 0 && K > 0, VG_ERR_ARG, "vg_gemm_f8: bad args M=%lld N=%lld K=%lld (M > 16)",
+           (long long)M, (long long)N, (long long)K);
+  VG_CHECK(K % 16 == 0 && lda % 16 == 0 && ldw % 16 == 0 && (((uintptr_t)A8 | (uintptr_t)W8) & 15) == 0, VG_ERR_ARG,
+           "vg_gemm_f8: K / lda / ldw must be multiples of 16 and the operands 16-byte aligned");
+  VG_CHECK(out_dtype == VG_BF16 || out_dtype == VG_F32, VG_ERR_ARG, "vg_gemm_f8: bad out_dtype %d", out_dtype);
+  VG_CHECK(a_op == 0 || (a_op == 1 && !R), VG_ERR_ARG, "vg_gemm_f8: a_op %d (0, or 1 = SwiGLU without residual)", a_op);
+  const int oes = out_dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK(N % 8 == 0 && (ldc * oes) % 16 == 0 && ((uintptr_t)C & 15) == 0 && (!R || ((ldr * oes) % 16 == 0 && ((uintptr_t)R & 15) == 0)),
+           VG_ERR_UNSUPPORTED, "vg_gemm_f8: C / R rows must be 16-byte aligned and N a multiple of 8");
+  GemmArgs p{};
+  p.A = A8; p.W = W8; p.C = C; p.bias = bias; p.gamma = nullptr; p.R = R;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = VG_ACT_NONE; p.vec_out = 1; p.a_op = a_op; p.gn = 4;
+  p.sa = a_scale; p.sw = w_scale;
+  if (out_dtype == VG_BF16) return launch_gemm_f8<bf16_t>(p, (hipStream_t)stream);
+  return launch_gemm_f8<float>(p, (hipStream_t)stream);
+}
 
 extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed) {
   if (M <= 16) return 0;

@@ -242,6 +242,35 @@ def quantize_fp8_rows(w):
     return q, scale
 
 
+def quantize_fp8(x):
+    """activations [M,K] (bf16 / fp32, rows contiguous) -> (uint8 [M,K] e4m3 codes, fp32 [M] row scales) on the device kernel."""
+    lib = _lib.load()
+    x2, M, ldx = _rows2d(x)
+    K = x2.shape[1]
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vg_quantize_fp8_rows(_p(x2), ldx, _p(q), K, _p(sc), M, K, _dt(x2), _stream()), "vg_quantize_fp8_rows")
+    return q, sc
+
+
+def linear_f8(q, qs, w8, ws, bias=None, residual=None, glu=False, out_dtype=torch.bfloat16):
+    """fp8 x fp8 GEMM with row scales on both operands (vg_gemm_f8): q uint8 [M,K] + qs [M]; w8 uint8 [N or 2N, K] + ws."""
+    lib = _lib.load()
+    M, K = q.shape
+    N = w8.shape[0] // 2 if glu else w8.shape[0]
+    assert q.dtype == torch.uint8 and w8.dtype == torch.uint8 and w8.shape[1] == K and q.is_contiguous() and w8.stride(1) == 1
+    y = torch.empty(M, N, dtype=out_dtype, device=q.device)
+    r2 = None
+    ldr = 0
+    if residual is not None:
+        r2, mr, ldr = _rows2d(residual)
+        assert r2.dtype == out_dtype and mr == M and r2.shape[1] == N
+    rc = lib.vg_gemm_f8(_p(q), K, _p(qs), _p(w8), w8.stride(0), _p(ws), _p(y), N, _p(_f32(bias)), _p(r2), ldr,
+                        M, N, K, _dt(y), 1 if glu else 0, _stream())
+    _lib.check(rc, "vg_gemm_f8")
+    return y
+
+
 def decode_gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, glu=False, out_dtype=None, out=None):
     """decode_gemv with fp8 (e4m3) weights + per-row scales (vg_decode_gemv_w8): x bf16 [1,K]; w8 uint8 [N or 2N, K]."""
     lib = _lib.load()

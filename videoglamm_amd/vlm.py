@@ -199,6 +199,9 @@ class LlamaDecoder:
         # fp8 (e4m3) weights with per-row scales in the decode step's MLP GEMVs and the lm_head (cfg["decode_weights"] == "fp8": the decode
         # side of BASELINE config C4's "fp8 LLM path"; bf16 activations, fp32 accumulation; the prefill GEMMs stay bf16)
         self.w8 = c.get("decode_weights") == "fp8"
+        # fp8 MFMA prefill GEMMs (cfg["prefill_gemm"] == "fp8"): vg_quantize_fp8_rows + vg_gemm_f8; the attention itself stays bf16
+        self.f8_prefill = c.get("prefill_gemm") == "fp8"
+        assert not self.f8_prefill or dt == torch.bfloat16, "the fp8 prefill pairs with a bf16 model"
         if self.w8:
             assert dt == torch.bfloat16 and self.D in (3072, 4096, 8192) and ffn in (8192, 14336), "fp8 decode weights: bf16 model, supported row lengths"
         self.fused_decode = (os.environ.get("VG_DECODE_FUSED", "1") != "0" and (self.H // self.Hkv) in (1, 2, 4, 8)
@@ -214,11 +217,17 @@ class LlamaDecoder:
         """decoder stack on x [S,D]; KV appended at pos (host value pos0, or *pos_dev when given)."""
         P, c = self.P, self.c
         S = x.shape[0]
+        f8 = self.f8_prefill and S > 16 and pos_dev is None
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
+            qkv_names = [l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"]
+            gu_names = [l + "mlp.gate_proj", l + "mlp.up_proj"]
             h = ops.rmsnorm(x, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
-            wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
-            qkv = ops.linear(h, wqkv)
+            if f8:      # fp8 MFMA prefill (config C4): activations quantised per token, weights per output channel, fp32 accumulation
+                qkv = ops.linear_f8(*ops.quantize_fp8(h), *P.fp8(qkv_names, stored=l + "self_attn.qkv_proj"))
+            else:
+                wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
+                qkv = ops.linear(h, wqkv)
             ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, pos0, pos_dev)
             q = qkv[:, : self.H * self.hd].view(1, S, self.H, self.hd)
             if pos_dev is None:
@@ -226,9 +235,15 @@ class LlamaDecoder:
                 o = ops.attention(q, self.kc[i][:n].unsqueeze(0), self.vc[i][:n].unsqueeze(0), self.hd ** -0.5, causal=True)
             else:
                 o = ops.attention_decode(q, self.kc[i], self.vc[i], pos_dev, self.hd ** -0.5)
+            if f8:
+                x = ops.linear_f8(*ops.quantize_fp8(o.view(S, self.D)), *P.fp8(l + "self_attn.o_proj"), residual=x)
+                h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
+                a = ops.linear_f8(*ops.quantize_fp8(h), *P.fp8(gu_names, stored=l + "mlp.gate_up_proj"), glu=True)
+                x = ops.linear_f8(*ops.quantize_fp8(a), *P.fp8(l + "mlp.down_proj"), residual=x)
+                continue
             x = ops.linear(o.view(S, self.D), P.w(l + "self_attn.o_proj"), residual=x)
             h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
-            wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
+            wgu, _ = P.fused(gu_names, stored=l + "mlp.gate_up_proj")
             # gate|up in one GEMM; for the decode step the SwiGLU runs in that GEMV's epilogue (ops.linear(glu=True))
             x = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
