@@ -364,7 +364,9 @@ class LlamaDecoder:
                 self.tok_dev.copy_(snap_tok)
                 self.pos_dev.copy_(snap_pos)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread-local capture mode: in multi-GPU runs the RCCL watchdog thread of torch.distributed polls events of
+                # finished collectives; under the default (global) mode such a call from another thread can invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._decode_step()
                 self.graph = g
                 self.tok_dev.copy_(snap_tok)
