@@ -6,7 +6,18 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import postproc as OP   # noqa: E402  (seeded test masks only)
+import numpy as np  # noqa: E402
+
+
+class OP:       # seeded blobby masks (box-filtered noise above a quantile); no reference logic involved
+    @staticmethod
+    def blobs(shape, seed, density=0.5, smooth=3):
+        rng = np.random.RandomState(seed)
+        x = rng.rand(*shape).astype(np.float32)
+        for ax in (-2, -1):
+            for _ in range(smooth):
+                x = (np.roll(x, 1, ax) + x + np.roll(x, -1, ax)) / 3
+        return x > np.quantile(x, 1 - density)
 from videoglamm_amd import ops      # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
