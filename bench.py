@@ -399,7 +399,7 @@ def main():
             res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 + decode_attn_kernel per layer)",
                                       "achieved": round(tbs * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tbs / 8.0, 4),
                                       "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
-    if rank == 0 and not args.no_cpu_baseline and not args.tiny:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:      # the CPU leg runs at N = 1 only
         res["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:
         print(json.dumps(res), flush=True)
