@@ -225,6 +225,12 @@ int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H
  * K in {3072, 4096, 8192, 14336}. */
 int vg_decode_gemv_w8(const void* x, const uint8_t* W8, int64_t ldw, const float* wscale, void* y, const float* norm_w,
                       float eps, const void* R, int N, int K, int glu, int out_dtype, vg_stream_t stream);
+/* vg_gemm for grids that leave most of the chip idle (few 128x128 tiles, long K): K is cut into ksplit slices that run as
+ * separate workgroups, the fp32 partial tiles go to `workspace` (>= ksplit*M*N floats) and one pass sums them and applies
+ * bias / act / gamma / residual.  Same result up to fp32 summation order.  M > 16, N % 8 == 0, no batch / GLU / window. */
+int vg_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                   const float* gamma, const void* R, int64_t ldr, int M, int N, int K, int in_dtype, int out_dtype, int act,
+                   int ksplit, float* workspace, int64_t ws_floats, vg_stream_t stream);
 /* fp8 (OCP e4m3) prefill path of BASELINE config C4.
  * vg_quantize_fp8_rows: q[m,:] = e4m3(x[m,:] / scale[m]) with scale[m] = absmax(x[m,:]) / 448 (round to nearest even, what
  * torch's .to(float8_e4m3fn) does); x bf16 / fp32 [M,K], K % 4 == 0.

@@ -415,3 +415,17 @@ def test_gemm_f8(cuda, M, N, K, glu, res):
     close(y, acc.to(torch.bfloat16), rtol=2e-2, atol=2e-2)
     if not glu and r is None:
         close(ops.linear_f8(q, qs, w8, ws, out_dtype=torch.float32), acc, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(213, 4096, 14336), (213, 4096, 4096), (2050, 1408, 6144), (100, 264, 4160), (425, 1024, 8192)])
+def test_gemm_splitk(cuda, dtype, M, N, K):
+    """few tiles, long K: ops.linear cuts K into slices (vg_gemm_splitk) — same result as the single-pass GEMM up to fp32
+    summation order, with bias / activation / LayerScale / residual applied by the reducing pass."""
+    from videoglamm_amd import ops
+    assert ops._splitk(M, N, K, 2 if dtype == torch.bfloat16 else 4) >= 2
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, gamma, res = rnd(N, seed=3), 1.0 + 0.1 * rnd(N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act=ops.ACT_GELU, gamma=gamma.to(cuda), residual=res.to(cuda))
+    close(y, ref.linear(x, w, bias, act=ref.ACT_GELU, gamma=gamma, residual=res), **tol(dtype, K))
+    close(ops.linear(x.to(cuda), w.to(cuda)), ref.linear(x, w), **tol(dtype, K))

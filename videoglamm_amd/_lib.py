@@ -24,6 +24,7 @@ def _sig(lib):
         "vg_last_error": ([], c_char_p),
         "vg_init": ([I], c_int),
         "vg_gemm": ([P, L, L, P, L, L, P, L, L, P, P, P, L, L, I, I, I, I, I, I, I, I, P], c_int),
+        "vg_gemm_splitk": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P, L, P], c_int),
         "vg_quantize_fp8_rows": ([P, L, P, L, P, L, I, I, P], c_int),
         "vg_gemm_f8": ([P, L, P, P, L, P, P, L, P, P, L, L, L, L, I, I, P], c_int),
         "vg_gemm_route": ([L, L, L, I, I, I], c_int),

@@ -25,6 +25,9 @@ struct GemmArgs {
   const void* zrow;   // K zeros: source of the padded window rows (the LDS-DMA cannot zero-fill)
   // fp8 operands (vg_gemm_f8): C = (A8 . W8^T) * sa[m] * sw[n] — one fp32 scale per A row (token) and per W row (output)
   const float* sa; const float* sw;
+  // split-K (vg_gemm_splitk, 128x128 LDS-DMA kernel only): blockIdx.z = K slice of kchunk elements; raw fp32 partial tiles
+  // go to part[z][M][N], a second kernel sums them and applies the epilogue
+  int ksplit, kchunk; float* part;
 };
 
 // window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
@@ -360,10 +363,11 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
   int bm, bn;
   gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+  const int bz = p.ksplit > 1 ? 0 : blockIdx.z;
+  const int kz = p.ksplit > 1 ? blockIdx.z : 0, k0 = kz * p.kchunk;
+  const int M = p.M, N = p.N, K = p.ksplit > 1 ? min(p.K - k0, p.kchunk) : p.K;      // K = this workgroup's slice
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA + k0;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW + k0;
 
   // this lane's 4 source rows per operand (wave w stages rows [32w, 32w+32) in 4 DMA instructions of 8 rows)
   const T* asrc[4];
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     }
   };
 
-  auto issue_piece = [&](int kt, int buf, int i) {      // A and W pieces i (of 4) of a stage
+  [[maybe_unused]] auto issue_piece = [&](int kt, int buf, int i) {      // A and W pieces i (of 4) of a stage (VG_GLDS_SPREAD)
     char* sa = smem + buf * 2 * TILEB + wave * 32 * 128;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
                                      (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
@@ -523,6 +527,21 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (p.ksplit > 1) {        // raw partial tile: lanes 0..31 of an accumulator register are 32 consecutive columns of one row
+    float* part = p.part + (int64_t)kz * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = bn * GBN + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = bm * GBM + wm * 64 + i * 32 + mfma32_row(r, h);
+          if (row < M && col < N) part[(int64_t)row * N + col] = acc[i][j][r];
+        }
+      }
+    return;
   }
   gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, p.a_op == 1 ? bn * 64 : bn * GBN + wn * 64, bz, wave, lane);
 }
@@ -1451,6 +1470,80 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
 // vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
 struct GemmWindow { int mode, H, W, ws; const void* zrow; };
 static thread_local GemmWindow g_window{0, 0, 0, 0, nullptr};
+
+// ---- split-K for grids that leave most of the chip idle (few 128x128 tiles, long K): K slices on blockIdx.z, fp32 partials,
+// one pass that sums them and applies the usual epilogue
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int ksplit, TO* C, int64_t ldc, const float* bias,
+                                                            const float* gamma, const TO* R, int64_t ldr, int M, int N, int act) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread = 8 consecutive columns of one row
+  const int ng = N / 8;
+  if (i >= (int64_t)M * ng) return;
+  const int m = (int)(i / ng), n0 = (int)(i % ng) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < ksplit; ++z) {
+    const f32x4_t* pp = (const f32x4_t*)(part + ((int64_t)z * M + m) * N + n0);
+    const f32x4_t a = pp[0], b = pp[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = vg_act(v[e] + (bias ? bias[n0 + e] : 0.f), act) * (gamma ? gamma[n0 + e] : 1.f);
+    if (R) v[e] += vg_elt<TO>::ld(R + (int64_t)m * ldr + n0 + e);
+    vg_elt<TO>::st(C + (int64_t)m * ldc + n0 + e, v[e]);
+  }
+}
+
+template <typename T, typename TO>
+static int launch_gemm_splitk(GemmArgs p, hipStream_t st) {
+  static bool attr = false;
+  const int lds128 = 4 * 128 * 144;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+    attr = true;
+  }
+  constexpr int BK = 128 / (int)sizeof(T);
+  const int nk = (p.K + BK - 1) / BK;
+  p.kchunk = ((nk + p.ksplit - 1) / p.ksplit) * BK;
+  p.ksplit = (p.K + p.kchunk - 1) / p.kchunk;         // no empty slices
+  const int nt = (p.N + GBN - 1) / GBN, mt = (p.M + GBM - 1) / GBM;
+  p.gn = nt < 4 ? nt : 4;
+  if (p.ksplit > 1) {
+    gemm_tile_glds_kernel<T, TO, true><<<dim3(nt, mt, p.ksplit), 256, lds128, st>>>(p);
+    const int64_t groups = (int64_t)p.M * (p.N / 8);
+    splitk_reduce_kernel<TO><<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(p.part, p.ksplit, (TO*)p.C, p.ldc, p.bias, p.gamma, (const TO*)p.R,
+                                                                             p.ldr, p.M, p.N, p.act);
+  } else {
+    gemm_tile_glds_kernel<T, TO, true><<<dim3(nt, mt, 1), 256, lds128, st>>>(p);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                              const float* gamma, const void* R, int64_t ldr, int M, int N, int K, int in_dtype, int out_dtype, int act,
+                              int ksplit, float* workspace, int64_t ws_floats, vg_stream_t stream) {
+  VG_CHECK(A && W && C && workspace, VG_ERR_ARG, "vg_gemm_splitk: null pointer");
+  VG_CHECK(M > 16 && N > 0 && K > 0 && N % 8 == 0 && ksplit >= 2 && ksplit <= 16, VG_ERR_ARG, "vg_gemm_splitk: bad shape M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
+  VG_CHECK(in_dtype == VG_BF16 || in_dtype == VG_F32, VG_ERR_ARG, "vg_gemm_splitk: bad in_dtype %d", in_dtype);
+  const int kpc = in_dtype == VG_BF16 ? 8 : 4, oes = out_dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK(K % kpc == 0 && lda % kpc == 0 && ldw % kpc == 0 && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)workspace) & 15) == 0, VG_ERR_ARG,
+           "vg_gemm_splitk: K / lda / ldw must be multiples of %d and A / W / workspace 16-byte aligned", kpc);
+  VG_CHECK((ldc * oes) % 16 == 0 && ((uintptr_t)C & 15) == 0, VG_ERR_ARG, "vg_gemm_splitk: C rows must be 16-byte aligned");
+  VG_CHECK(ws_floats >= (int64_t)ksplit * M * N, VG_ERR_ARG, "vg_gemm_splitk: workspace %lld < %lld floats", (long long)ws_floats, (long long)ksplit * M * N);
+  GemmArgs p{};
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.gamma = gamma; p.R = R;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.act = act; p.vec_out = 1; p.gn = 4;
+  p.ksplit = ksplit; p.part = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm_splitk<bf16_t, bf16_t>(p, st);
+  if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm_splitk<bf16_t, float>(p, st);
+  if (in_dtype == VG_F32 && out_dtype == VG_F32) return launch_gemm_splitk<float, float>(p, st);
+  vg_set_error("vg_gemm_splitk: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
+  return VG_ERR_UNSUPPORTED;
+}
 
 // ---- fp8 path (config C4's LLM prefill): per-row quantisation of the activations and the fp8 x fp8 tile GEMM
 template <typename T>

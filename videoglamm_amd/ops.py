@@ -56,6 +56,35 @@ def _rows2d(x):
     return x2, x2.shape[0], K
 
 
+def _splitk(M, N, K, es):
+    """K slices for a GEMM whose 128x128 tiles leave most of the 256 CUs (two workgroups each) idle while K is long:
+    measured r01 (tools/bench_gemm.py): the Llama down projection at M = 213 streams 117 MB of weights in 157 us on 64 tiles."""
+    import os
+    if M <= 16 or N % 8 or os.environ.get("VG_GEMM_SPLITK", "1") == "0":
+        return 0
+    tiles = -(-M // 128) * -(-N // 128)
+    steps = K * es // 128
+    if tiles > 192 or steps < 32:
+        return 0
+    ks = min(8, 512 // tiles, steps // 16)
+    return ks if ks >= 2 else 0
+
+
+def _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, out=None):
+    N, K = w.shape
+    y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
+    assert y.numel() == M * N
+    ws = torch.empty(ks * M * N, dtype=torch.float32, device=x.device)
+    r2, ldr = None, 0
+    if residual is not None:
+        r2, mr, ldr = _rows2d(residual)
+        assert mr == M and r2.shape[1] == N and r2.dtype == odt
+    rc = lib.vg_gemm_splitk(_p(x2), lda, _p(w), w.stride(0), _p(y), N, _p(_f32(bias)), _p(_f32(gamma)), _p(r2), ldr, M, N, K, _dt(x2), _dt(y),
+                            int(act), ks, _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "vg_gemm_splitk")
+    return y
+
+
 def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
     """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K).
     glu: w is [2N, K] = gate rows | up rows and y = silu(x @ gate^T) * (x @ up^T) — done in the GEMV epilogue for
@@ -70,6 +99,9 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     assert x2.shape[1] == K, (x.shape, w.shape)
     assert w.stride(1) == 1
     odt = out_dtype if out_dtype is not None else x.dtype
+    ks = _splitk(M, N, K, x2.element_size()) if (not glu and (out is None or (out.is_contiguous() and out.dtype == odt))) else 0
+    if ks:
+        return _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, out)
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
     o2, Mo, ldc = _rows2d(out)
