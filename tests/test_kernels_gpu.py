@@ -423,7 +423,7 @@ def test_gemm_splitk(cuda, dtype, M, N, K):
     """few tiles, long K: ops.linear cuts K into slices (vg_gemm_splitk) — same result as the single-pass GEMM up to fp32
     summation order, with bias / activation / LayerScale / residual applied by the reducing pass."""
     from videoglamm_amd import ops
-    assert ops._splitk(M, N, K, 2 if dtype == torch.bfloat16 else 4) >= 2
+    assert ops._splitk(M, N, K, 2 if dtype == torch.bfloat16 else 4) >= 2      # every case here is routed to split-K
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
     bias, gamma, res = rnd(N, seed=3), 1.0 + 0.1 * rnd(N, seed=4), rnd(M, N, dtype=dtype, seed=5)
     y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act=ops.ACT_GELU, gamma=gamma.to(cuda), residual=res.to(cuda))

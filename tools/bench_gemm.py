@@ -20,6 +20,7 @@ shapes = [("llm qkv/o", 1697, 4096, 4096), ("llm gate|up", 1697, 28672, 4096), (
           ("hiera s4 fc1", 8192, 4608, 1152), ("square 4k", 4096, 4096, 4096), ("square 8k", 8192, 8192, 8192),
           ("sp8 qkv", 213, 6144, 4096), ("sp8 o", 213, 4096, 4096), ("sp8 gate|up", 213, 28672, 4096), ("sp8 down", 213, 4096, 14336),
           ("sp4 gate|up", 425, 28672, 4096), ("sp4 down", 425, 4096, 14336),
+          ("sp2 o", 849, 4096, 4096), ("sp2 down", 849, 4096, 14336), ("sp2 qkv", 849, 6144, 4096),
           ("c2 llm qkv", 3361, 6144, 4096), ("c2 llm o", 3361, 4096, 4096), ("c2 llm gate|up", 3361, 28672, 4096), ("c2 llm down", 3361, 4096, 14336)]
 if os.environ.get("VG_BENCH_SHAPES"):
     shapes = [s for s in shapes if any(t in s[0] for t in os.environ["VG_BENCH_SHAPES"].split(","))]

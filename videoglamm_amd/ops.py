@@ -64,7 +64,7 @@ def _splitk(M, N, K, es):
         return 0
     tiles = -(-M // 128) * -(-N // 128)
     steps = K * es // 128
-    if tiles > 192 or steps < 32:
+    if tiles > int(os.environ.get("VG_GEMM_SPLITK_TILES", "256")) or steps < 32:
         return 0
     ks = min(8, 512 // tiles, steps // 16)
     return ks if ks >= 2 else 0
