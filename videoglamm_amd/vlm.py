@@ -213,8 +213,10 @@ class LlamaDecoder:
         self.pos = 0
         self.pos_dev.zero_()
 
-    def _layers(self, x, pos0, pos_dev):
-        """decoder stack on x [S,D]; KV appended at pos (host value pos0, or *pos_dev when given)."""
+    def _layers(self, x, pos0, pos_dev, kv_hook=None):
+        """decoder stack on x [S,D]; KV appended at pos (host value pos0, or *pos_dev when given).
+        kv_hook(i): called after layer i wrote its K/V rows and before its attention (the sequence-parallel prefill
+        all-gathers the other ranks' rows there)."""
         P, c = self.P, self.c
         S = x.shape[0]
         f8 = self.f8_prefill and S > 16 and pos_dev is None
@@ -229,6 +231,8 @@ class LlamaDecoder:
                 wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
                 qkv = ops.linear(h, wqkv)
             ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, pos0, pos_dev)
+            if kv_hook is not None:
+                kv_hook(i)
             q = qkv[:, : self.H * self.hd].view(1, S, self.H, self.hd)
             if pos_dev is None:
                 n = pos0 + S
@@ -294,41 +298,33 @@ class LlamaDecoder:
         state — what the replicated decode continues from — is broadcast by its owner."""
         import torch.distributed as dist
 
-        P, c = self.P, self.c
+        c = self.c
         S, W, r = x.shape[0], comm.world, comm.rank
         m = -(-S // W)
         a = min(r * m, S)
         n = max(min(m, S - a), 0)                       # this rank's rows [a, a+n)
         assert self.pos == 0 and W * m <= self.max_len
-        xl = x[a:a + n].contiguous()
         send = torch.zeros(m, 2, self.Hkv, self.hd, dtype=x.dtype, device=x.device)
         recv = torch.empty(W * m, 2, self.Hkv, self.hd, dtype=x.dtype, device=x.device)
-        for i in range(c["num_layers"]):
-            l = f"model.layers.{i}."
+
+        def gather(i):
             if n:
-                h = ops.rmsnorm(xl, P.f32(l + "input_layernorm.weight"), c["rms_eps"])
-                wqkv, _ = P.fused([l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"], stored=l + "self_attn.qkv_proj")
-                qkv = ops.linear(h, wqkv)
-                ops.rope_kv_append_(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, a, None)
                 send[:n, 0].copy_(self.kc[i][a:a + n])
                 send[:n, 1].copy_(self.vc[i][a:a + n])
             dist.all_gather(list(recv.chunk(W)), send, group=comm.group)
             self.kc[i][:W * m].copy_(recv[:, 0])        # rows >= S are padding: never read, overwritten by the decode appends
             self.vc[i][:W * m].copy_(recv[:, 1])
-            if n:
-                q = qkv[:, : self.H * self.hd].view(1, n, self.H, self.hd)
-                o = ops.attention(q, self.kc[i][:a + n].unsqueeze(0), self.vc[i][:a + n].unsqueeze(0), self.hd ** -0.5, causal=True)
-                xl = ops.linear(o.view(n, self.D), P.w(l + "self_attn.o_proj"), residual=xl)
-                h = ops.rmsnorm(xl, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
-                wgu, _ = P.fused([l + "mlp.gate_proj", l + "mlp.up_proj"], stored=l + "mlp.gate_up_proj")
-                xl = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=xl)
+
         last = torch.zeros(1, self.D, dtype=x.dtype, device=x.device)
         owner = (S - 1) // m
         if n:
-            hl = ops.rmsnorm(xl, P.f32("model.norm.weight"), c["rms_eps"])
+            hl = self._layers(x[a:a + n].contiguous(), a, None, kv_hook=gather)      # the same stack as forward(), bf16 or fp8 GEMMs
             self.hid_all[a:a + n].copy_(hl)
             if r == owner:
                 last.copy_(hl[-1:])
+        else:
+            for i in range(c["num_layers"]):      # a rank without rows still takes part in every gather
+                gather(i)
         dist.broadcast(last, src=dist.get_global_rank(comm.group, owner) if comm.group is not None else owner, group=comm.group)
         self.hid_all[S - 1:S].copy_(last)
         self.pos = S
