@@ -118,7 +118,7 @@ def test_decode_gemv(cuda, dtype, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("H,Hkv,D,max_len", [(8, 2, 64, 640), (32, 8, 128, 2048), (4, 2, 16, 128), (4, 4, 96, 256), (8, 1, 32, 192)])
+@pytest.mark.parametrize("H,Hkv,D,max_len", [(8, 2, 64, 640), (32, 8, 128, 2048), (4, 2, 16, 128), (4, 4, 96, 256), (8, 1, 32, 192), (32, 32, 96, 2048)])
 def test_decode_attention(cuda, dtype, H, Hkv, D, max_len):
     """fused RoPE + KV append + split attention + last-workgroup merge vs rope_kv_append + attention of the fp32
     statement; replayed at several positions (split boundaries, first and last slot) on ONE workspace."""

@@ -702,6 +702,7 @@ static void launch_decode_attn_gd(const DecAttnArgs& p, dim3 grid, size_t lds, h
 template <typename T, int G>
 static void launch_decode_attn_g(const DecAttnArgs& p, dim3 grid, size_t lds, hipStream_t st) {
   if (p.D == 128) launch_decode_attn_gd<T, G, 128>(p, grid, lds, st);
+  else if (p.D == 96) launch_decode_attn_gd<T, G, 96>(p, grid, lds, st);      // Phi-3-mini: the released checkpoint's LLM
   else launch_decode_attn_gd<T, G, 0>(p, grid, lds, st);
 }
 
