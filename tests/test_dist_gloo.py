@@ -63,6 +63,7 @@ def _worker(rank, world, port, q):
     d0 = LlamaDecoder(Params(lsd, "cpu", torch.float32), lc, 64, use_graph=False)
     ref_h = d0.forward(xs)
     ok_sp = bool(torch.allclose(last, ref_h[-1:], rtol=1e-5, atol=1e-5)) and d1.pos == 45 and int(d1.pos_dev[0]) == 45
+    ok_sp = ok_sp and bool(torch.allclose(d1.hid_all[:45], ref_h, rtol=1e-5, atol=1e-5))        # every prompt row on every rank
     ok_sp = ok_sp and all(bool(torch.allclose(d1.kc[i][:45], d0.kc[i][:45], rtol=1e-5, atol=1e-5)) and
                           bool(torch.allclose(d1.vc[i][:45], d0.vc[i][:45], rtol=1e-5, atol=1e-5)) for i in range(lc["num_layers"]))
     step1, step0 = d1.forward(xs[:1] * 0.5), d0.forward(xs[:1] * 0.5)          # one more row through both caches

@@ -294,8 +294,8 @@ class LlamaDecoder:
         rank r runs rows [r*m, (r+1)*m) (m = ceil(S/world)) through every layer; per layer the new K/V rows are all-gathered
         straight into every rank's KV cache (S/world x 2 x Hkv x hd elements per rank: ~0.9 MB at S = 1697, world = 8) and a
         row attends causally to the keys [0, its position].  The projections of a row do not depend on the other rows, so the
-        prefill costs 1/world per rank (plus one weight pass) instead of a whole one on every rank; the last row's final-norm
-        state — what the replicated decode continues from — is broadcast by its owner."""
+        prefill costs 1/world per rank (plus one weight pass) instead of a whole one on every rank; the final-norm rows are
+        all-gathered at the end (the replicated decode continues from the last one)."""
         import torch.distributed as dist
 
         c = self.c
@@ -315,18 +315,18 @@ class LlamaDecoder:
             self.kc[i][:W * m].copy_(recv[:, 0])        # rows >= S are padding: never read, overwritten by the decode appends
             self.vc[i][:W * m].copy_(recv[:, 1])
 
-        last = torch.zeros(1, self.D, dtype=x.dtype, device=x.device)
-        owner = (S - 1) // m
+        hsend = torch.zeros(m, self.D, dtype=x.dtype, device=x.device)
         if n:
-            hl = self._layers(x[a:a + n].contiguous(), a, None, kv_hook=gather)      # the same stack as forward(), bf16 or fp8 GEMMs
-            self.hid_all[a:a + n].copy_(hl)
-            if r == owner:
-                last.copy_(hl[-1:])
+            hsend[:n].copy_(self._layers(x[a:a + n].contiguous(), a, None, kv_hook=gather))   # the same stack as forward(), bf16 or fp8 GEMMs
         else:
             for i in range(c["num_layers"]):      # a rank without rows still takes part in every gather
                 gather(i)
-        dist.broadcast(last, src=dist.get_global_rank(comm.group, owner) if comm.group is not None else owner, group=comm.group)
-        self.hid_all[S - 1:S].copy_(last)
+        # every rank gets every final-norm row: the decode continues from the last one, and [SEG] tokens that sit INSIDE the prompt
+        # (multi-turn) take their hidden state from prompt rows (S x D elements once per clip: 14 MB at S = 1697)
+        hrecv = torch.empty(W * m, self.D, dtype=x.dtype, device=x.device)
+        dist.all_gather(list(hrecv.chunk(W)), hsend, group=comm.group)
+        self.hid_all[:W * m].copy_(hrecv)
+        last = self.hid_all[S - 1:S].clone()
         self.pos = S
         self.pos_dev.fill_(S)
         return last
