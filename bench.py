@@ -185,8 +185,10 @@ def meter_decode_gemv(model, ops, reps=3):
 def cpu_baseline(cfg, args):
     """Reference algorithm (oracle/, CPU fp32 restatement pinned to the reference) on the host cores, bounded
     sample of the same workload: ONE frame through every per-frame stage at full architecture size
-    (Hiera-L+FPN+mask decoder, CLIP-L/336, 1/4 of an InternVideo2-1B 4-frame chunk).  The LLM is excluded
-    (8B fp32 parameters = 32 GB of host RAM), so the figure is an UPPER bound of the CPU path's frames/sec."""
+    (Hiera-L+FPN+mask decoder, CLIP-L/336, 1/4 of an InternVideo2-1B 4-frame chunk) and ONE decoder layer of the LLM on
+    the whole prompt (all 32 layers in fp32 would need 32 GB of host RAM and minutes).  The clip time is assembled from
+    the samples under the oracle's own schedule — vision once, the LM re-forwarded over the whole sequence for every
+    generated token (the reference runs generate(use_cache=False), R/model/VideoGLaMM.py:610-626)."""
     from oracle import sam2 as osam, seeded, vlm as ovlm
     from videoglamm_amd import synth
 
@@ -219,9 +221,25 @@ def cpu_baseline(cfg, args):
                      torch.randn(1, 4, 3, cfg["iv2"]["img_size"], cfg["iv2"]["img_size"]))
     t_iv2 = (time.time() - t0) / 4.0
     t_total += t_iv2
-    return dict(value=round(1.0 / t_total, 4), unit="frames/sec", cores=cores, kind="port",
-                sample=f"1 frame through Hiera-L+FPN+mask decoder ({t_sam:.1f}s), CLIP-L/336 ({t_clip:.1f}s), InternVideo2-1B chunk/4 "
-                       f"({t_iv2:.1f}s), fp32 oracle; LLM (Llama-3-8B) excluded -> upper bound of the CPU path")
+    del sdi
+    # one LLM decoder layer on the S prompt rows
+    c = cfg["llm"]
+    pl = "model."
+    sdl = seeded.seeded_state_dict({k: v for k, v in vman.items() if k.startswith("model.layers.0.") or k == "model.norm.weight"}, 0)
+    S_llm = 208 * args.te + 33
+    x = torch.randn(S_llm, c["hidden"], generator=torch.Generator().manual_seed(3)) * 0.1
+    t0 = time.time()
+    ovlm.llama_forward(sdl, pl, dict(c, num_layers=1), x)
+    t_layer = time.time() - t0
+    del sdl
+    T, G, L = args.frames_per_gpu, args.max_new_tokens, c["num_layers"]
+    t_vision = T * t_sam + args.te * t_clip + args.te * t_iv2
+    t_llm = (G + 1) * L * t_layer                     # G + 1 full re-forwards of the sequence, L layers each
+    return dict(value=round(T / (t_vision + t_llm), 5), unit="frames/sec", cores=cores, kind="port",
+                sample=f"fp32 oracle at full architecture size: 1 frame through Hiera-L+FPN+mask decoder ({t_sam:.1f}s), 1 frame through CLIP-L/336 "
+                       f"({t_clip:.1f}s), InternVideo2-1B chunk/4 ({t_iv2:.1f}s), 1 of {L} LLM layers on the {S_llm}-row prompt ({t_layer:.2f}s); clip time "
+                       f"= {T} x SAM + {args.te} x (CLIP + IV2) + {G + 1} re-forwards x {L} layers (the oracle restates generate(use_cache=False)) "
+                       f"= {t_vision:.0f}s vision + {t_llm:.0f}s LLM; vision alone: {T / t_vision:.4f} frames/sec")
 
 
 def main():
