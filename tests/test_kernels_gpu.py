@@ -419,10 +419,12 @@ def test_gemm_f8(cuda, M, N, K, glu, res):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(213, 4096, 14336), (213, 4096, 4096), (2050, 1408, 6144), (100, 264, 4160), (425, 1024, 8192)])
-def test_gemm_splitk(cuda, dtype, M, N, K):
+def test_gemm_splitk(cuda, dtype, M, N, K, monkeypatch):
     """few tiles, long K: ops.linear cuts K into slices (vg_gemm_splitk) — same result as the single-pass GEMM up to fp32
     summation order, with bias / activation / LayerScale / residual applied by the reducing pass."""
     from videoglamm_amd import ops
+    monkeypatch.setenv("VG_GEMM_SPLITK", "1")
+    monkeypatch.delenv("VG_GEMM_SPLITK_TILES", raising=False)
     assert ops._splitk(M, N, K, 2 if dtype == torch.bfloat16 else 4) >= 2      # every case here is routed to split-K
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
     bias, gamma, res = rnd(N, seed=3), 1.0 + 0.1 * rnd(N, seed=4), rnd(M, N, dtype=dtype, seed=5)
