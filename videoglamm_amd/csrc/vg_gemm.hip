@@ -1222,6 +1222,216 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_w128_kernel(GemmArgs p) {
   }
 }
 
+// The same 256x256 tile on EIGHT waves (2 in M x 4 in N, 128x64 each: 128 accumulator registers, two waves per SIMD): while
+// one wave of a SIMD waits for the next stage's DMAs or sits in the barrier the other one keeps the matrix pipe busy — the
+// four-wave kernel spends 21 % of its wave time there with nobody to cover.  Default since r01 (+1...8 % on the LLM shapes);
+// VG_GEMM_W128=5 (shape rule) / 2 (forced) select the four-wave kernel.
+template <typename T, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int TA = 256 * 128, STAGE = 2 * TA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int bm, bn;
+  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
+  const int bz = blockIdx.z;
+  const int M = p.M, N = p.N, K = p.K;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+
+  // wave w stages rows [32w, 32w+32) of each operand: 4 DMA instructions of 8 rows (8 lanes per 128-byte row) each
+  const T* src[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * 256 + row, gn = bn * 256 + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
+      const int o = bn * 128 + (row & 127);
+      gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
+    }
+    src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+    src[4 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
+  }
+  auto dma = [&](int kt, int buf, int i) {      // instruction i of stage kt: 0..3 A pieces, 4..7 W pieces
+    char* dst = smem + buf * STAGE + (i >> 2) * TA + wave * 32 * 128 + (i & 3) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ra = wm * 128 + l31, rb = wn * 64 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r + 32 i share the key
+  const int nk = K / BK;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  u32x4_t fa[2][4], fb[2][2];          // fragment sets of two consecutive MFMA groups
+  auto frag = [&](int buf, int g, int x) -> u32x4_t {       // x: 0..3 A row tiles, 4..5 W row tiles
+    const int c = 2 * g + h;
+    if (x < 4) return *(const u32x4_t*)(smem + buf * STAGE + (ra + x * 32) * 128 + ((c ^ swa) << 4));
+    return *(const u32x4_t*)(smem + buf * STAGE + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
+  };
+#pragma unroll
+  for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(0, 0, x);
+
+  // one K step = 4 groups x 4 slots; a slot = 2 MFMAs, then one or two fragment reads of the next group (6 per group), then
+  // (first three groups, while a next stage exists) at most one DMA instruction of the next stage (3 + 3 + 2)
+  auto step = [&](int kt, int buf, bool has_next) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g == 0) __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        MmaOp<T>::run(fa[cur][sl], fb[cur][0], acc[sl][0]);
+        MmaOp<T>::run(fa[cur][sl], fb[cur][1], acc[sl][1]);
+        if (g < 3) {
+          // reads 0..5 of the next group over the four slots: 2, 2, 1, 1
+          const int r0 = sl < 2 ? 2 * sl : 2 + sl, r1 = sl < 2 ? r0 + 2 : r0 + 1;
+#pragma unroll
+          for (int x = r0; x < r1; ++x) {
+            const u32x4_t v = frag(buf, g + 1, x);
+            if (x < 4) fa[nxt][x] = v; else fb[nxt][x - 4] = v;
+          }
+        }
+        const int di = g * 3 + sl;                          // 3 + 3 + 2 DMA instructions over groups 0..2
+        if (has_next && g < 3 && sl < (g < 2 ? 3 : 2)) dma(kt + 1, buf ^ 1, di);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g < 3) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int buf = kt & 1;
+    step(kt, buf, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  step(kt, kt & 1, false);
+  __syncthreads();   // the epilogue reuses the ring as fp32 staging: 8 waves x 32 rows x 68 floats
+
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 68;
+  float* ws = (float*)smem + wave * 32 * ES;
+  const int cg = lane & 7, rsub = lane >> 3;
+  const int n0 = (p.a_op == 1 ? bn * 128 + (wn & 1) * 64 : bn * 256 + wn * 64) + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    if (p.a_op == 1) {
+      // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows
+      const float* wg = (const float*)smem + (wm * 4 + (wn & 1)) * 32 * ES;
+      const float* wu = wg + 2 * 32 * ES;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const int ml = (wn >> 1) * 16 + pass * 8 + rsub;
+        const int m = bm * 256 + wm * 128 + i * 32 + ml;
+        if (m >= M || n0 >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g = wg[ml * ES + cg * 8 + e] + bv[e];
+          float u = wu[ml * ES + cg * 8 + e] + ((p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f);
+          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+          g = g / (1.0f + __expf(-g));
+          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
+          v[e] = g * u;
+        }
+        TO* cp = C + (int64_t)m * p.ldc + n0;
+        if (n0 + 8 <= N) {
+          if constexpr (sizeof(TO) == 2) {
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+            *(u32x4_t*)cp = o;
+          } else {
+            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *(f32x4_t*)cp = o0;
+            *(f32x4_t*)(cp + 4) = o1;
+          }
+        } else {
+          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+        }
+      }
+      continue;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ml = pass * 8 + rsub;
+      const int m = bm * 256 + wm * 128 + i * 32 + ml;
+      if (m >= M || n0 >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      TO* cp = C + (int64_t)m * p.ldc + n0;
+      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N && p.vec_out) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+  }
+}
+
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& a, const u32x4_t& b);
 template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& a, const u32x4_t& b) {
   float s = 0.f;
@@ -1371,7 +1581,7 @@ static bool route_w128(int64_t M, int64_t N, int64_t K, int es, int a_op, int wm
   if (ntw_out) { *ntw_out = ntw; *mtw_out = mtw; }
   const int w = knob_w128();
   if (!w || es != 2 || route_small_k(K, es, a_op) || wmode || K % (128 / es) != 0 || !vec_out) return false;
-  if (w == 2) return true;
+  if (w == 2 || w == 4) return true;       // 2 / 4: force the 4-wave / 8-wave kernel on every eligible shape (3: 8-wave, shape rule)
   const int64_t t256 = (int64_t)ntw * mtw * batch;
   const double useful = (double)M * N / ((double)mtw * 256 * ntw * (a_op == 1 ? 128 : 256));
   const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
@@ -1432,6 +1642,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     static bool w128_attr = false;
     if (!w128_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_w128_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_w128x8_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
       w128_attr = true;
     }
     int ntw, mtw;
@@ -1439,7 +1650,8 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     if (big) {
       dim3 gridw(ntw, mtw, batch);
       q.gn = pick_gn(mtw, ntw);
-      gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
+      if (knob_w128() != 2 && knob_w128() != 5) gemm_tile_w128x8_kernel<T, TO><<<gridw, 512, 2 * 2 * 256 * 128, st>>>(q);   // 2 / 5: the 4-wave kernel
+      else gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
     } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
       gemm_tile_s128_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (small_k) {
