@@ -382,7 +382,7 @@ def main():
         # one object per tile kernel; "roofline" is the one with the most GPU time in the step (gemm_tile_glds_kernel on C1)
         labels = {"glds": ("gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)", "r01_pmc_gemm_glds.json"),
                   "k64b": ("gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)", "r01_pmc_gemm_k64b.json"),
-                  "w128": ("gemm_tile_w128_kernel<bf16> (256x256 tile, 128x128 per wave: grids that fill the chip)", "r01_pmc_gemm_w128.json"),
+                  "w128": ("gemm_tile_w128x8_kernel<bf16> (256x256 tile, 8 waves of 128x64: grids that fill the chip)", "r01_pmc_gemm_w128.json"),
                   "s128": ("gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)", "r01_pmc_gemm_s128.json")}
         roofs = {k: roof(k, *labels[k]) for k in labels}
         roofs = {"gemm_" + k: v for k, v in roofs.items() if v["launches"]}
