@@ -44,3 +44,26 @@ def test_product_never_imports_the_oracle():
     for f in os.listdir(pkg):
         if f.endswith(".py") and f != "smoke.py":
             assert "oracle" not in open(os.path.join(pkg, f)).read().replace("oracle/seeded.py", ""), f
+
+
+def test_gemm_routing_rules():
+    """vg_gemm_route launches nothing: the shape rules of the GEMM launcher on the C1 / C2 shapes."""
+    import __graft_entry__ as g
+
+    g.build()
+    from videoglamm_amd import _lib, ops
+
+    lib = _lib.load()
+    route = lambda M, N, K, glu=0, win=0: lib.vg_gemm_route(M, N, K, 1, glu, win)      # bf16
+    assert route(1, 4096, 4096) == 0                       # decode row: skinny kernel
+    assert route(1697, 4096, 4096) == 1                    # C1 o_proj: 112 tiles of 256^2 do not fill the chip -> 128x128 kernel
+    assert route(1697, 14336, 4096, glu=1) == 3            # C1 gate|up + SwiGLU: 256x256 kernel
+    assert route(3361, 4096, 14336) == 3                   # C2 down
+    assert route(32768, 1728, 576) == 4                    # Hiera stage 3 qkv: single-stage whole-line kernel
+    assert route(32768, 1728, 576, win=1) == 4
+    assert route(524288, 432, 144) == 2                    # Hiera stage 1: 64-byte-step kernel
+    assert route(32768, 576, 2304) == 1                    # Hiera stage 3 fc2: N = 576 wastes a quarter of a 256-wide tile
+    assert lib.vg_gemm_route(1697, 4096, 4096, 0, 0, 0) == 1   # fp32 parity mode never takes the bf16-only kernels
+    # split-K (ops.linear): under-filled grids with a long K only
+    assert ops._splitk(213, 4096, 14336, 2) >= 2 and ops._splitk(2050, 1408, 6144, 2) == 2
+    assert ops._splitk(1697, 4096, 4096, 2) == 0 and ops._splitk(213, 4096, 576, 2) == 0 and ops._splitk(8, 4096, 14336, 2) == 0
