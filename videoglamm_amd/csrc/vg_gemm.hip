@@ -1,13 +1,17 @@
-// vg_gemm: C = ((act(A @ W^T + bias)) * gamma) + R      (see include/vg_kernels.h)
+// vg_gemm: C = ((act(A @ W^T + bias)) * gamma) + R      (see include/vg_kernels.h; DESIGN.md section 5 has the measurements)
 //
-// Two kernels:
-//   gemm_tile_kernel   128x128 output tile / 256-thread workgroup (4 waves as 2x2, each 64x64 =
-//                      2x2 MFMA 32x32 tiles), K stepped 128 bytes at a time (64 bf16 / 32 f32),
-//                      global -> registers -> LDS double buffer (one barrier per K step), LDS rows
-//                      padded to 144 B so the ds_read_b128 fragment reads are bank-conflict free.
-//                      bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA).
-//   gemm_skinny_kernel M <= 16 rows (LLM decode GEMV, mask-decoder token MLPs): one wave per output
-//                      column streams its W row once with 16-byte loads; HBM-bound by construction.
+// Kernels (all bf16: v_mfma_f32_32x32x16_bf16; fp32 parity mode: v_mfma_f32_32x32x2_f32, exact fp32 FMA):
+//   gemm_tile_glds_kernel    128x128 tile, 4 waves, 128-byte K steps staged by LDS-DMA into swizzled unpadded rows, two stages,
+//                            two workgroups per CU.  Carries the window gather/scatter (vg_gemm_window), the SwiGLU epilogue,
+//                            split-K (vg_gemm_splitk) and, instantiated on bytes, the fp8 x fp8 GEMM (vg_gemm_f8).
+//   gemm_tile_w128x8_kernel  256x256 tile, 8 waves of 128x64 (two per SIMD), whole-line DMAs issued between MFMAs: grids that fill the
+//   gemm_tile_w128_kernel    chip (the 4-wave variant, 128x128 per wave, is the A/B twin).
+//   gemm_tile_s128_kernel    128x128 tile, ONE 128-byte-row stage, four workgroups per CU: 1024 <= K*es <= 3072 bytes.
+//   gemm_tile_k64b_kernel    128x128 tile, 64-byte K steps, four workgroups per CU: K*es < 1024 bytes.
+//   gemm_tile_kernel / gemm_tile_ring_kernel   register-staged and 3-stage-ring variants kept as measured A/B knobs.
+//   gemm_skinny_kernel       M <= 16 rows (LLM decode lm_head, mask-decoder token MLPs): one wave per output column streams its
+//                            W row once with 16-byte loads; HBM-bound by construction.
+// Routing: launch_gemm / route_* below (and vg_gemm_route for the bench).
 #include "vg_common.h"
 #include <stdlib.h>
 
