@@ -191,5 +191,9 @@ class VideoGLaMMForCausalLM:
         if self.comm is not None:
             emb = self.comm.sync_seg_embeddings(emb)
             feats = self.comm.gather_frame_feats(feats, sam.shape[0])
-        logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
+        if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "0") == "1":
+            # the propagation replayed from a HIP graph: same results, measured neutral (r01: 201.05 vs 200.51 ms per clip), off by default
+            logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)
+        else:
+            logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
         return out_ids, [self._segments(self._binarize(logits).cpu())]
