@@ -9,11 +9,15 @@ One "step" = one full pass of VideoGLaMMForCausalLM.inference() over one synthet
 device-resident preprocessed tensors + input_ids to (token ids on host, thresholded masks on host):
 dual vision encoders -> V-L adapters -> Llama-3-8B prefill + 32 greedy decode steps with one [SEG]
 -> L-V adapter -> SAM2-L (Hiera + FPN + mask decoder) over every frame.
-Workload at N=1 = BASELINE config C1 (8-frame 512^2-source clip -> 8 x 1024^2 SAM frames, Te=8 encoder
-frames, Llama-3-8B bf16, SAM2-L, one [SEG] object).  N>1: weak scaling, 8 SAM frames per rank (clip of
-8N frames, frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding and of the masks).
+Workload at N=1 = BASELINE config C2, the configuration BASELINE.json's metric is quoted on (32-frame 1024^2 clip
+-> 32 x 1024^2 SAM frames, masks returned at 1024^2, Te=16 encoder frames -> 3361-row prompt, Llama-3-8B bf16,
+InternVideo2-1B, CLIP-L/336, SAM2-L, one [SEG] object).  N>1: weak scaling, 32 SAM frames per rank (clip of 32N frames,
+frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding and of the masks).
 Weights are random-init of the exact architectures (no network / no public Llama VideoGLaMM checkpoint).
+The line is self-checking ("quality"): after the timed region the same clip is re-run ONCE in fp32 parity mode on the
+GPU (same bf16-rounded weights, teacher-forced to the bf16 run's ids) and the bf16 masks / argmaxes are compared with it.
 """
+import zlib
 import argparse
 import json
 import os
@@ -33,9 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--branch", default="framewise", choices=["framewise", "video"],
                     help="framewise = the reference's default path (chat.py without --use_sam2_video_branch)")
-    ap.add_argument("--frames-per-gpu", type=int, default=8)
-    ap.add_argument("--te", type=int, default=8, help="encoder frames (NUM_FRAMES)")
-    ap.add_argument("--src", type=int, default=512, help="source (output mask) resolution")
+    ap.add_argument("--frames-per-gpu", type=int, default=32)
+    ap.add_argument("--te", type=int, default=16, help="encoder frames (NUM_FRAMES; the reference's default 16)")
+    ap.add_argument("--src", type=int, default=1024, help="source (output mask) resolution")
     ap.add_argument("--max-new-tokens", type=int, default=32)
     ap.add_argument("--objects", type=int, default=1, help="[SEG] objects (multi-object GCG: 8)")
     ap.add_argument("--prefill", default="bf16", choices=["bf16", "fp8"],
@@ -46,8 +50,9 @@ def parse():
                          "LLM path; NOT the bf16 headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-quality", action="store_true", help="skip the fp32 parity-mode re-run that fills the \"quality\" object")
     ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
-                    help="llama3-8b = BASELINE config C1 (default); phi3-mini = the released checkpoint's LLM")
+                    help="llama3-8b = BASELINE configs C1-C3 (default); phi3-mini = the released checkpoint's LLM")
     ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
     return ap.parse_args()
 
@@ -71,6 +76,7 @@ class GemmMeter:
 
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.linear, []
+        self.scope = None          # "mask_decoder" while SAM2.mask_decoder runs (the north star's mask-decoder GEMMs)
 
     @staticmethod
     def kernel_of(M, N, K, glu, windowed):
@@ -90,7 +96,7 @@ class GemmMeter:
             N, K = w.shape[0] // (2 if k.get("glu") else 1), w.shape[1]
             es = x.element_size()
             nbytes = (M * K + w.shape[0] * K) * es + M * N * y.element_size() * (2 if k.get("residual") is not None else 1)
-            self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes, self.kernel_of(M, N, K, k.get("glu"), False)))
+            self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes, self.kernel_of(M, N, K, k.get("glu"), False), self.scope))
             return y
         def timed_window(x, w, bias, B, H, W, ws, scatter, **k):      # Hiera's window-folded projections: same kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,23 +106,91 @@ class GemmMeter:
             M = B * (-(-H // ws)) * (-(-W // ws)) * ws * ws
             N, K = w.shape
             nbytes = (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size() * (2 if k.get("residual") is not None else 1)
-            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, True)))
+            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, True), self.scope))
             return y
+        from videoglamm_amd import sam2 as _sam2
+        meter = self
+        self.orig_md = _sam2.SAM2.mask_decoder
+
+        def scoped_md(obj, *a, **k):
+            meter.scope = "mask_decoder"
+            try:
+                return meter.orig_md(obj, *a, **k)
+            finally:
+                meter.scope = None
+        _sam2.SAM2.mask_decoder = scoped_md
         self.ops.linear = timed
         self.orig_window = self.ops.linear_window
         self.ops.linear_window = timed_window
         return self
 
     def __exit__(self, *exc):
+        from videoglamm_amd import sam2 as _sam2
+        _sam2.SAM2.mask_decoder = self.orig_md
         self.ops.linear = self.orig
         self.ops.linear_window = self.orig_window
 
-    def summary(self, kernel):
+    def summary(self, kernel=None, scope=None):
         torch.cuda.synchronize()
-        rec = [r for r in self.rec if r[4] == kernel]
+        rec = [r for r in self.rec if (kernel is None or r[4] == kernel) and (scope is None or r[5] == scope)]
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         return flops, ms, len(rec), sum(r[3] for r in rec)
+
+
+class AttnMeter:
+    """Per-launch HIP events around ops.attention / ops.attention_windows (attn_kernel<bf16, DP, 64, 4>, one record class per
+    head-dim instantiation DP).  Algorithmic flops = 4 * B * H * Sq * Skv * D (QK^T and PV), halved under the causal mask,
+    Skv = the window length for Hiera's packed windows."""
+
+    def __init__(self, ops):
+        self.ops, self.rec = ops, []
+
+    @staticmethod
+    def dp(D):
+        return 32 if D <= 32 else 64 if D <= 64 else 96 if D <= 96 else 128 if D <= 128 else 256
+
+    def __enter__(self):
+        self.o_attn, self.o_win = self.ops.attention, self.ops.attention_windows
+
+        def timed(q, k, v, scale, causal=False):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.o_attn(q, k, v, scale, causal)
+            e1.record()
+            B, Sq, H, D = q.shape
+            Skv = k.shape[1]
+            fl = 4.0 * B * H * Sq * Skv * D
+            if causal:
+                fl *= (Skv - Sq + (Sq + 1) / 2.0) / Skv
+            self.rec.append((fl, e0, e1, self.dp(D), (B, H, Sq, Skv, D)))
+            return y
+
+        def timed_win(q, k, v, scale):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = len(self.rec)
+            e0.record()
+            y = self.o_win(q, k, v, scale)
+            e1.record()
+            del self.rec[n0:]            # (the unpacked fallback goes through ops.attention: count it once, here)
+            Bw, wtok, H, D = q.shape
+            self.rec.append((4.0 * Bw * H * wtok * wtok * D, e0, e1, self.dp(D), (Bw, H, wtok, wtok, D)))
+            return y
+        self.ops.attention, self.ops.attention_windows = timed, timed_win
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.attention, self.ops.attention_windows = self.o_attn, self.o_win
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fl, e0, e1, dp, _ in self.rec:
+            a = out.setdefault(dp, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1)
+            a[2] += 1
+        return out
 
 
 class DecodeMeter:
@@ -181,6 +255,64 @@ def meter_decode_gemv(model, ops, reps=3):
     if not rec:
         return None
     return rec[0][2], [1e3 * a.elapsed_time(b) for a, b, _ in rec]
+
+PMC_TAG = "r02_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
+
+
+def quality(cfg, args, model, step, device):
+    """Self-check of the timed configuration's OUTPUTS (outside the timed region).  The bf16 model's clip is re-run once in
+    fp32 parity mode on the GPU — the same bf16-rounded weights upcast to fp32, the exact-fp32 MFMA path that the -m gpu
+    parity tests pin to the reference within 1e-3 — teacher-forced to the bf16 run's token ids so that both runs see the
+    same sequence.  mask_miou_vs_fp32 follows R/eval_gcg_metrics.py:26-35 (sum of intersections / sum of unions over the
+    frames of an object, mean over objects); ids_top1_agree = fraction of decode steps where the bf16 argmax equals the
+    fp32 argmax on the same prefix (random-init logits are near-flat over 128k tokens: near-ties flip)."""
+    from videoglamm_amd import synth
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    cap = model.capture = {}
+    out_ids, _ = step()
+    model.capture = None
+    lb = cap["logits"]                                   # [T,N,H,W] fp32 on the device
+    ids = out_ids[0].tolist()
+    n_prompt = len(ids) - len(cap["argmax"])
+    q = {"mode": "bf16 run vs the same clip in fp32 parity mode on the GPU (same bf16-rounded weights, teacher-forced to the bf16 ids)",
+         "finite": bool(torch.isfinite(lb).all()) and bool(torch.isfinite(cap["emb"].float()).all()),
+         "mask_fraction": round(float((lb > 0).float().mean()), 4),
+         "ids_crc32": zlib.crc32(str(ids).encode()) & 0xffffffff,
+         "seg_objects": int(cap["emb"].shape[0])}
+    mb = lb > 0
+    del lb
+    sd = synth.device_state_dict(synth.manifest(cfg), device, torch.bfloat16)
+    sd = {k: v.float() for k, v in sd.items()}
+    cfg32 = dict(cfg, forced_tokens={i: t for i, t in enumerate(ids[n_prompt:])})
+    cfg32["llm"] = {k: v for k, v in cfg["llm"].items() if k not in ("decode_weights", "prefill_gemm")}
+    m32 = VideoGLaMMForCausalLM(sd, cfg32, torch_dtype=torch.float32, device=device)
+    del sd
+    images, context, sam, pids = make_inputs(cfg, args, 1, device)
+    cap32 = m32.capture = {}
+    t0 = time.time()
+    m32.inference([images], [context], [sam], pids, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=args.max_new_tokens,
+                  use_sam2_video_branch=args.branch == "video")
+    torch.cuda.synchronize()
+    q["fp32_run_s"] = round(time.time() - t0, 1)
+    l32 = cap32["logits"]
+    m32b = l32 > 0
+    inter = (mb & m32b).sum(dim=(0, 2, 3)).double()
+    union = (mb | m32b).sum(dim=(0, 2, 3)).double()
+    iou = torch.where(union > 0, inter / union.clamp_min(1), torch.ones_like(union))
+    q["mask_miou_vs_fp32"] = round(float(iou.mean()), 5)
+    per_frame = (mb & m32b).sum(dim=(2, 3)).double() / (mb | m32b).sum(dim=(2, 3)).double().clamp_min(1)
+    q["min_frame_iou_vs_fp32"] = round(float(per_frame.min()), 5)
+    q["mask_fraction_fp32"] = round(float(m32b.float().mean()), 4)
+    forced = cfg.get("forced_tokens") or {}
+    free = [i for i in range(len(cap["argmax"])) if i not in forced]
+    agree = sum(1 for i in free if cap["argmax"][i] == cap32["argmax"][i])
+    q["ids_top1_agree"] = round(agree / max(len(free), 1), 4)
+    q["seg_emb_cosine"] = round(float(torch.nn.functional.cosine_similarity(cap["emb"].float(), cap32["emb"].float(), dim=-1).min()), 5)
+    del m32
+    torch.cuda.empty_cache()
+    return q
+
 
 def cpu_baseline(cfg, args):
     """Reference algorithm (oracle/, CPU fp32 restatement pinned to the reference) on the host cores, bounded
@@ -318,7 +450,7 @@ def main():
         dt = float(tt[0])
     out_ids, segs = out
     n_obj = len(segs[0][0]) if segs[0] else 0
-    name = "C1" if (args.frames_per_gpu, args.src, args.objects) == (8, 512, 1) else "C2" if (args.frames_per_gpu, args.src, args.objects) == (32, 1024, 1) \
+    name = "C1" if (args.frames_per_gpu, args.src, args.objects, args.te) == (8, 512, 1, 8) else "C2" if (args.frames_per_gpu, args.src, args.objects, args.te) == (32, 1024, 1, 16) \
         else "C4 share of one GPU (64 frames / 8)" if (args.frames_per_gpu, args.src, args.objects) == (8, 1024, 8) else "custom"
     if args.llm != "llama3-8b":
         name += " with the Phi-3-mini LLM"
@@ -350,7 +482,7 @@ def main():
         try:
             step()      # untimed: in this stream configuration the caching allocator first has to grow the main stream's pool,
             #             and a hipMalloc between an event pair's records would be billed to the launch it brackets
-            with GemmMeter(ops) as gm, DecodeMeter() as dm:
+            with GemmMeter(ops) as gm, DecodeMeter() as dm, AttnMeter(ops) as am:
                 step()
         finally:
             for k, v in prev.items():
@@ -360,52 +492,64 @@ def main():
                     os.environ[k] = v
         dec_ms, dec_n = dm.summary()
         peak = 2500.0
-        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summary):
-        # only quoted for the workload it was measured on (C1 framewise, 1 GPU)
-        pmc_ok = (world == 1 and not args.tiny and args.branch == "framewise" and args.frames_per_gpu == 8 and args.te == 8
-                  and args.llm == "llama3-8b")
+        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summaries made by
+        # tools/collect_profiles.sh + tools/pmc_json.py): only quoted for the workload they were measured on (C2 framewise, 1 GPU)
+        pmc_ok = (world == 1 and not args.tiny and args.branch == "framewise" and (args.frames_per_gpu, args.te, args.src, args.objects) == (32, 16, 1024, 1)
+                  and args.llm == "llama3-8b" and (args.decode_weights, args.prefill) == ("bf16", "bf16"))
 
-        def roof(kernel, label, pmc_file):
-            flops, ms, n, nbytes = gm.summary(kernel)
-            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", pmc_file)
+        def traffic_of(key):
+            pmc = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_{key}.json")
             if pmc_ok and os.path.exists(pmc):
                 with open(pmc) as fh:
-                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
+                    return round(json.load(fh)["traffic_bytes_per_launch"])
+            return None
+
+        def roof(kernel, label, scope=None, key=None):
+            flops, ms, n, nbytes = gm.summary(kernel, scope)
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(key) if key else None,
                     "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                     "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
                     "kernel_ms_per_step": round(ms, 2)}
-        # one object per tile kernel; "roofline" is the one with the most GPU time in the step (gemm_tile_glds_kernel on C1)
-        labels = {"glds": ("gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)", "r01_pmc_gemm_glds.json"),
-                  "k64b": ("gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)", "r01_pmc_gemm_k64b.json"),
-                  "w128": ("gemm_tile_w128x8_kernel<bf16> (256x256 tile, 8 waves of 128x64: grids that fill the chip)", "r01_pmc_gemm_w128.json"),
-                  "s128": ("gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)", "r01_pmc_gemm_s128.json")}
-        roofs = {k: roof(k, *labels[k]) for k in labels}
+        # one object per tile kernel; "roofline" is the one with the most GPU time in the step
+        labels = {"glds": "gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)",
+                  "k64b": "gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)",
+                  "w128": "gemm_tile_w128x8_kernel<bf16> (256x256 tile, 8 waves of 128x64: grids that fill the chip)",
+                  "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)"}
+        roofs = {k: roof(k, labels[k], key="gemm_" + k) for k in labels}
         roofs = {"gemm_" + k: v for k, v in roofs.items() if v["launches"]}
         gv = None if args.tiny else meter_decode_gemv(model, ops)
         if gv is not None:
             nbytes, us = gv
             avg = sum(us) / len(us)
             per_step = avg * 1e-3 * len(us) / 3 * dec_n          # launches per decode step x decode steps per clip
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_gemv_glu.json")
-            if pmc_ok and os.path.exists(pmc):
-                with open(pmc) as fh:
-                    traffic = round(json.load(fh)["traffic_bytes_per_launch"])
             roofs["decode_gemv_glu"] = {"bound": "hbm", "kernel": "decode_gemv_fast_kernel<bf16, GLU> (decode step: RMSNorm + gate|up GEMV + SwiGLU of one row)",
                                         "achieved": round(nbytes / avg / 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / avg / 1e3 / 8000.0, 4),
-                                        "traffic": traffic, "launches": round(len(us) / 3 * dec_n), "algorithmic_bytes_per_launch": nbytes,
+                                        "traffic": traffic_of("decode_gemv_glu"), "launches": round(len(us) / 3 * dec_n), "algorithmic_bytes_per_launch": nbytes,
                                         "avg_launch_us": round(avg, 1), "kernel_ms_per_step": round(per_step, 2),
                                         "note": "timed on eager replays of the decode step; the timed region runs it inside a HIP graph"}
+        # attention kernels, one object per head-dim instantiation (the north star's "attention-GEMM roofline": QK^T and PV on the MFMA)
+        for dp, (fl, ms, n) in sorted(am.summary().items()):
+            if ms <= 0:
+                continue
+            ach = fl / (ms * 1e-3) / 1e12
+            roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": f"attn_kernel<bf16, {dp}, 64, 4> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)",
+                                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
+                                    "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
+                                    "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2)}
         # "roofline" = the kernel with the most GPU time in a step; the others ride along under their own keys
         main = max(roofs, key=lambda k: roofs[k]["kernel_ms_per_step"])
         res["roofline"] = roofs.pop(main)
         for k, v in roofs.items():
             res["roofline_" + k] = v
+        # the mask-decoder GEMMs (S7/S8: two-way transformer projections, ConvT-as-GEMM upscaling, hypernetwork MLPs and product), over whatever
+        # tile kernels they route to — a cross-section of the objects above, not an additional kernel
+        md = roof(None, "every ops.linear launch inside SAM2.mask_decoder (two-way transformer q/k/v/out projections on [frames x objects, 4096, 256], "
+                        "ConvTranspose-as-GEMM upscaling, token MLPs)", scope="mask_decoder")
+        if md["launches"]:
+            res["roofline_mask_decoder_gemm"] = md
         if dec_n and not args.tiny:
             c = cfg["llm"]
             hd = c["hidden"] // c["num_heads"]
@@ -417,6 +561,8 @@ def main():
             res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 + decode_attn_kernel per layer)",
                                       "achieved": round(tbs * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tbs / 8.0, 4),
                                       "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
+    if world == 1 and not args.no_quality and not args.tiny:
+        res["quality"] = quality(cfg, args, model, step, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:      # the CPU leg runs at N = 1 only
         res["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:

@@ -80,7 +80,9 @@ int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t ldw, void*
 
 /* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
  * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)
- * causal = 1: key j visible to query i iff j <= i + (Skv - Sq).  causal = -w (w > 0): block-diagonal mask — the
+ * causal = 1: key j visible to query i iff j <= i + (Skv - Sq).  causal = c >= 2: the same with a sliding window of c
+ * visible keys, the query's own position included: i + (Skv - Sq) - c < j <= i + (Skv - Sq) (HF Phi-3's sliding_window mask,
+ * transformers==4.41.0 modeling_attn_mask_utils._make_causal_mask: c = sliding_window + 1).  causal = -w (w > 0): block-diagonal mask — the
  * sequence is a pack of independent w-token windows (key j visible to query i iff j/w == i/w; Sq == Skv), which lets
  * Hiera's 16- / 64-token windows share 128-query tiles.  D % 8 == 0, D <= 256.
  * Strides are in elements: *_sb batch, *_ss token, *_sh head; the head dim is contiguous.
@@ -122,13 +124,14 @@ int vg_add_int(int* p, int v, vg_stream_t stream);
  *   glu != 0: W is [2N,K] = gate rows | up rows and y[n] = silu(x.gate_n) * (x.up_n) (LlamaMLP).  Row stride of W = ldw.
  * vg_decode_attention: qkv = fused projection row [(H+2*Hkv)*D] of the new token at position p = *pos_dev.  Applies
  *   rotate-half RoPE (cos/sin tables [max_len, D/2]) to q and k, appends k/v to the caches ([max_len,Hkv,D]) and writes
- *   softmax(q.K[0..p]^T * scale).V[0..p] to out [H*D].  workspace: fp32, vg_decode_attention_ws_floats() floats, must be
+ *   softmax(q.K[lo..p]^T * scale).V[lo..p] to out [H*D], lo = window > 0 ? max(0, p + 1 - window) : 0 (window = number of
+ *   visible positions, the new one included; 0 = the whole cache).  workspace: fp32, vg_decode_attention_ws_floats() floats, must be
  *   zero-filled ONCE by the caller before the first launch (it ends with self-resetting per-head counters). */
 int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y, const float* norm_w, float eps,
                    const void* R, int N, int K, int glu, int in_dtype, int out_dtype, vg_stream_t stream);
 int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_len);
 int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
-                        void* out, int H, int Hkv, int D, int max_len, float scale, const int* pos_dev,
+                        void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
                         float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream);
 
 /* ---- row normalisation -------------------------------------------------------------------------

@@ -150,16 +150,20 @@ def llama_forward(sd, p, cfg, x):
     """HF LlamaModel / Phi3Model over inputs_embeds (causal, no cache) + final norm. x: [S,D] -> [S,D] normed hidden.
     HF modeling_llama.py: LlamaDecoderLayer / LlamaAttention (repeat_kv GQA) / LlamaMLP / LlamaRMSNorm; modeling_phi3.py is
     the same arithmetic with fused qkv_proj / gate_up_proj weights (the LLM of the released checkpoint,
-    R/model/videogpt_plus/model/language_model/phi3.py:29-40) and a sliding window (2047 for Phi-3-mini-4k) that only
-    changes the mask of sequences longer than the window — rejected here and in the product rather than guessed at
-    (transformers 4.41 and 5.x disagree by one position on where the window ends)."""
+    R/model/videogpt_plus/model/language_model/phi3.py:29-40) and a sliding window w = cfg["sliding_window"] (2047 for
+    Phi-3-mini-4k): position i attends to [i - w, i], i.e. w + 1 keys.  That is the mask of the reference's pinned
+    transformers==4.41.0 (modeling_attn_mask_utils.AttentionMaskConverter._make_causal_mask: context_mask =
+    tril(ones, diagonal = -w - 1) filled with min; its flash-attention path passes window_size = (w, w): the same keys).
+    SOURCE ABSENT (4.41.0 is not installed here; restated from its published code): the window EDGE is "parity unpinned";
+    the arithmetic is pinned by HF 5.15's Phi3Model run with sliding_window = w + 1, whose mask (kv > q - sliding_window)
+    shows exactly these keys (tests/golden/phi3_tiny.npz: phi3_win_out)."""
     S, D = x.shape
-    if cfg.get("sliding_window") and S > cfg["sliding_window"]:
-        raise NotImplementedError("sequence longer than the sliding window")
     H, Hkv, eps = cfg["num_heads"], cfg["num_kv_heads"], cfg["rms_eps"]
     hd = D // H
     cos, sin = rope_tables(hd, S, cfg["rope_theta"])
     mask = torch.full((S, S), float("-inf")).triu(1)
+    if cfg.get("sliding_window"):
+        mask = mask.masked_fill(torch.ones(S, S, dtype=torch.bool).tril(-int(cfg["sliding_window"]) - 1), float("-inf"))
     for i in range(cfg["num_layers"]):
         l = f"{p}layers.{i}."
         h = rms_norm(x, sd[l + "input_layernorm.weight"], eps)

@@ -57,7 +57,7 @@ def bmm_nt(a, w, out_dtype=None):
     return (a.float() @ w.float().transpose(-1, -2)).to(odt)
 
 
-def attention(q, k, v, scale, causal=False):
+def attention(q, k, v, scale, causal=False, window=0):
     B, Sq, Hq, D = q.shape
     Skv, Hkv = k.shape[1], k.shape[2]
     qf = q.float().permute(0, 2, 1, 3)
@@ -68,6 +68,8 @@ def attention(q, k, v, scale, causal=False):
         i = torch.arange(Sq, device=q.device)[:, None]
         j = torch.arange(Skv, device=q.device)[None, :]
         s = s.masked_fill(j > i + (Skv - Sq), float("-inf"))
+        if window:      # the query's own position and the window - 1 before it
+            s = s.masked_fill(j <= i + (Skv - Sq) - window, float("-inf"))
     p = torch.softmax(s, dim=-1)
     return (p @ vf).permute(0, 2, 1, 3).contiguous().to(q.dtype)
 
@@ -170,9 +172,9 @@ def argmax(x, out=None):
     return r
 
 
-def attention_decode(q, k_cache, v_cache, pos_dev, scale):
+def attention_decode(q, k_cache, v_cache, pos_dev, scale, window=0):
     n = int(pos_dev[0]) + q.shape[1]
-    return attention(q, k_cache[:n].unsqueeze(0), v_cache[:n].unsqueeze(0), scale, causal=True)
+    return attention(q, k_cache[:n].unsqueeze(0), v_cache[:n].unsqueeze(0), scale, causal=True, window=window)
 
 
 def rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos0=0, pos_dev=None):
@@ -196,11 +198,11 @@ def decode_attention_workspace(H, Hkv, D, max_len, device):
     return torch.zeros(1)
 
 
-def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws):
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0):
     qkv = qkv.clone()
     rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, 0, pos_dev)
     q = qkv[:, : H * D].view(1, 1, H, D)
-    return attention_decode(q, k_cache, v_cache, pos_dev, scale).view(1, H * D)
+    return attention_decode(q, k_cache, v_cache, pos_dev, scale, window).view(1, H * D)
 
 
 def store_row_(src, dst, idx_dev, idx_off=0):

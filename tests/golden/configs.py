@@ -25,3 +25,5 @@ E2E = dict(
 # Phi-3-mini shape family (the LLM of the released VideoGLaMM checkpoint): fused qkv_proj / gate_up_proj, MHA
 PHI3_TINY = dict(vocab=320, hidden=64, ffn=176, num_layers=2, num_heads=4, num_kv_heads=4, rms_eps=1e-5, rope_theta=10000.0,
                  sliding_window=2047)
+# the same decoder with a window shorter than the fixtures' 45-token sequence (4.41 semantics: position i sees [i - 11, i], 12 keys)
+PHI3_TINY_WIN = dict(PHI3_TINY, sliding_window=11)

@@ -189,7 +189,20 @@ def gen_phi3():
                                attn_implementation="eager")).eval()
     load_seeded(llm, 5, None, "phi3_tiny_manifest.json")
     emb = rnd((1, 45, c["hidden"]), 34)
-    save("phi3_tiny.npz", phi3_out=llm(inputs_embeds=emb).last_hidden_state[0])
+    out = dict(phi3_out=llm(inputs_embeds=emb).last_hidden_state[0])
+    # the same weights with a window the 45-token sequence crosses.  transformers 5.x masks kv <= q - sliding_window (sliding_window keys
+    # visible, own position included); the reference's pin 4.41.0 shows sliding_window + 1 keys — so HF-5 sliding_window = 12 is the mask
+    # of a 4.41 model with sliding_window = 11 (PHI3_TINY_WIN), which is what the oracle / product are given
+    from configs import PHI3_TINY_WIN
+    w5 = PHI3_TINY_WIN["sliding_window"] + 1
+    win = Phi3Model(Phi3Config(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["ffn"], num_hidden_layers=c["num_layers"],
+                               num_attention_heads=c["num_heads"], num_key_value_heads=c["num_kv_heads"], rms_norm_eps=c["rms_eps"],
+                               rope_theta=c["rope_theta"], max_position_embeddings=4096, original_max_position_embeddings=4096,
+                               sliding_window=w5, pad_token_id=0, bos_token_id=1, eos_token_id=2, attn_implementation="eager")).eval()
+    win.load_state_dict(llm.state_dict())
+    out["phi3_win_out"] = win(inputs_embeds=emb).last_hidden_state[0]
+    assert (out["phi3_win_out"] - out["phi3_out"]).abs().max() > 1e-3, "the window must change the result"
+    save("phi3_tiny.npz", **out)
 
 
 def build_ref_e2e(use_video_branch):

@@ -1,0 +1,111 @@
+"""Full-size checks of the bf16 performance mode (-m gpu): the configurations bench.py times, at the real widths.
+
+The micro fixtures pin the ARITHMETIC of every stage to the reference in fp32; these tests pin the bf16-only kernels and
+routes that only full-size shapes reach (256x256-tile GEMMs, 128-dim decode attention, Hiera-L's windows) against
+(a) the fp32 parity mode of the same HIP path and (b) the CPU oracle (oracle/, restatement of the reference), on the
+same synthetic weights.  Tolerances are bf16-sized and stated per check.
+"""
+import pytest
+import torch
+
+from oracle import sam2 as osam, seeded, vlm as ovlm
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _llama2(cuda, S):
+    from videoglamm_amd import synth
+    c = dict(synth.LLAMA3_8B, num_layers=2, vocab=8192)
+    man = {k: v for k, v in synth.vlm_manifest(dict(synth.videoglamm_llama3_8b(), llm=c)).items()
+           if k.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))}
+    sd = seeded.seeded_state_dict(man, 5)
+    sd = {k: (v.to(torch.bfloat16) if v.dim() >= 2 else v) for k, v in sd.items()}          # the checkpoint IS bf16: both modes read the same values
+    x = (torch.randn(S, c["hidden"], generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16)
+    return c, sd, x
+
+
+def test_llama3_8b_width_prefill_decode_bf16(cuda):
+    """2 decoder layers at Llama-3-8B width on the C2 prompt length (3361 rows: o / gate|up / down take the 256x256-tile
+    kernel, qkv the 128x128 one) + 6 graph-free decode steps: bf16 mode vs fp32 mode of the HIP path vs the CPU oracle
+    (HF LlamaModel arithmetic, oracle/vlm.py:llama_forward)."""
+    from videoglamm_amd import _lib
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    S, G = 3361, 6
+    c, sd, x = _llama2(cuda, S + G)
+    lib = _lib.load()
+    assert lib.vg_gemm_route(S, 4096, 14336, 1, 0, 0) == 3 and lib.vg_gemm_route(S, 14336, 4096, 1, 1, 0) == 3 and lib.vg_gemm_route(S, 4096, 4096, 1, 0, 0) == 3
+    out = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        P = Params({k: v.float() if dt == torch.float32 else v for k, v in sd.items()}, cuda, dt)
+        dec = LlamaDecoder(P, c, 4096, use_graph=False)
+        h = dec.forward(x[:S].to(cuda, dt))
+        rows = []
+        for i in range(G):                       # teacher-forced decode rows through the fused decode kernels
+            h1 = dec._layers_decode(x[S + i:S + i + 1].to(cuda, dt)) if dec.fused_decode else dec._layers(x[S + i:S + i + 1].to(cuda, dt), 0, dec.pos_dev)
+            dec.pos += 1
+            dec.pos_dev.fill_(dec.pos)
+            rows.append(h1)
+        hid = torch.cat([h] + rows).float()
+        logits = torch.nn.functional.linear(hid[-(G + 64):], P.w("lm_head").float())
+        out[name] = (hid.cpu(), logits.cpu())
+        del dec, P
+    torch.cuda.empty_cache()
+    ref = ovlm.llama_forward({k: v.float() for k, v in sd.items()}, "model.", c, x.float())       # [S+G, D] final-norm states, fp32 on the CPU
+    hb, lb = out["bf16"]
+    hf, lf = out["fp32"]
+    assert torch.isfinite(hb).all() and torch.isfinite(hf).all()
+    # fp32 mode == oracle (summation order only)
+    torch.testing.assert_close(hf, ref, rtol=2e-3, atol=2e-3)
+    # bf16 mode: rounding noise of bf16 activations through 2 layers (rel. error of a row < 3 %, cosine > 0.9995) — a wrong tile, a
+    # dropped K step or a mis-routed residual is orders of magnitude above that
+    cos = torch.nn.functional.cosine_similarity(hb, ref, dim=1)
+    rel = (hb - ref).norm(dim=1) / ref.norm(dim=1)
+    assert cos.min() > 0.9995 and rel.max() < 0.03, (float(cos.min()), float(rel.max()))
+    # greedy choice: wherever the fp32 top-1 leads the runner-up by more than the bf16 noise, bf16 picks the same token
+    top2 = lf.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05 * lf.std()
+    agree = (lb.argmax(1) == lf.argmax(1))
+    assert clear.sum() >= 10 and bool(agree[clear].all()), (int(clear.sum()), float(agree.float().mean()))
+
+
+def test_sam2_large_frame_bf16_vs_oracle(cuda):
+    """ONE full-size frame through Hiera-L + FPN + the mask decoder (framewise branch, 2 objects, 1024^2 input, masks at
+    480x640): fp32 parity mode vs the CPU oracle on logits, bf16 mode vs the oracle on masks (mIoU as
+    R/eval_gcg_metrics.py:26-35) and on the logits' correlation."""
+    from videoglamm_amd import synth
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+    cfg = synth.SAM2_L
+    sd = seeded.seeded_state_dict(synth.sam2_manifest(cfg), 2, seeded.sam2_overrides())
+    sd = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()}      # bf16-representable weights for every mode
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(1, 3, 1024, 1024, generator=g)
+    text = torch.randn(2, 256, generator=g) * 0.5
+    hw = (480, 640)
+    ref, _ = osam.framewise_branch(sd, "", cfg, img, text, hw)
+    ref = torch.stack(ref)                                                                       # [1, N, H, W]
+    out = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = SAM2(Params(sd, cuda, dt), "", cfg)
+        logits, _ = m.framewise_branch(img.to(cuda), text.to(cuda), hw)
+        out[name] = logits.float().cpu()
+        del m
+    lf, lb = out["fp32"], out["bf16"]
+    assert lf.shape == ref.shape and torch.isfinite(lf).all() and torch.isfinite(lb).all()
+    scale = float(ref.abs().max())
+    err = float((lf - ref).abs().max())
+    print(f"SAM2-L frame: |logit| max {scale:.3f}, fp32 HIP vs oracle max abs err {err:.2e}")
+    assert err <= 1e-3 * max(1.0, scale), (err, scale)          # the north star's "mask logits within 1e-3 fp32" (48 blocks deep, order of summation only)
+    mr, mf, mb = ref > 0, lf > 0, lb > 0
+    assert 0.01 < float(mr.float().mean()) < 0.99, "degenerate reference masks: the check would be vacuous"
+
+    def miou(a, b):
+        i, u = (a & b).sum(dim=(0, 2, 3)).double(), (a | b).sum(dim=(0, 2, 3)).double()
+        return float((i / u.clamp_min(1)).mean())
+    assert miou(mf, mr) > 0.999, miou(mf, mr)
+    # bf16: activations rounded to 8 bits of mantissa through 48 blocks; logits stay highly correlated, masks overlap
+    corr = float(torch.corrcoef(torch.stack([lb.flatten(), ref.flatten()]))[0, 1])
+    print(f"SAM2-L frame: bf16 vs oracle mIoU {miou(mb, mr):.4f}, logit correlation {corr:.5f}")
+    assert miou(mb, mr) > 0.97 and corr > 0.995, (miou(mb, mr), corr)

@@ -68,8 +68,19 @@ def check_modules(device, tol):
     else:
         rows += [dec.forward(x[i:i + 1]) for i in range(40, 45)]
     torch.testing.assert_close(torch.cat(rows).cpu(), ref, **tol)
-    with pytest.raises(NotImplementedError):
-        LlamaDecoder(Params(sd, device, torch.float32), c, 4096)   # beyond the sliding window
+    # sliding window crossed by the sequence (position i sees [i - 11, i]): prefill at once, prefill in chunks (Sq < Skv),
+    # and decode steps through the windowed decode attention — vs HF Phi3Model with the same mask (phi3_win_out)
+    c = G.configs.PHI3_TINY_WIN
+    ref = G.fixture("phi3_tiny.npz")["phi3_win_out"]
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    torch.testing.assert_close(dec.forward(x).cpu(), ref, **tol)
+    dec = LlamaDecoder(Params(sd, device, torch.float32), c, 64)
+    rows = [dec.forward(x[:9]), dec.forward(x[9:30])]
+    if device.type == "cuda":
+        rows += [ops_decode_row(dec, x[i:i + 1]) for i in range(30, 45)]
+    else:
+        rows += [dec.forward(x[i:i + 1]) for i in range(30, 45)]
+    torch.testing.assert_close(torch.cat(rows).cpu(), ref, **tol)
 
 
 def check_e2e(device, branch):

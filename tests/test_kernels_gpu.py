@@ -431,3 +431,113 @@ def test_gemm_splitk(cuda, dtype, M, N, K, monkeypatch):
     y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act=ops.ACT_GELU, gamma=gamma.to(cuda), residual=res.to(cuda))
     close(y, ref.linear(x, w, bias, act=ref.ACT_GELU, gamma=gamma, residual=res), **tol(dtype, K))
     close(ops.linear(x.to(cuda), w.to(cuda)), ref.linear(x, w), **tol(dtype, K))
+
+
+BIG = [  # (M, N, K, glu): bf16 shapes the launcher routes to the 256x256-tile kernels (vg_gemm_route == 3) — the LLM prefill GEMMs of C1 / C2
+    (3361, 4096, 14336, False),      # C2 down projection (+ residual)
+    (1697, 14336, 4096, True),       # C1 gate|up with the SwiGLU epilogue
+    (4096, 4096, 4096, False),
+    (3333, 4104, 4160, False),       # ragged M and N, K = 65 steps
+    (3361, 4096, 4096, False),       # C2 o projection
+]
+
+
+def _check_big_gemm(cuda, M, N, K, glu):
+    from videoglamm_amd import _lib, ops
+    assert _lib.load().vg_gemm_route(M, N, K, 1, 1 if glu else 0, 0) == 3, "this shape must take the 256x256-tile kernel"
+    dtype = torch.bfloat16
+    x = rnd(M, K, dtype=dtype, seed=1)
+    w = rnd((2 if glu else 1) * N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias = rnd((2 if glu else 1) * N, seed=3)
+    if glu:
+        y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), glu=True)
+        close(y, ref.linear(x, w, bias, glu=True), rtol=2e-2, atol=2e-2)
+        assert torch.equal(y, ops.swiglu(ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda))))     # same roundings as GEMM + vg_swiglu
+        return
+    gamma, res = 1.0 + 0.1 * rnd(N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), ops.ACT_GELU, gamma.to(cuda), res.to(cuda))
+    close(y, ref.linear(x, w, bias, ref.ACT_GELU, gamma, res), rtol=2e-2, atol=2e-2)
+    y = ops.linear(x.to(cuda), w.to(cuda), residual=res.to(cuda))
+    close(y, ref.linear(x, w, residual=res), rtol=2e-2, atol=2e-2)
+    y32 = ops.linear(x.to(cuda), w.to(cuda), out_dtype=torch.float32)                          # fp32 output: no output rounding in the way
+    close(y32, ref.linear(x, w, out_dtype=torch.float32), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,glu", BIG)
+def test_gemm_w128x8(cuda, M, N, K, glu):
+    """the default (eight-wave) 256x256-tile kernel on the bench's heaviest bf16 GEMMs, against the fp32 statement."""
+    import os
+    assert os.environ.get("VG_GEMM_W128", "1") == "1"
+    _check_big_gemm(cuda, M, N, K, glu)
+
+
+def test_gemm_w128_four_wave(cuda):
+    """the four-wave variant (VG_GEMM_W128=5) of the same kernel: the knob is read once per process, so a child process runs it."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
+            "import test_kernels_gpu as t\n"
+            "from videoglamm_amd import _lib\n"
+            "assert _lib.load().vg_init(0) > 0\n"
+            "dev = torch.device('cuda:0')\n"
+            "for c in t.BIG[:3]: t._check_big_gemm(dev, *c)\n"
+            "print('four-wave ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_GEMM_W128="5"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "four-wave ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+WIN = [  # (Hq, Hkv, Sq, Skv, D, window): causal + sliding window (the query's own position and the window - 1 before it)
+    (4, 4, 700, 700, 96, 100),       # Phi-3 head dim, window shorter than a query tile
+    (4, 4, 700, 700, 96, 257),       # window spanning several key tiles, ragged edge
+    (8, 2, 333, 333, 128, 64),       # GQA
+    (4, 4, 213, 1697, 96, 300),      # chunked prefill rows (Sq < Skv): split-KV + merge with whole splits outside the window
+    (4, 4, 1, 700, 96, 130),         # one row against a cache
+    (32, 32, 3361, 3361, 96, 2048),  # the released model at NUM_FRAMES = 16: Phi-3-mini heads, S = 3361, 2048 visible keys
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", WIN)
+def test_attention_sliding_window(cuda, dtype, cfg):
+    from videoglamm_amd import ops
+    Hq, Hkv, Sq, Skv, D, window = cfg
+    if Sq > 3000 and dtype == torch.float32:
+        pytest.skip("full-size case runs in bf16 only")
+    q, k, v = rnd(1, Sq, Hq, D, dtype=dtype, seed=1), rnd(1, Skv, Hkv, D, dtype=dtype, seed=2), rnd(1, Skv, Hkv, D, dtype=dtype, seed=3)
+    o = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5, True, window=window)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    want = ref.attention(q, k, v, D ** -0.5, True, window=window)
+    close(o, want, **t)
+    assert (want.float() - ref.attention(q, k, v, D ** -0.5, True).float()).abs().max() > 1e-2     # the window matters in this case
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("H,Hkv,D,max_len,window", [(4, 4, 96, 1024, 100), (4, 4, 96, 1024, 64), (4, 4, 96, 1024, 65), (32, 8, 128, 2048, 700),
+                                                    (32, 32, 96, 4096, 2048)])
+def test_decode_attention_sliding_window(cuda, dtype, H, Hkv, D, max_len, window):
+    """the fused decode attention with a window: whole splits before the window never run, the first visible split is masked
+    per key, and the merge / arrival counter only count the visible splits."""
+    from videoglamm_amd import ops
+    kc, vc = rnd(max_len, Hkv, D, dtype=dtype, seed=2), rnd(max_len, Hkv, D, dtype=dtype, seed=3)
+    ang = torch.arange(max_len)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, D, 2).float() / D)))[None]
+    cos, sin = ang.cos(), ang.sin()
+    ws = ops.decode_attention_workspace(H, Hkv, D, max_len, cuda)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    for pos in (0, 5, window - 1, window, window + 1, window + 63, window + 64, max_len // 2 + 7, max_len - 1):
+        if pos >= max_len:
+            continue
+        qkv = rnd(1, (H + 2 * Hkv) * D, dtype=dtype, seed=10 + pos)
+        pos_dev = torch.tensor([pos], dtype=torch.int32)
+        g_kc, g_vc = kc.to(cuda), vc.to(cuda)
+        o = ops.decode_attention(qkv.to(cuda), g_kc, g_vc, cos.to(cuda), sin.to(cuda), H, Hkv, D, pos_dev.to(cuda), D ** -0.5, ws, window=window)
+        r_qkv, r_kc, r_vc = qkv.clone(), kc.clone(), vc.clone()
+        ref.rope_kv_append_(r_qkv, r_kc, r_vc, cos, sin, H, Hkv, D, 0, pos_dev)
+        close(o, ref.attention_decode(r_qkv[:, : H * D].view(1, 1, H, D), r_kc, r_vc, pos_dev, D ** -0.5, window).view(1, H * D), **t)
+        # and the unfused path (vg_attention_splitkv with the device-side length)
+        u_qkv = qkv.to(cuda)
+        ops.rope_kv_append_(u_qkv, kc.to(cuda), vc.to(cuda), cos.to(cuda), sin.to(cuda), H, Hkv, D, 0, pos_dev.to(cuda))
+        o2 = ops.attention_decode(u_qkv[:, : H * D].view(1, 1, H, D), g_kc, g_vc, pos_dev.to(cuda), D ** -0.5, window=window)
+        close(o2.view(1, H * D), o, **t)
+    assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0

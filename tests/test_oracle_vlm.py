@@ -42,3 +42,13 @@ def test_phi3():
     sd = G.weights("phi3_tiny_manifest.json", 5)
     out = O.llama_forward(sd, "", c, G.rnd((1, 45, c["hidden"]), 34)[0])
     torch.testing.assert_close(out, G.fixture("phi3_tiny.npz")["phi3_out"], **TOL)
+
+
+def test_phi3_sliding_window():
+    """the window mask (position i sees [i - w, i]) on a sequence that crosses it, vs HF Phi3Model with the same visible keys"""
+    c = G.configs.PHI3_TINY_WIN
+    sd = G.weights("phi3_tiny_manifest.json", 5)
+    out = O.llama_forward(sd, "", c, G.rnd((1, 45, c["hidden"]), 34)[0])
+    torch.testing.assert_close(out, G.fixture("phi3_tiny.npz")["phi3_win_out"], **TOL)
+    full = O.llama_forward(sd, "", G.configs.PHI3_TINY, G.rnd((1, 45, c["hidden"]), 34)[0])
+    assert (out[:12] - full[:12]).abs().max() < 1e-5 and (out[12:] - full[12:]).abs().max() > 1e-4     # rows inside the window are untouched

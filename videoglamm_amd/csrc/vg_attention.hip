@@ -130,7 +130,14 @@ __global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? 
   // causal < 0: block-diagonal mask, windows of wtok = -causal tokens packed back to back along the sequence (Hiera's
   // 16- and 64-token windows: 8 or 2 of them fill one 128-query tile instead of one padded tile each)
   const int wtok = p.causal < 0 ? -p.causal : 0;
+  // causal >= 2: causal mask with a sliding window of `causal` visible keys (the query's own position included):
+  // key j visible to query i iff i + off - causal < j <= i + off  (HF Phi-3 / Mistral sliding_window)
+  const int win = p.causal > 1 ? p.causal : 0;
   int kv_first = 0;
+  if (win) {
+    const int lo = (p.fold ? 0 : q0) + off - win + 1;      // first key any query of this block sees
+    kv_first = lo > 0 ? lo / BKV * BKV : 0;
+  }
   if (wtok) {
     kv_first = q0 / wtok * wtok;
     const int e = (q0 + BQ + wtok - 1) / wtok * wtok;
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? 
     kv_begin = split * p.split_len;
     const int e = kv_begin + p.split_len;
     kv_end = e < kv_end ? e : kv_end;
+    if (kv_begin < kv_first) kv_begin = kv_first;
   }
   // K/V staging: a tile is fetched into registers one iteration ahead (the loads of tile t+1 are in flight while
   // tile t is multiplied), then written to LDS — K as padded rows, V (bf16) transposed for pv_step_bf16t
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? 
     // softmax in the exp2 domain: t = s * (scale * log2 e), so every score costs one fma + one v_exp_f32; m_i and the
     // partials keep natural-log units (m = max(t) / log2 e) for the split-KV merge.  The mask arithmetic only runs on
     // tiles that need it (sequence end, causal diagonal, window edges): the inner loop is VALU-bound, not MFMA-bound.
-    const bool need_mask = kv0 + BKV > Skv || p.causal < 0 || (p.causal > 0 && kv0 + BKV - 1 > (p.fold ? 0 : q0) + off);
+    const bool need_mask = kv0 + BKV > Skv || p.causal < 0 || (p.causal > 0 && kv0 + BKV - 1 > (p.fold ? 0 : q0) + off) ||
+                           (win && kv0 <= (p.fold ? Sq - 1 : q0 + BQ - 1) + off - win);
     float mx = -INFINITY;
     if (need_mask) {
 #pragma unroll
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kt * 32 + mfma32_row(r, h);
-          const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi;
+          const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi && (!win || key > q_idx + off - win);
           const float v = ok ? s[kt][r] * sl2 : -INFINITY;
           s[kt][r] = v;
           mx = fmaxf(mx, v);

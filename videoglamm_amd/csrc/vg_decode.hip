@@ -429,6 +429,7 @@ struct DecAttnArgs {
   const void* qkv; void* kc; void* vc; const float* cs; const float* sn; void* o;
   float* ws; int* cnt; const int* pos_dev;
   int H, Hkv, D, nsplit; float scale;
+  int window;   // > 0: only the last `window` positions (the new one included) are attended (sliding-window LLMs); 0: all
 };
 
 __device__ __forceinline__ float ld_agent(const float* p) {
@@ -449,7 +450,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   const int pos = *p.pos_dev;
   const int s = blockIdx.x, kvh = blockIdx.y;
   const int active = pos / L + 1;
-  if (s >= active) return;
+  const int lo = p.window > 0 ? max(0, pos + 1 - p.window) : 0;     // first visible position
+  const int first = lo / L;                                         // first split with a visible key
+  if (s >= active || s < first) return;
+  const int nact = active - first;
   const int D = DT ? DT : p.D;
   const int CH = D / KPC, hd = D / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -562,9 +566,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   __syncthreads();
   for (int g = wave; g < G; g += 4) {
     float v = (sp[(0 * G + g) * 64 + lane] + sp[(1 * G + g) * 64 + lane] + sp[(2 * G + g) * 64 + lane] + sp[(3 * G + g) * 64 + lane]) * p.scale;
-    if (lane >= nk) v = -INFINITY;
+    const bool seen = lane < nk && j0 + lane >= lo;
+    if (!seen) v = -INFINITY;
     const float m = wave_max(v);
-    const float e = lane < nk ? __expf(v - m) : 0.f;
+    const float e = seen ? __expf(v - m) : 0.f;
     const float l = wave_sum(e);
     sc[g * 64 + lane] = e;
     if (lane == 0) { ms[g] = m; ms[G + g] = l; }
@@ -617,14 +622,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   __syncthreads();
   if (tid == 0) ticket = __hip_atomic_fetch_add(&p.cnt[kvh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (ticket != active - 1) return;
+  if (ticket != nact - 1) return;
   // ---- 6. merge by the last workgroup of this KV head to arrive.  All loads of a pass (the (max, sum) of every
   //         split and two accumulator columns per thread) are requested together: one fabric round trip per pass.
-  const float* wbase = p.ws + (int64_t)kvh * p.nsplit * G * (D + 2);
-  float* cw = sp;                    // [active][G] max -> weight      (sp is free again; nsplit*G*2 <= 4*G*64)
-  float* cl = sp + p.nsplit * G;     // [active][G] sum
+  const float* wbase = p.ws + ((int64_t)kvh * p.nsplit + first) * G * (D + 2);   // the visible splits [first, active)
+  float* cw = sp;                    // [nact][G] max -> weight      (sp is free again; nsplit*G*2 <= 4*G*64)
+  float* cl = sp + p.nsplit * G;     // [nact][G] sum
   T* out = (T*)p.o;
-  const int nml = active * G;
+  const int nml = nact * G;
   for (int o0 = 0; o0 < G * D; o0 += 512) {
     int oo[2], og[2], od[2];
 #pragma unroll
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
       od[k] = oc % D;
     }
     float num[2] = {0.f, 0.f};
-    for (int sb = 0; sb < active; sb += 32) {
+    for (int sb = 0; sb < nact; sb += 32) {
       float mv[2], lv[2];
       if (o0 == 0 && sb == 0) {
 #pragma unroll
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
       for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int u = 0; u < 32; ++u)
-          v[k][u] = ld_agent(wbase + ((int64_t)min(sb + u, active - 1) * G + og[k]) * (D + 2) + od[k]);
+          v[k][u] = ld_agent(wbase + ((int64_t)min(sb + u, nact - 1) * G + og[k]) * (D + 2) + od[k]);
       if (o0 == 0 && sb == 0) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -663,10 +668,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
         __syncthreads();
         for (int gg = wave; gg < G; gg += 4) {
           float M = -INFINITY;
-          for (int s2 = lane; s2 < active; s2 += 64) M = fmaxf(M, cw[s2 * G + gg]);
+          for (int s2 = lane; s2 < nact; s2 += 64) M = fmaxf(M, cw[s2 * G + gg]);
           M = wave_max(M);
           float den = 0.f;
-          for (int s2 = lane; s2 < active; s2 += 64) {
+          for (int s2 = lane; s2 < nact; s2 += 64) {
             const float wgt = __expf(cw[s2 * G + gg] - M);
             cw[s2 * G + gg] = wgt;
             den = fmaf(wgt, cl[s2 * G + gg], den);
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
       for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int u = 0; u < 32; ++u)
-          if (sb + u < active) num[k] = fmaf(cw[(sb + u) * G + og[k]], v[k][u], num[k]);
+          if (sb + u < nact) num[k] = fmaf(cw[(sb + u) * G + og[k]], v[k][u], num[k]);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -732,12 +737,13 @@ extern "C" int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_
 }
 
 extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
-                                   void* out, int H, int Hkv, int D, int max_len, float scale, const int* pos_dev,
+                                   void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
                                    float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream) {
   VG_CHECK(qkv && k_cache && v_cache && cos && sin && out && pos_dev && workspace, VG_ERR_ARG, "vg_decode_attention: null pointer");
   VG_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && D > 0 && D % 2 == 0 && max_len > 0, VG_ERR_ARG,
            "vg_decode_attention: bad shape H=%d Hkv=%d D=%d max_len=%d", H, Hkv, D, max_len);
   VG_CHECK(dtype == VG_BF16 || dtype == VG_F32, VG_ERR_ARG, "vg_decode_attention: bad dtype %d", dtype);
+  VG_CHECK(window >= 0, VG_ERR_ARG, "vg_decode_attention: window %d < 0", window);
   const int kpc = dtype == VG_BF16 ? 8 : 4, es = dtype == VG_BF16 ? 2 : 4;
   VG_CHECK(D % kpc == 0 && D * es <= 512, VG_ERR_UNSUPPORTED, "vg_decode_attention: head_dim %d unsupported (multiple of %d, <= %d)", D, kpc, 512 / es);
   VG_CHECK((((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) == 0, VG_ERR_ARG, "vg_decode_attention: caches must be 16-byte aligned");
@@ -745,7 +751,7 @@ extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache
   VG_CHECK(ws_floats >= need, VG_ERR_ARG, "vg_decode_attention: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
   const int nsplit = (max_len + 63) / 64;
   VG_CHECK(nsplit <= 128, VG_ERR_UNSUPPORTED, "vg_decode_attention: max_len %d > 8192", max_len);
-  DecAttnArgs p{qkv, k_cache, v_cache, cos, sin, out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale};
+  DecAttnArgs p{qkv, k_cache, v_cache, cos, sin, out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale, window};
   if (dtype == VG_BF16) return launch_decode_attn<bf16_t>(p, H / Hkv, (hipStream_t)stream);
   return launch_decode_attn<float>(p, H / Hkv, (hipStream_t)stream);
 }

@@ -67,6 +67,10 @@ def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_
     if os.path.exists(cfg_path):
         with open(cfg_path) as fh:
             hf = json.load(fh)
+        gen_path = os.path.join(model_dir, "generation_config.json")     # HF generate() stops on generation_config's eos ids
+        if os.path.exists(gen_path):
+            with open(gen_path) as fh:
+                hf["_generation_eos_token_id"] = json.load(fh).get("eos_token_id")
     if not any(k.startswith(IV2_PREFIX) for k in sd):
         vision_tower = vision_tower or (hf or {}).get("mm_vision_tower")
         if not vision_tower:
@@ -157,6 +161,20 @@ def derive_config(sd, hf=None, seg_token_idx=None):
     if seg_token_idx is None:
         seg_token_idx = hf.get("seg_token_idx", emb.shape[0] - 1)     # "[SEG]" is the last added token (R/chat.py:297-300)
     cfg = dict(seg_token_idx=int(seg_token_idx), iv2=iv2, clip=clip, llm=llm, sam2=sam2, projector_depth=depth)
-    if hf.get("eos_token_id") is not None:
-        cfg["eos_token_id"] = hf["eos_token_id"] if isinstance(hf["eos_token_id"], int) else hf["eos_token_id"][0]
+    eos = eos_ids(hf.get("eos_token_id"), hf.get("_generation_eos_token_id"))
+    if eos:
+        cfg["eos_token_id"] = eos     # every id HF's generate() would stop on (config.json + generation_config.json)
+    for k in ("bos_token_id", "pad_token_id"):
+        if hf.get(k) is not None:
+            cfg[k] = hf[k]
     return cfg
+
+
+def eos_ids(*sources):
+    """int / list / None values -> sorted list of distinct EOS ids (stock Phi-3-mini: generation_config eos = [32000, 32001, 32007])."""
+    out = set()
+    for s in sources:
+        if s is None:
+            continue
+        out.update([int(s)] if isinstance(s, int) else [int(x) for x in s])
+    return sorted(out)

@@ -34,6 +34,11 @@ class VideoGLaMMForCausalLM:
         self.config = _Cfg(dict(seg_token_idx=config["seg_token_idx"], use_sam2=True))
         self.dtype = torch_dtype
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            # the C-ABI launches go to HIP's CURRENT device and torch's current stream of it (ops._stream): bind this process to the
+            # model's device (one process per GPU) instead of launching on device 0 against device-k pointers
+            self.device = torch.device("cuda", torch.cuda.current_device() if self.device.index is None else self.device.index)
+            torch.cuda.set_device(self.device)
         self.use_sam2_video_branch = use_sam2_video_branch
         self.P = Params(state_dict, self.device, torch_dtype)
         self.towers = VisionTowers(self.P, self.cfg)
@@ -43,6 +48,9 @@ class VideoGLaMMForCausalLM:
         # what the reference's evaluation does on the host afterwards (remove_small_blobs(min_size=20),
         # R/eval_gcg_infer.py:20-29,182).  0 = the reference's inference() behaviour.
         self.min_blob_size = int(kwargs.get("min_blob_size", 0))
+        # diagnostics only: when set to a dict, inference() leaves the fp32 mask logits ("logits", device), the [SEG] embeddings
+        # ("emb") and the model's own per-step argmaxes ("argmax") in it (bench.py's self-check, tests)
+        self.capture = None
 
     @classmethod
     def from_pretrained(cls, path, config=None, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None,
@@ -91,6 +99,8 @@ class VideoGLaMMForCausalLM:
     def inference(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
                   max_new_tokens=32, use_sam2_video_branch=False):
         """R/model/VideoGLaMM.py:560-596."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         if use_sam2_video_branch:
             if self.config.use_sam2:
                 return self.inference_video_branch(images, context_images, images_for_sam, input_ids, resize_list,
@@ -105,7 +115,10 @@ class VideoGLaMMForCausalLM:
         ctx = context_images[0] if context_images is not None else None
         out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
-                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm)
+                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm,
+                                trace=self.capture)
+        if self.capture is not None:
+            self.capture["emb"] = emb
         return out_ids.unsqueeze(0), emb
 
     def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens):
@@ -177,6 +190,8 @@ class VideoGLaMMForCausalLM:
             masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=self._binarize)
         else:
             logits, _ = self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats)
+            if self.capture is not None:
+                self.capture["logits"] = logits
             masks = self._binarize(logits).cpu()
         return out_ids, [self._segments(masks)]
 
@@ -196,4 +211,6 @@ class VideoGLaMMForCausalLM:
             logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)
         else:
             logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
+        if self.capture is not None:
+            self.capture["logits"] = logits
         return out_ids, [self._segments(self._binarize(logits).cpu())]

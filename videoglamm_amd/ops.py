@@ -174,8 +174,18 @@ def bmm_nt(a, w, out_dtype=None):
     return out
 
 
-def attention(q, k, v, scale, causal=False):
-    """q: [B,Sq,Hq,D], k/v: [B,Skv,Hkv,D] (arbitrary batch/token/head strides, D contiguous) -> [B,Sq,Hq,D]."""
+def _causal_code(causal, window):
+    """the kernel's mask code: 0 none, 1 causal, c >= 2 causal with a sliding window of c visible keys (own position included)."""
+    if not causal:
+        assert not window, "a sliding window needs the causal mask"
+        return 0
+    assert window == 0 or window >= 2, "a window of one key cannot be expressed (and is not attention)"
+    return int(window) if window else 1
+
+
+def attention(q, k, v, scale, causal=False, window=0):
+    """q: [B,Sq,Hq,D], k/v: [B,Skv,Hkv,D] (arbitrary batch/token/head strides, D contiguous) -> [B,Sq,Hq,D].
+    window > 0 (with causal): every query sees its own position and the window - 1 before it (sliding-window LLMs)."""
     lib = _lib.load()
     B, Sq, Hq, D = q.shape
     Skv, Hkv = k.shape[1], k.shape[2]
@@ -192,7 +202,7 @@ def attention(q, k, v, scale, causal=False):
     rc = lib.vg_attention_splitkv(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
                                   q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                   v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
-                                  float(scale), int(bool(causal)), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit,
+                                  float(scale), _causal_code(causal, window), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit,
                                   None, _stream())
     _lib.check(rc, "vg_attention")
     return out
@@ -220,7 +230,7 @@ def attention_windows(q, k, v, scale):
     return out
 
 
-def attention_decode(q, k_cache, v_cache, pos_dev, scale):
+def attention_decode(q, k_cache, v_cache, pos_dev, scale, window=0):
     """One decode step against a growing KV cache: q [1,1,Hq,D]; k_cache/v_cache [max_len,Hkv,D]; the number of valid
     keys is *pos_dev + 1, read on the device (graph-replayable).  The split geometry is fixed by max_len."""
     lib = _lib.load()
@@ -232,7 +242,7 @@ def attention_decode(q, k_cache, v_cache, pos_dev, scale):
     rc = lib.vg_attention_splitkv(_p(q), _p(k_cache), _p(v_cache), _p(out), 1, Hq, Hkv, Sq, max_len, D,
                                   q.stride(0), q.stride(1), q.stride(2), 0, k_cache.stride(0), k_cache.stride(1),
                                   0, v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1), out.stride(2),
-                                  float(scale), 1, _dt(q), _p(ws), ws.numel(), nsplit, _p(pos_dev), _stream())
+                                  float(scale), _causal_code(True, window), _dt(q), _p(ws), ws.numel(), nsplit, _p(pos_dev), _stream())
     _lib.check(rc, "vg_attention_splitkv(decode)")
     return out
 
@@ -329,14 +339,14 @@ def decode_attention_workspace(H, Hkv, D, max_len, device):
     return torch.zeros(n, dtype=torch.float32, device=device)
 
 
-def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws):
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0):
     """Fused RoPE + KV append + attention of the one new token (vg_decode_attention): qkv [1,(H+2Hkv)*D] -> [1,H*D]."""
     lib = _lib.load()
     assert qkv.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and pos_dev.dtype == torch.int32
     max_len = k_cache.shape[0]
     out = torch.empty(1, H * D, dtype=qkv.dtype, device=qkv.device)
     rc = lib.vg_decode_attention(_p(qkv), _p(k_cache), _p(v_cache), _p(_f32(cos)), _p(_f32(sin)), _p(out), H, Hkv, D, max_len,
-                                 float(scale), _p(pos_dev), _p(ws), ws.numel(), _dt(qkv), _stream())
+                                 int(window), float(scale), _p(pos_dev), _p(ws), ws.numel(), _dt(qkv), _stream())
     _lib.check(rc, "vg_decode_attention")
     return out
 

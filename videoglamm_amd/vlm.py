@@ -163,8 +163,10 @@ class VisionTowers:
 class LlamaDecoder:
     """HF LlamaModel / Phi3Model arithmetic (RMSNorm, rotate-half RoPE, GQA attention, SwiGLU) with a KV cache.  Phi-3 (the
     released checkpoint's LLM, R/model/videogpt_plus/model/language_model/phi3.py:29-40) is the same graph with the
-    q|k|v and gate|up projections already fused in the checkpoint; its sliding window (cfg["sliding_window"], 2047 for
-    Phi-3-mini-4k) only matters past that many positions, which this path rejects instead of attending differently.
+    q|k|v and gate|up projections already fused in the checkpoint, and a sliding window: with cfg["sliding_window"] = w (2047 for
+    Phi-3-mini-4k) position i attends to positions [i - w, i] — w + 1 keys, the mask transformers==4.41.0 (the reference's pin) builds
+    in modeling_attn_mask_utils._make_causal_mask (diagonal = -w - 1) and its flash-attention path (window_size = (w, w)) — applied
+    inside the prefill and decode attention kernels.  The released model at the reference's default NUM_FRAMES = 16 (S ~ 3370) needs it.
 
     Prefill runs eagerly (sequence length varies per clip).  A decode step is fully static — the token id, the
     cache position and the KV length all live in device memory (tok_dev / pos_dev) — so it is captured ONCE into
@@ -177,8 +179,7 @@ class LlamaDecoder:
         self.D, self.H, self.Hkv = c["hidden"], c["num_heads"], c["num_kv_heads"]
         self.hd = self.D // self.H
         self.max_len = max_len
-        if c.get("sliding_window") and max_len > c["sliding_window"] + 1:
-            raise NotImplementedError(f"sequence budget {max_len} exceeds the sliding window {c['sliding_window']} of this LLM")
+        self.window = int(c["sliding_window"]) + 1 if c.get("sliding_window") else 0     # visible keys, own position included
         dev, dt = params.device, params.dtype
         self.kc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
         self.vc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
@@ -236,9 +237,10 @@ class LlamaDecoder:
             q = qkv[:, : self.H * self.hd].view(1, S, self.H, self.hd)
             if pos_dev is None:
                 n = pos0 + S
-                o = ops.attention(q, self.kc[i][:n].unsqueeze(0), self.vc[i][:n].unsqueeze(0), self.hd ** -0.5, causal=True)
+                o = ops.attention(q, self.kc[i][:n].unsqueeze(0), self.vc[i][:n].unsqueeze(0), self.hd ** -0.5, causal=True,
+                                  window=self.window)
             else:
-                o = ops.attention_decode(q, self.kc[i], self.vc[i], pos_dev, self.hd ** -0.5)
+                o = ops.attention_decode(q, self.kc[i], self.vc[i], pos_dev, self.hd ** -0.5, window=self.window)
             if f8:
                 x = ops.linear_f8(*ops.quantize_fp8(o.view(S, self.D)), *P.fp8(l + "self_attn.o_proj"), residual=x)
                 h = ops.rmsnorm(x, P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"])
@@ -265,7 +267,7 @@ class LlamaDecoder:
             wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
             qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
             o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
-                                     self.pos_dev, self.hd ** -0.5, self.attn_ws)
+                                     self.pos_dev, self.hd ** -0.5, self.attn_ws, window=self.window)
             x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
             if self.w8:
                 # fp8 weights + row scales for the MLP (81 % of a layer's bytes) — the attention projections stay bf16: at K = 4096
@@ -388,14 +390,17 @@ def splice(params, input_ids, visual):
 
 
 def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
-             forced_tokens=None, after_prefill=None, comm=None):
+             forced_tokens=None, after_prefill=None, comm=None, trace=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
     emitted.  forced_tokens {step: id} overrides the emitted token at given steps AFTER the full lm_head+argmax
     has been computed (synthetic-weight benchmarks need a [SEG] at a known position; no work is skipped).
+    trace: optional dict; trace["argmax"] receives the model's own argmax of every step (before any forcing).
+    eos_token_id: one id or several (HF generate() stops on any id of generation_config.eos_token_id).
     input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
     seg_idx = cfg["seg_token_idx"]
+    eos = set() if eos_token_id is None else ({int(eos_token_id)} if isinstance(eos_token_id, int) else {int(e) for e in eos_token_id})
     if visual is None:
         visual = towers.encode(images, context_images, comm)
     x = splice(params, input_ids, visual)
@@ -418,11 +423,13 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
         #                   overlaps the HBM-bound decode loop below
     for step in range(max_new_tokens):
         nxt = int(dec.tok_dev[0])
+        if trace is not None:
+            trace.setdefault("argmax", []).append(nxt)
         if forced_tokens and step in forced_tokens:
             nxt = int(forced_tokens[step])
             dec.tok_dev.fill_(nxt)
         ids.append(nxt)
-        if (eos_token_id is not None and nxt == eos_token_id) or step == max_new_tokens - 1:
+        if nxt in eos or step == max_new_tokens - 1:
             break
         dec.decode_step()
     out_ids = torch.tensor(ids, dtype=torch.int64)
