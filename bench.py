@@ -153,16 +153,17 @@ class AttnMeter:
     def __enter__(self):
         self.o_attn, self.o_win = self.ops.attention, self.ops.attention_windows
 
-        def timed(q, k, v, scale, causal=False):
+        def timed(q, k, v, scale, causal=False, window=0):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = self.o_attn(q, k, v, scale, causal)
+            y = self.o_attn(q, k, v, scale, causal, window)
             e1.record()
             B, Sq, H, D = q.shape
             Skv = k.shape[1]
             fl = 4.0 * B * H * Sq * Skv * D
-            if causal:
-                fl *= (Skv - Sq + (Sq + 1) / 2.0) / Skv
+            if causal:        # visible (query, key) pairs / all pairs; a window caps the keys per query
+                vis = sum(min(Skv - Sq + i + 1, window or Skv) for i in range(Sq)) if window else Sq * (Skv - Sq) + Sq * (Sq + 1) / 2.0
+                fl *= vis / (Sq * Skv)
             self.rec.append((fl, e0, e1, self.dp(D), (B, H, Sq, Skv, D)))
             return y
 

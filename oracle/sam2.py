@@ -458,6 +458,7 @@ def video_branch(sd, p, cfg, images, text_embeds, video_hw):
     cond = dict(maskmem_features=mem0, obj_ptr=ptr0)
     non_cond = {}
     outs = [low0]
+    trace["obj_ptr"], trace["maskmem"] = [ptr0], [mem0.float()]
     tpos = sd[p + "maskmem_tpos_enc"]
     for t in range(1, T):
         vf, vp, sizes = feats(t, N)
@@ -493,6 +494,8 @@ def video_branch(sd, p, cfg, images, text_embeds, video_hw):
         mem, _ = encode_new_memory(sd, p, cfg, vf[-1], o["high"], False)
         non_cond[t] = dict(maskmem_features=mem.to(torch.bfloat16), obj_ptr=o["obj_ptr"])
         outs.append(o["low"])
+        trace["obj_ptr"].append(o["obj_ptr"])
+        trace["maskmem"].append(non_cond[t]["maskmem_features"].float())
         if t == 1:
             trace["frame1_pix_feat_with_mem"] = pix
             trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
@@ -501,6 +504,7 @@ def video_branch(sd, p, cfg, images, text_embeds, video_hw):
     H, W = video_hw
     video_res = [F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False) for x in outs]
     trace["low_res"] = torch.stack(outs)
+    trace["obj_ptr"] = torch.stack(trace["obj_ptr"])          # [T,N,256]
     return video_res, trace
 
 

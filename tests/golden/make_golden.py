@@ -138,6 +138,42 @@ def gen_sam2():
     save("sam2_micro.npz", meta=np.array([T, N, H, W]), **out)
 
 
+from make_golden_keys import LONG_MEM_FRAMES  # noqa: E402
+
+
+def gen_sam2_long():
+    """video branch over T = 18 frames, N = 2 objects: past the 7-slot memory bank (t >= 8: the oldest memory drops out, the tpos slots
+    roll) and past the 16-pointer cap (t >= 17: the oldest non-conditioning pointer drops out) — R/.../sam2_base.py:536-633,
+    sam2_video_predictor.py:744-827.  The first 9 frames of this run ARE the T = 9 run of the same clip up to the pointer window
+    (min(T, 16) pointers: no difference before frame 16), so one fixture pins both lengths."""
+    m = build_ref_sam2()
+    S = SAM2_MICRO["image_size"]
+    T, N, H, W = 18, 2, 40, 56
+    images = rnd((T, 3, S, S), 41)
+    text = rnd((N, 256), 42, 0.5)
+    state = m.init_state_from_tensor(images, H, W)
+    m.reset_state(state)
+    for k in range(N):
+        m.add_new_text(inference_state=state, frame_idx=0, obj_id=k, text=text.unsqueeze(1)[k].unsqueeze(0))
+    vid = [logits.clone() for _, _, logits in m.propagate_in_video(state)]
+    od = state["output_dict"]
+    frames = [od["cond_frame_outputs"][0]] + [od["non_cond_frame_outputs"][t] for t in range(1, T)]
+    out = dict(meta=np.array([T, N, H, W]), video_logits=torch.stack(vid)[:, :, 0], low_res=torch.stack([f["pred_masks"] for f in frames]),
+               obj_ptr=torch.stack([f["obj_ptr"] for f in frames]))
+    for t in LONG_MEM_FRAMES:
+        out[f"maskmem_{t}"] = frames[t]["maskmem_features"].float()
+    # the same clip cut to 9 frames: must equal the first 9 frames of the long run (checked here, against the reference itself)
+    state9 = m.init_state_from_tensor(images[:9], H, W)
+    m.reset_state(state9)
+    for k in range(N):
+        m.add_new_text(inference_state=state9, frame_idx=0, obj_id=k, text=text.unsqueeze(1)[k].unsqueeze(0))
+    vid9 = torch.stack([logits.clone() for _, _, logits in m.propagate_in_video(state9)])[:, :, 0]
+    assert torch.equal(vid9, out["video_logits"][:9]), "T = 9 is not a prefix of T = 18 in the reference"
+    frac = (out["video_logits"] > 0).float().mean(dim=(1, 2, 3))
+    print("mask fraction per frame:", [round(float(f), 3) for f in frac])
+    save("sam2_video_long.npz", **out)
+
+
 def gen_vlm():
     ri.install()
     from model.videogpt_plus.model.internvideo.internvideo2 import PretrainInternVideo2
@@ -385,6 +421,8 @@ if __name__ == "__main__":
         gen_e2e_image()
     if what in ("sam2", "all"):
         gen_sam2()
+    if what in ("sam2_long", "all"):
+        gen_sam2_long()
     if what in ("vlm", "all"):
         gen_vlm()
     if what in ("phi3", "all"):

@@ -70,6 +70,34 @@ def run_checks(device, tol):
     assert ((vid.cpu() > 0) == (fx["video_logits"][:, :, 0] > 0)).float().mean() > 0.9995
 
 
+def run_long(device, tol):
+    """T = 18 / T = 9 video branch vs the reference (tests/golden/sam2_video_long.npz): memory-bank roll-over, pointer window."""
+    from make_golden_keys import LONG_MEM_FRAMES
+    fx = G.fixture("sam2_video_long.npz")
+    T, N, H, W = [int(v) for v in fx["meta"]]
+    m = build(device)
+    images, text = G.rnd((T, 3, m.S, m.S), 41).to(device), G.rnd((N, 256), 42, 0.5).to(device)
+    trace = {}
+    vid = m.video_branch(images, text, (H, W), trace)
+    torch.testing.assert_close(trace["low_res"].cpu(), fx["low_res"], **tol)
+    torch.testing.assert_close(trace["obj_ptr"].float().cpu(), fx["obj_ptr"], **tol)
+    torch.testing.assert_close(vid.cpu(), fx["video_logits"], **tol)
+    for t in LONG_MEM_FRAMES:       # [N, es*es, 64] token-major -> the reference's [N,64,es,es]; bf16-stored: one rounding step of slack
+        got = trace["maskmem"][t].float().cpu().view(N, 16, 16, 64).permute(0, 3, 1, 2)
+        torch.testing.assert_close(got, fx[f"maskmem_{t}"], rtol=1e-2, atol=2e-3)
+    vid9 = m.video_branch(images[:9], text, (H, W))
+    torch.testing.assert_close(vid9.cpu(), fx["video_logits"][:9], **tol)
+
+
+def test_video_long_cpu(cpu_ops):
+    run_long(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
+
+
+@pytest.mark.gpu
+def test_video_long_hip_fp32(cuda):
+    run_long(cuda, dict(rtol=1e-3, atol=1e-3))
+
+
 def test_host_graph_cpu(cpu_ops):
     run_checks(torch.device("cpu"), dict(rtol=1e-4, atol=2e-4))
 

@@ -65,3 +65,24 @@ def test_video_branch():
     torch.testing.assert_close(torch.stack(vid), fx["video_logits"], rtol=1e-3, atol=1e-3)
     # the masks the user finally sees
     assert ((torch.stack(vid) > 0) == (fx["video_logits"] > 0)).float().mean() > 0.9999
+
+
+def test_video_branch_long():
+    """T = 18, N = 2 (tests/golden/sam2_video_long.npz): the 7-slot memory bank rolls over from frame 8 and the 16-pointer window
+    from frame 17 (R/.../sam2_base.py:536-633); every frame's low-res logits, object pointers and bf16-rounded memories vs the
+    reference, and the T = 9 clip as a prefix (the generator checks the same property on the reference itself)."""
+    from make_golden_keys import LONG_MEM_FRAMES
+    fxl = G.fixture("sam2_video_long.npz")
+    Tl, Nl, Hl, Wl = [int(v) for v in fxl["meta"]]
+    S = cfg["image_size"]
+    imgs, txt = G.rnd((Tl, 3, S, S), 41), G.rnd((Nl, 256), 42, 0.5)
+    vid, trace = O.video_branch(sd, "", cfg, imgs, txt, (Hl, Wl))
+    tol = dict(rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(trace["low_res"], fxl["low_res"], **tol)
+    torch.testing.assert_close(trace["obj_ptr"], fxl["obj_ptr"], **tol)
+    torch.testing.assert_close(torch.stack(vid)[:, :, 0], fxl["video_logits"], **tol)
+    for t in LONG_MEM_FRAMES:
+        # memories are stored in bf16 (sam2_video_predictor.py:967,1011): a value on a rounding boundary may land one bf16 step apart
+        torch.testing.assert_close(trace["maskmem"][t], fxl[f"maskmem_{t}"], rtol=1e-2, atol=2e-3)
+    vid9, _ = O.video_branch(sd, "", cfg, imgs[:9], txt, (Hl, Wl))
+    torch.testing.assert_close(torch.stack(vid9)[:, :, 0], fxl["video_logits"][:9], **tol)

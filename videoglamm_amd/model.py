@@ -16,8 +16,50 @@ from .vlm import VisionTowers, generate
 
 
 class _Cfg:
+    """model.config: the attributes R/chat.py:296-331 reads and assigns (seg_token_idx, eos/bos/pad ids, use_sam2, ...)."""
+
     def __init__(self, d):
         self.__dict__.update(d)
+
+
+class _Tower:
+    """What get_vision_tower() / get_image_vision_tower() hand to R/chat.py:316-319,335-351: an object whose dtype / device
+    movers are no-ops — the towers' weights live in the model's packed parameter store and follow the model."""
+
+    def __init__(self, name):
+        self.name, self.is_loaded = name, True
+
+    def to(self, *a, **k):
+        return self
+
+    half = bfloat16 = float = cuda = eval = lambda self, *a, **k: self
+
+    def __repr__(self):
+        return f"<{self.name} (weights packed inside VideoGLaMMForCausalLM)>"
+
+
+class _Inner:
+    """model.get_model() / model.model: config + the vision-module initialisers of VideoGPTPlusMetaModel
+    (R/model/videogpt_plus/model/arch.py:14-85).  The reference builds and loads the towers there; here they arrive with the
+    checkpoint (ingest.load_state_dict), so the initialiser only checks that they are present."""
+
+    def __init__(self, outer):
+        self._outer = outer
+        self.config = outer.config
+        self.vision_tower = _Tower("InternVideo2 video tower")
+        self.image_vision_tower = _Tower("CLIP image tower")
+
+    def initialize_vision_modules(self, model_args=None, fsdp=None):
+        sd = self._outer.P.sd
+        for prefix in ("model.vision_tower.vision_encoder.", "model.image_vision_tower.vision_tower."):
+            if not any(k.startswith(prefix) for k in sd):
+                raise RuntimeError(f"no {prefix}* tensors in the checkpoint: pass vision_tower / image_vision_tower to from_pretrained")
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_image_vision_tower(self):
+        return self.image_vision_tower
 
 
 class VideoGLaMMForCausalLM:
@@ -31,7 +73,16 @@ class VideoGLaMMForCausalLM:
 
         _lib.load()  # fail loudly if the HIP extension is missing: there is no fallback path
         self.cfg = dict(config)
-        self.config = _Cfg(dict(seg_token_idx=config["seg_token_idx"], use_sam2=True))
+        self.config = _Cfg(dict(seg_token_idx=config["seg_token_idx"], use_sam2=True, eos_token_id=config.get("eos_token_id"),
+                                bos_token_id=config.get("bos_token_id"), pad_token_id=config.get("pad_token_id"),
+                                mm_use_im_start_end=False, mm_use_im_patch_token=False))
+        if torch_dtype == torch.float16:
+            raise NotImplementedError("the MI355X kernels compute in bfloat16 or float32 (same 16-bit storage as fp16, wider exponent): "
+                                      "pass torch_dtype=torch.bfloat16")
+        for k in ("load_in_8bit", "load_in_4bit", "quantization_config"):
+            if kwargs.get(k):
+                raise NotImplementedError(f"{k}: bitsandbytes quantisation (R/chat.py:247-272) is CUDA-only; the fp8 LLM path of this build is "
+                                          "cfg['llm']['decode_weights'] = cfg['llm']['prefill_gemm'] = 'fp8'")
         self.dtype = torch_dtype
         self.device = torch.device(device)
         if self.device.type == "cuda":
@@ -40,9 +91,8 @@ class VideoGLaMMForCausalLM:
             self.device = torch.device("cuda", torch.cuda.current_device() if self.device.index is None else self.device.index)
             torch.cuda.set_device(self.device)
         self.use_sam2_video_branch = use_sam2_video_branch
-        self.P = Params(state_dict, self.device, torch_dtype)
-        self.towers = VisionTowers(self.P, self.cfg)
-        self.sam2 = SAM2(self.P, "model.visual_model.", self.cfg["sam2"])
+        self._build(state_dict)
+        self.model = _Inner(self)
         self.comm = comm
         # > 0: clear 4-connected blobs smaller than this from the thresholded masks ON THE DEVICE, before they cross PCIe —
         # what the reference's evaluation does on the host afterwards (remove_small_blobs(min_size=20),
@@ -67,8 +117,83 @@ class VideoGLaMMForCausalLM:
             config = (hf or {}).get("videoglamm_amd") or ingest.derive_config(sd, hf, seg_token_idx)
         return cls(sd, config, **kwargs)
 
+    def _build(self, sd):
+        """(re)create the packed parameter store and the graphs over it for self.device / self.dtype (packing is lazy)."""
+        self.P = Params(sd, self.device, self.dtype)
+        self.towers = VisionTowers(self.P, self.cfg)
+        self.sam2 = SAM2(self.P, "model.visual_model.", self.cfg["sam2"])
+
+    # ------------------------------------------------------------------ start-up surface (R/chat.py:277-350)
     def eval(self):
         return self
+
+    def get_model(self):
+        return self.model
+
+    def resize_token_embeddings(self, new_num_tokens=None):
+        """HF PreTrainedModel.resize_token_embeddings as R/chat.py:300 uses it after tokenizer.add_tokens("[SEG]"): the input
+        embedding and the lm_head grow (or shrink) to new_num_tokens rows.  A released checkpoint already has the [SEG] row, so
+        this is the identity there.  New rows are ZERO here (HF draws them from N(0, initializer_range): values no checkpoint
+        pins) — a zero lm_head row can never win the argmax, i.e. an untrained token is never emitted."""
+        sd = self.P.sd
+        rows = sd["model.embed_tokens.weight"].shape[0]
+        if new_num_tokens is None or new_num_tokens == rows:
+            return self
+        for name in ("model.embed_tokens.weight", "lm_head.weight"):
+            w = sd[name]
+            if new_num_tokens < rows:
+                sd[name] = w[:new_num_tokens].contiguous()
+            else:
+                sd[name] = torch.cat([w, torch.zeros(new_num_tokens - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)])
+        self.cfg["llm"] = dict(self.cfg["llm"], vocab=int(new_num_tokens))
+        self._build(sd)
+        return self
+
+    def _cast(self, dtype=None, device=None):
+        dtype = self.dtype if dtype is None else dtype
+        device = self.device if device is None else torch.device(device)
+        if dtype == torch.float16:
+            raise NotImplementedError("float16 is not a compute type of this build: use .bfloat16() or .float()")
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if (dtype, device) != (self.dtype, self.device):
+            self.dtype, self.device = dtype, device
+            if device.type == "cuda":
+                torch.cuda.set_device(device)
+            self._build(self.P.sd)
+        return self
+
+    def bfloat16(self):
+        return self._cast(dtype=torch.bfloat16)
+
+    def float(self):
+        return self._cast(dtype=torch.float32)
+
+    def half(self):
+        return self._cast(dtype=torch.float16)
+
+    def cuda(self, device=None):
+        return self._cast(device="cuda" if device is None else (f"cuda:{device}" if isinstance(device, int) else device))
+
+    def to(self, *args, **kwargs):
+        dtype, device = kwargs.get("dtype"), kwargs.get("device")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            else:
+                device = f"cuda:{a}" if isinstance(a, int) else a
+        return self._cast(dtype, device)
+
+    def _live_cfg(self):
+        """the architecture config with the ids the caller may have (re)assigned on model.config (R/chat.py:303-307)."""
+        c = self.cfg
+        seg = getattr(self.config, "seg_token_idx", c["seg_token_idx"])
+        return c if seg == c["seg_token_idx"] else dict(c, seg_token_idx=seg)
+
+    def _eos(self):
+        """ids generation stops on: the checkpoint's (config.json + generation_config.json) and model.config.eos_token_id."""
+        from .ingest import eos_ids
+        return eos_ids(self.cfg.get("eos_token_id"), getattr(self.config, "eos_token_id", None)) or None
 
     # ------------------------------------------------------------------ forward surface
     def forward(self, **kwargs):
@@ -89,7 +214,7 @@ class VideoGLaMMForCausalLM:
         assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
         hw = tuple(label_list[0].shape[-2:])
         ids = input_ids[0].cpu()
-        _, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), context_images[0].to(self.device), ids, 0)
+        _, emb = generate(self.P, self._live_cfg(), self.towers, images[0].to(self.device), context_images[0].to(self.device), ids, 0)
         if emb.shape[0] == 0:
             return {"pred_masks": [[torch.zeros(0, *hw, device=self.device) for _ in range(len(images_for_sam[0]))]], "gt_masks": masks_list}
         logits, _ = self.sam2.framewise_branch(images_for_sam[0].to(self.device), emb, hw)
@@ -113,8 +238,8 @@ class VideoGLaMMForCausalLM:
         assert len(images) == 1 and input_ids.shape[0] == 1  # batch size is 1 (VideoGLaMM.py:252-253)
         # context_images=None: single-image prompt (CLIP -> image_mm_projector without pooling, arch.py:243-245,393-397)
         ctx = context_images[0] if context_images is not None else None
-        out_ids, emb = generate(self.P, self.cfg, self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
-                                input_ids[0].cpu(), max_new_tokens, self.cfg.get("eos_token_id"),
+        out_ids, emb = generate(self.P, self._live_cfg(), self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
+                                input_ids[0].cpu(), max_new_tokens, self._eos(),
                                 forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm,
                                 trace=self.capture)
         if self.capture is not None:

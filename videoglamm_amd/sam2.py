@@ -376,10 +376,13 @@ class SAM2:
         if trace is not None:
             trace["frame0_low_multi_pre_where"] = torch.cat([o["low_multi_pre_where"] for o in outs0])
             trace["frame0_obj_logits"] = torch.cat([o["obj_logits"] for o in outs0])
+            trace["obj_ptr"], trace["maskmem"] = [ptr0], []
         # preflight: consolidate + memory-encode frame 0 (binarised mask, is_mask_from_pts=True)
         high0 = ops.bilinear(low0.view(N, 4 * es, 4 * es), self.S, self.S).view(N, 1, self.S, self.S)
         top0 = fpn0[2].view(1, hw, 256).expand(N, -1, -1).contiguous()
         cond = dict(mem=self.encode_new_memory(top0, high0, True), ptr=ptr0)
+        if trace is not None:
+            trace["maskmem"].append(cond["mem"])
         non_cond = {}
         lows = [low0]
         tpos = self.P.t(self.p + "maskmem_tpos_enc").view(7, 64)
@@ -408,12 +411,16 @@ class SAM2:
             non_cond[t] = dict(mem=self.encode_new_memory(top, o["high"], False), ptr=o["obj_ptr"])
             non_cond.pop(t - 16, None)
             lows.append(o["low"])
+            if trace is not None:
+                trace["obj_ptr"].append(o["obj_ptr"])
+                trace["maskmem"].append(non_cond[t]["mem"])
             if trace is not None and t == 1:
                 trace["frame1_pix_feat_with_mem"] = pix
                 trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
         low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
         if trace is not None:
             trace["low_res"] = low
+            trace["obj_ptr"] = torch.stack(trace["obj_ptr"])       # [T,N,256]; trace["maskmem"][t]: [N, es*es, 64] (bf16-rounded)
         return ops.bilinear(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
 
     def video_branch_graphed(self, images, text_embeds, video_hw, frame_feats):
