@@ -293,6 +293,15 @@ int vg_boundary_counts(const uint8_t* fg, const uint8_t* gt, int64_t* out, int N
  * bicubic resize at R/utils/enc_preprocessors.py:120-166. */
 int vg_resample_u8(const uint8_t* in, uint8_t* out, int N, int H, int W, int C, int out_size, int axis,
                    const int32_t* bounds, const int32_t* coeffs, int ksize, vg_stream_t stream);
+/* OpenCV's cv2.resize(img, (Wo, Ho)) with the default INTER_LINEAR on N uint8 images [N,H,W,C] -> [N,Ho,Wo,C]: the InternVideo2
+ * stream of the reference's pre-processing (R/model/videogpt_plus/model/internvideo/utils.py:124).  2 taps per axis in 11-bit
+ * fixed point (imgproc/src/resize.cpp: HResizeLinear + VResizeLinear with FixedPtCast<int, uchar, 22>), no antialiasing.
+ * xi / yi: int32 [Wo,2] / [Ho,2] source indices (already clamped), xa / yb: int32 [Wo,2] / [Ho,2] taps (sum 2048), computed by
+ * the host in OpenCV's float32 arithmetic (videoglamm_amd/host.py:cv_linear_taps).  An exact 2x down-scale on both axes takes
+ * the INTER_AREA fast path cv::resize re-routes it to ((a+b+c+d+2)>>2; tables may be NULL).  H == Ho && W == Wo is refused. */
+int vg_resize_cv_linear_u8(const uint8_t* in, uint8_t* out, int N, int H, int W, int C, int Ho, int Wo, const int32_t* xi,
+                           const int32_t* xa, const int32_t* yi, const int32_t* yb, vg_stream_t stream);
+
 /* in:[N,H,W,3] uint8, crop (top,left,h,w) -> out:[N,3,h,w] planar.  mean / std: three doubles each on the HOST.
  * mode 0: fp32 (x - mean) / std on 0..255 values (SAM: R/utils/sam_transforms.py:50-55);
  * mode 1: (x / 255 - mean) / std evaluated in fp64, rounded once (the encoder processors' numpy arithmetic,

@@ -346,6 +346,18 @@ def resample_u8(x, out_size, axis, bounds, coeffs):
     return torch.from_numpy(_n.ascontiguousarray(_n.moveaxis(out, 0, 2 if axis == 1 else 1)))
 
 
+def resize_cv_linear_u8(x, Ho, Wo, xi=None, xa=None, yi=None, yb=None):
+    """numpy statement of vg_resize_cv_linear_u8: the two fixed-point passes from the given index / tap tables."""
+    import numpy as _n
+    a = x.numpy().astype(_n.int64)
+    if xi is None:
+        return torch.from_numpy(((a[:, 0::2, 0::2] + a[:, 0::2, 1::2] + a[:, 1::2, 0::2] + a[:, 1::2, 1::2] + 2) >> 2).astype(_n.uint8))
+    xi, xa, yi, yb = (t.numpy().astype(_n.int64) for t in (xi, xa, yi, yb))
+    rows = a[:, :, xi[:, 0]] * xa[None, None, :, 0, None] + a[:, :, xi[:, 1]] * xa[None, None, :, 1, None]
+    out = (((yb[None, :, 0, None, None] * (rows[:, yi[:, 0]] >> 4)) >> 16) + ((yb[None, :, 1, None, None] * (rows[:, yi[:, 1]] >> 4)) >> 16) + 2) >> 2
+    return torch.from_numpy(out.astype(_n.uint8))
+
+
 def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
     import numpy as _n
     top, left, h, w = crop if crop is not None else (0, 0, x.shape[1], x.shape[2])

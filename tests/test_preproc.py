@@ -47,6 +47,67 @@ def test_product_coefficient_tables():
             np.testing.assert_array_equal(k, k2)
 
 
+# ------------------------------------------------------------------------------------------------ OpenCV INTER_LINEAR (InternVideo2 stream)
+CV_SIZES = [((37, 53), (224, 224)), ((480, 640), (224, 224)), ((448, 448), (224, 224)), ((224, 224), (224, 224)), ((300, 225), (224, 224)),
+            ((225, 223), (224, 224)), ((5, 7), (3, 2)), ((64, 80), (37, 53)), ((1, 9), (4, 4)), ((720, 1280), (224, 224))]
+
+
+def test_cv2_linear_properties_and_hand_vectors():
+    """OpenCV is absent (source absent: parity unpinned against cv2 itself): the restatement is anchored on what cv2.resize is known to
+    do — identity at equal size, the exact 2x2 box mean at 2x down-scaling (the INTER_AREA re-route), constants preserved, 2-tap support
+    without antialiasing — and on vectors computed by hand from the published fixed-point formulas."""
+    from videoglamm_amd import host
+    for fn in (OP.cv2_resize_linear_u8, host.cv2_resize_linear_u8):
+        img = image((40, 56), 3)
+        np.testing.assert_array_equal(fn(img, (40, 56)), img)
+        big = image((48, 64), 4).astype(np.int64)
+        box = ((big[0::2, 0::2] + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        np.testing.assert_array_equal(fn(big.astype(np.uint8), (24, 32)), box)
+        for v in (0, 1, 77, 254, 255):
+            assert np.unique(fn(np.full((10, 12, 3), v, np.uint8), (23, 31))).tolist() == [v]
+        # one row, 4 -> 3 pixels: fx = (d + 0.5) * 4/3 - 0.5 = 1/6, 3/2, 17/6 -> (s, f) = (0, 1/6), (1, 1/2), (2, 5/6);
+        # taps round(2048 * {1 - f, f}) = (1707, 341), (1024, 1024), (341, 1707); rows: same row twice with (b0, b1) from
+        # fy = (0 + 0.5) * 1 - 0.5 = 0 -> (2048, 0) [same height would be a copy, so use 2 -> 2 rows via a 2 x 4 -> 2 x 3 call]
+        row = np.array([[[10], [200], [30], [255]]], np.uint8).repeat(2, axis=0)          # [2,4,1], two equal rows
+        s = [10 * 1707 + 200 * 341, 200 * 1024 + 30 * 1024, 30 * 341 + 255 * 1707]
+        want = [(((2048 * (v >> 4)) >> 16) + 0 + 2) >> 2 for v in s]
+        got = fn(row, (2, 3))
+        assert got[:, :, 0].tolist() == [want, want], (got[:, :, 0].tolist(), want)
+        # no antialiasing: at 8x down-scaling an output pixel sees 2 source pixels per axis, not the 8x8 area
+        spike = np.zeros((64, 64, 1), np.uint8)
+        spike[5, 5] = 255                                           # between the taps of every output pixel (taps at 3,4 and 11,12)
+        assert fn(spike, (8, 8)).max() == 0
+        # up-scaling 2x: interior taps are (1536, 512) / (512, 1536) on both axes
+        up = fn(np.array([[[0], [100]], [[0], [100]]], np.uint8), (2, 4))      # rows equal -> pure horizontal
+        assert up[0, :, 0].tolist() == [0, 25, 75, 100]
+
+
+def test_cv2_linear_host_equals_oracle():
+    from videoglamm_amd import host
+    for i, (src, dst) in enumerate(CV_SIZES):
+        for smooth in (False, True):
+            img = image(src, 50 + i, smooth=smooth)
+            np.testing.assert_array_equal(host.cv2_resize_linear_u8(img, dst), OP.cv2_resize_linear_u8(img, dst))
+    # upscaling by a 2-tap filter: Pillow's bilinear has the same support there, the two differ by rounding only
+    img = image((37, 53), 9)
+    pil = np.array(Image.fromarray(img).resize((224, 224), Image.BILINEAR)).astype(int)
+    assert np.abs(pil - host.cv2_resize_linear_u8(img, (224, 224)).astype(int)).max() <= 1
+    # down-scaling: Pillow antialiases (support grows with the scale), cv2 does not — the streams must NOT be the same any more
+    img = image((480, 640), 10)
+    pil = np.array(Image.fromarray(img).resize((224, 224), Image.BILINEAR)).astype(int)
+    assert np.abs(pil - host.cv2_resize_linear_u8(img, (224, 224)).astype(int)).max() > 30
+
+
+@pytest.mark.gpu
+def test_resize_cv_hip(cuda):
+    from videoglamm_amd import preproc as PP
+    for i, (src, dst) in enumerate(CV_SIZES):
+        imgs = np.stack([image(src, 70 + 10 * i + n, smooth=n == 1) for n in range(3)])
+        got = PP.resize_cv_u8(torch.from_numpy(imgs).to(cuda), dst).cpu().numpy()
+        for n in range(3):
+            np.testing.assert_array_equal(got[n], OP.cv2_resize_linear_u8(imgs[n], dst))
+
+
 # ------------------------------------------------------------------------------------------------ pipeline vs host.py
 def check_pipeline(device, hw, T, num_frames):
     from videoglamm_amd import host, preproc as PP

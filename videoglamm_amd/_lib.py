@@ -67,6 +67,7 @@ def _sig(lib):
         "vg_mask_pair_counts": ([P, P, P, P, I, I, L, I, P], c_int),
         "vg_boundary_counts": ([P, P, P, I, I, I, I, P], c_int),
         "vg_resample_u8": ([P, P, I, I, I, I, I, I, P, P, I, P], c_int),
+        "vg_resize_cv_linear_u8": ([P, P, I, I, I, I, I, I, P, P, P, P, P], c_int),
         "vg_normalize_u8": ([P, P, I, I, I, I, I, I, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), I, I, P], c_int),
     }
     for name, (args, res) in S.items():

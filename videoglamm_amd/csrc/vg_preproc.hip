@@ -5,6 +5,7 @@
 //   resample_u8_kernel : one 8-bit pass of Pillow's separable resampler (Resample.c ImagingResampleHorizontal_8bpc /
 //                        Vertical_8bpc): out = clip8((2^21 + sum_k in[xmin + k] * coeff[k]) >> 22), integer
 //                        coefficients from the host (videoglamm_amd/preproc.py).  Bit-exact with Image.resize.
+//   resize_cv_linear_kernel: OpenCV's 8-bit INTER_LINEAR resize (the InternVideo2 stream: cv2.resize in the reference)
 //   normalize_u8_kernel: uint8 HWC (optional crop) -> planar CHW: SAM's (x - mean) / std in fp32 on 0..255 values
 //                        (R/utils/sam_transforms.py:50-55), or (x / 255 - mean) / std evaluated in fp64 (the numpy
 //                        arithmetic of the encoder processors, R/utils/enc_preprocessors.py:120-166).
@@ -55,6 +56,34 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* in, uint
   out[((int64_t)blockIdx.z * Ho + yo) * rowbytes + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
 }
 
+// OpenCV's 8-bit INTER_LINEAR resize (imgproc/src/resize.cpp): 2 taps per axis in 11-bit fixed point, both passes in one
+// kernel — one thread per output byte (x, c flattened: a wave reads runs of neighbouring bytes of two source rows).
+//   S(row) = in[row, x0] * a0 + in[row, x1] * a1                                    (HResizeLinear, int32)
+//   out    = (((b0 * (S(y0) >> 4)) >> 16) + ((b1 * (S(y1) >> 4)) >> 16) + 2) >> 2   (VResizeLinear, FixedPtCast<.., 22>)
+// area2 != 0: the exact 2x down-scale, which cv::resize re-routes to the INTER_AREA fast path: (a + b + c + d + 2) >> 2.
+__global__ __launch_bounds__(256) void resize_cv_linear_kernel(const uint8_t* in, uint8_t* out, int H, int W, int C, int Ho, int Wo,
+                                                               const int32_t* xi, const int32_t* xa, const int32_t* yi, const int32_t* yb, int area2) {
+  const int64_t rowb = (int64_t)Wo * C;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rowb) return;
+  const int yo = blockIdx.y, n = blockIdx.z;
+  const int xo = (int)(i / C), c = (int)(i % C);
+  const uint8_t* img = in + (int64_t)n * H * W * C;
+  int v;
+  if (area2) {
+    const uint8_t* r0 = img + ((int64_t)(2 * yo) * W + 2 * xo) * C + c;
+    const uint8_t* r1 = r0 + (int64_t)W * C;
+    v = ((int)r0[0] + (int)r0[C] + (int)r1[0] + (int)r1[C] + 2) >> 2;
+  } else {
+    const int x0 = xi[2 * xo] * C + c, x1 = xi[2 * xo + 1] * C + c, a0 = xa[2 * xo], a1 = xa[2 * xo + 1];
+    const uint8_t* r0 = img + (int64_t)yi[2 * yo] * W * C;
+    const uint8_t* r1 = img + (int64_t)yi[2 * yo + 1] * W * C;
+    const int s0 = (int)r0[x0] * a0 + (int)r0[x1] * a1, s1 = (int)r1[x0] * a0 + (int)r1[x1] * a1;
+    v = (((yb[2 * yo] * (s0 >> 4)) >> 16) + ((yb[2 * yo + 1] * (s1 >> 4)) >> 16) + 2) >> 2;
+  }
+  out[((int64_t)n * Ho + yo) * rowb + i] = (uint8_t)v;
+}
+
 struct NormArgs {
   const uint8_t* in;
   void* out;
@@ -95,6 +124,20 @@ extern "C" int vg_resample_u8(const uint8_t* in, uint8_t* out, int N, int H, int
     const int64_t rowbytes = (int64_t)W * C;
     resample_v_kernel<<<dim3((unsigned)((rowbytes + 255) / 256), out_size, N), 256, 0, st>>>(in, out, H, rowbytes, out_size, bounds, coeffs, ksize);
   }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_resize_cv_linear_u8(const uint8_t* in, uint8_t* out, int N, int H, int W, int C, int Ho, int Wo, const int32_t* xi,
+                                      const int32_t* xa, const int32_t* yi, const int32_t* yb, vg_stream_t stream) {
+  VG_CHECK(in && out, VG_ERR_ARG, "vg_resize_cv_linear_u8: null pointer");
+  VG_CHECK(N > 0 && H > 0 && W > 0 && C >= 1 && C <= 4 && Ho > 0 && Wo > 0 && Ho <= 65535 && N <= 65535, VG_ERR_ARG,
+           "vg_resize_cv_linear_u8: bad shape N=%d H=%d W=%d C=%d -> %dx%d", N, H, W, C, Ho, Wo);
+  const int area2 = (H == 2 * Ho && W == 2 * Wo) ? 1 : 0;
+  VG_CHECK(area2 || (xi && xa && yi && yb), VG_ERR_ARG, "vg_resize_cv_linear_u8: tap tables missing");
+  VG_CHECK(!(H == Ho && W == Wo), VG_ERR_ARG, "vg_resize_cv_linear_u8: same size (cv::resize copies; so should the caller)");
+  const int64_t rowb = (int64_t)Wo * C;
+  resize_cv_linear_kernel<<<dim3((unsigned)((rowb + 255) / 256), Ho, N), 256, 0, (hipStream_t)stream>>>(in, out, H, W, C, Ho, Wo, xi, xa, yi, yb, area2);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

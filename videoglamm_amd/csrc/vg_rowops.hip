@@ -213,7 +213,9 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
     if (vec && C <= 256 * NV * 4 && grid.x > pgrid) grid.x = pgrid;
     if (vec) norm_kernel<TI, TO, RMS, 256, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
     else norm_kernel<TI, TO, RMS, 256, false><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
-  } else if (vec && C <= 512) {   // short rows (Hiera stage 1-2: C = 144 / 288): 16 lanes per row, 16 rows per workgroup
+  } else if (vec && C <= 16 * NV * 4) {   // short rows (Hiera stage 1-2: C = 144 / 288 in bf16): 16 lanes per row, 16 rows per workgroup.
+    // Only rows that fit the 16-lane register-resident path come here: that path is persistent, the fall-back below it is one
+    // row group per workgroup and must never see a capped grid (r02: fp32 rows of 256 < C <= 512 were capped at 32768 rows)
     dim3 grid((unsigned)((rows + 15) / 16 < (int64_t)pgrid ? (rows + 15) / 16 : (int64_t)pgrid));
     norm_kernel<TI, TO, RMS, 16, true><<<grid, 256, 0, st>>>(xi, ldx, w, b, yo, ldy, rows, C, eps);
   } else {

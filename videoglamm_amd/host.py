@@ -61,11 +61,45 @@ def sam_preprocess(frame_u8, img_size=1024):
     return x, (th, tw)
 
 
-def iv2_preprocess(frame_u8, size=224):
-    """VideoTrainProcessor.frames2tensor — R/.../internvideo/utils.py:105-143 (cv2.resize bilinear + ImageNet norm)."""
-    from PIL import Image
+def cv_linear_taps(in_size, out_size, clamp_frac):
+    """Taps of OpenCV's INTER_LINEAR resize for 8-bit images (imgproc/src/resize.cpp, resizeGeneric_ with INTER_RESIZE_COEF_BITS = 11):
+    f = float32((d + 0.5) * scale - 0.5), s = floor(f), f -= s, taps = round_half_even({1 - f, f} * 2048).  Horizontal rule
+    (clamp_frac): f = 0 at the borders (s < 0 or s >= in_size - 1); vertical rule: f kept, the two row indices clamped.
+    -> (index0 int32 [out], index1 int32 [out], taps int32 [out, 2])."""
+    scale = 1.0 / (float(out_size) / float(in_size))
+    f = ((np.arange(out_size, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_frac:
+        f = np.where((s < 0) | (s >= in_size - 1), np.float32(0.0), f).astype(np.float32)
+    taps = np.stack([np.rint((np.float32(1.0) - f) * np.float32(2048.0)), np.rint(f * np.float32(2048.0))], axis=1).astype(np.int32)
+    return np.clip(s, 0, in_size - 1).astype(np.int32), np.clip(s + 1, 0, in_size - 1).astype(np.int32), taps
 
-    x = _pil_resize(frame_u8, (size, size), Image.BILINEAR).astype(np.float64)
+
+def cv2_resize_linear_u8(img, hw):
+    """cv2.resize(img, (w, h)) with the default INTER_LINEAR on an [H,W,C] uint8 image — what the reference's InternVideo2
+    processor runs (R/model/videogpt_plus/model/internvideo/utils.py:124); a 2-tap, NON-antialiased filter in 11-bit fixed
+    point, not Pillow's area-weighted triangle.  OpenCV is absent from this image: its published algorithm (4.x resize.cpp)
+    is restated — same size: copy; exact 2x down-scale: the INTER_AREA fast path, (a + b + c + d + 2) >> 2; otherwise
+    HResizeLinear (int32 row sums) + VResizeLinear (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    h, w = hw
+    H, W = img.shape[:2]
+    if (H, W) == (h, w):
+        return img.copy()
+    src = img.astype(np.int32)
+    if H == 2 * h and W == 2 * w:
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x0, x1, xa = cv_linear_taps(W, w, True)
+    y0, y1, yb = cv_linear_taps(H, h, False)
+    rows = src[:, x0] * xa[None, :, 0, None] + src[:, x1] * xa[None, :, 1, None]          # [H, w, C] int32
+    out = (((yb[:, 0, None, None] * (rows[y0] >> 4)) >> 16) + ((yb[:, 1, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def iv2_preprocess(frame_u8, size=224):
+    """VideoTrainProcessor.frames2tensor — R/.../internvideo/utils.py:105-143: cv2.resize (INTER_LINEAR) + (x/255 - mean)/std in
+    numpy float64, cast to fp32 by the caller's .float()."""
+    x = cv2_resize_linear_u8(frame_u8, (size, size)).astype(np.float64)
     x = (x / 255.0 - IV2_MEAN.reshape(1, 1, 3)) / IV2_STD.reshape(1, 1, 3)
     return torch.from_numpy(np.transpose(x, (2, 0, 1))).float()
 

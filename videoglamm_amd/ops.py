@@ -707,6 +707,21 @@ def resample_u8(x, out_size, axis, bounds, coeffs):
     return out
 
 
+def resize_cv_linear_u8(x, Ho, Wo, xi=None, xa=None, yi=None, yb=None):
+    """OpenCV's 8-bit INTER_LINEAR resize of x [N,H,W,C] uint8 -> [N,Ho,Wo,C]; index / tap tables int32 [Wo,2] / [Ho,2] on the device
+    (None for the exact 2x down-scale, which is OpenCV's area fast path)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.uint8 and x.dim() == 4
+    N, H, W, C = x.shape
+    for t, n in ((xi, Wo), (xa, Wo), (yi, Ho), (yb, Ho)):
+        assert t is None or (t.dtype == torch.int32 and t.shape == (n, 2) and t.is_contiguous())
+    out = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    rc = lib.vg_resize_cv_linear_u8(_p(x), _p(out), N, H, W, C, int(Ho), int(Wo), _p(xi), _p(xa), _p(yi), _p(yb), _stream())
+    _lib.check(rc, "vg_resize_cv_linear_u8")
+    return out
+
+
 def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
     """x [N,H,W,3] uint8 -> [N,3,h,w]; crop = (top, left, h, w); mode 0: fp32 (x - mean) / std, 1: fp64 (x / 255 - mean) / std."""
     lib = _lib.load()

@@ -1,14 +1,15 @@
 """Row H1 of SURVEY.md §8a on the device (§8f row 1): frame sub-sampling stays on the host (index arithmetic), the
 decoded uint8 frames are uploaded ONCE and the three model inputs are produced in HBM by csrc/vg_preproc.hip:
 
-    images          [Te,3,224,224]   bilinear resize, (x/255 - mean)/std        R/.../internvideo/utils.py:105-143
+    images          [Te,3,224,224]   cv2.resize (INTER_LINEAR), (x/255 - mean)/std R/.../internvideo/utils.py:105-143
     context_images  [Te,3,336,336]   CLIP processor: bicubic short side 336, centre crop, /255, mean/std
                                                                                  R/utils/enc_preprocessors.py:120-166
     images_for_sam  [T,3,1024,1024]  resize longest side, (x - mean)/std, bilinear stretch to 1024^2
                                                                                  R/utils/sam_transforms.py:26-65
 
-Same results as videoglamm_amd/host.py (bit for bit: the resampler is Pillow's integer arithmetic, whose coefficient
-tables are computed here in float64 exactly like Pillow's precompute_coeffs / normalize_coeffs_8bpc), at 0.75 MB of
+Same results as videoglamm_amd/host.py (bit for bit: the SAM / CLIP resampler is Pillow's integer arithmetic, whose coefficient
+tables are computed here in float64 exactly like Pillow's precompute_coeffs / normalize_coeffs_8bpc; the InternVideo2 stream is
+OpenCV's 11-bit fixed-point INTER_LINEAR with the tap tables of host.cv_linear_taps), at 0.75 MB of
 PCIe traffic per 512^2 frame instead of 12.6 MB per SAM frame plus the encoder tensors.
 """
 import functools
@@ -89,8 +90,26 @@ def sam_preprocess(frames, img_size=1024):
     return x, (th, tw)
 
 
+@functools.lru_cache(maxsize=64)
+def _cv_taps_on(device, in_size, out_size, clamp_frac):
+    i0, i1, taps = host.cv_linear_taps(in_size, out_size, clamp_frac)
+    return torch.from_numpy(np.stack([i0, i1], 1).astype(np.int32)).to(device), torch.from_numpy(np.ascontiguousarray(taps)).to(device)
+
+
+def resize_cv_u8(x, hw):
+    """cv2.resize(img, (w, h)) (INTER_LINEAR) of every image of x [N,H,W,C] uint8 (device): one launch, both passes."""
+    h, w = hw
+    if tuple(x.shape[1:3]) == (h, w):
+        return x
+    if x.shape[1] == 2 * h and x.shape[2] == 2 * w:
+        return ops.resize_cv_linear_u8(x, h, w)
+    xi, xa = _cv_taps_on(x.device, x.shape[2], w, True)
+    yi, yb = _cv_taps_on(x.device, x.shape[1], h, False)
+    return ops.resize_cv_linear_u8(x, h, w, xi, xa, yi, yb)
+
+
 def iv2_preprocess(frames, size=224):
-    x = resize_u8(_frames(frames), (size, size), "bilinear")
+    x = resize_cv_u8(_frames(frames), (size, size))
     return ops.normalize_u8(x, host.IV2_MEAN, host.IV2_STD, 1)
 
 
