@@ -218,6 +218,10 @@ int vg_window_unpartition(const void* win, void* x, int B, int H, int W, int C, 
 /* bilinear resize, align_corners=False, no antialias, planar fp32 [N,Hi,Wi] -> [N,Ho,Wo]
  * (F.interpolate at sam2_base.py:368-374, sam2_video_predictor.py:509-516, VideoGLaMM.py:147-153) */
 int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream);
+/* vg_bilinear + (logit > 0) in one pass: uint8 masks [N,Ho,Wo] (0 / 1) from low-resolution fp32 logits [N,Hi,Wi] — the final
+ * `postprocess_masks(...) > 0` / `video_res_masks > 0.0` of R/model/VideoGLaMM.py:147-153,757-766,869-875 without materialising
+ * the fp32 logits at output resolution.  Bit-identical to vg_threshold(vg_bilinear(x)). */
+int vg_bilinear_mask(const float* in, uint8_t* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream);
 /* y:[B,2H,2W,C] = lateral + nearest2x(top:[B,H,W,C])   (FPN top-down, image_encoder.py:113-127) */
 int vg_upsample2_add(const void* lateral, const void* top, void* y, int B, int H, int W, int C,
                      int dtype, vg_stream_t stream);

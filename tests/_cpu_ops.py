@@ -132,6 +132,10 @@ def mask_for_mem(x, binarize, scale, bias, out_dtype):
     return (m * scale + bias).to(out_dtype)
 
 
+def bilinear_mask(x, Ho, Wo):
+    return threshold(bilinear(x, Ho, Wo))
+
+
 def threshold(x):
     return (x > 0).to(torch.uint8)
 

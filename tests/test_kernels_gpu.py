@@ -315,6 +315,18 @@ def test_bilinear(cuda):
         close(ops.bilinear(x.to(cuda), Ho, Wo), ref.bilinear(x, Ho, Wo), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,Hi,Wi,Ho,Wo", [(3, 64, 64, 40, 56), (2, 256, 256, 1024, 1024), (5, 16, 16, 33, 31), (1, 64, 64, 480, 854), (4, 256, 256, 512, 512)])
+def test_bilinear_mask(cuda, N, Hi, Wi, Ho, Wo):
+    """the fused upsample + threshold == vg_threshold(vg_bilinear(x)) bit for bit (odd widths take the byte-store path)"""
+    from videoglamm_amd import ops
+    x = rnd(N, Hi, Wi, seed=7).to(cuda)
+    x[0, :3] = 0.0                      # exact zeros: "> 0" is strict
+    got = ops.bilinear_mask(x, Ho, Wo)
+    want = ops.threshold(ops.bilinear(x, Ho, Wo))
+    assert got.dtype == torch.uint8 and torch.equal(got, want)
+    assert torch.equal(got.cpu(), ref.threshold(ref.bilinear(x.cpu(), Ho, Wo)))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 16, 16, 8, 144, 432), (1, 20, 12, 7, 72, 40), (3, 64, 64, 14, 64, 192), (2, 8, 8, 4, 288, 288)])
 def test_gemm_window(cuda, dtype, B, H, W, ws, K, N):

@@ -17,7 +17,9 @@ shapes = [("llm qkv/o", 1697, 4096, 4096), ("llm gate|up", 1697, 28672, 4096), (
           ("clip qkv", 4616, 3072, 1024), ("clip fc1", 4616, 4096, 1024), ("clip fc2", 4616, 1024, 4096),
           ("hiera s1 qkv", 524288, 432, 144), ("hiera s1 fc1", 524288, 576, 144), ("hiera s2 qkv", 131072, 864, 288),
           ("hiera s3 qkv", 32768, 1728, 576), ("hiera s3 fc1", 32768, 2304, 576), ("hiera s3 fc2", 32768, 576, 2304),
-          ("hiera s4 fc1", 8192, 4608, 1152), ("square 4k", 4096, 4096, 4096), ("square 8k", 8192, 8192, 8192),
+          ("hiera s4 fc1", 8192, 4608, 1152), ("hiera s3 proj", 32768, 576, 576), ("hiera s4 qkv", 8192, 3456, 1152), ("hiera s4 fc2", 8192, 1152, 4608),
+          ("hiera s4 proj", 8192, 1152, 1152), ("hiera s2 fc1", 131072, 1152, 288), ("hiera s2 fc2", 131072, 288, 1152), ("hiera s1 fc2", 524288, 144, 576),
+          ("hiera s2 proj", 131072, 288, 288), ("square 4k", 4096, 4096, 4096), ("square 8k", 8192, 8192, 8192),
           ("sp8 qkv", 213, 6144, 4096), ("sp8 o", 213, 4096, 4096), ("sp8 gate|up", 213, 28672, 4096), ("sp8 down", 213, 4096, 14336),
           ("sp4 gate|up", 425, 28672, 4096), ("sp4 down", 425, 4096, 14336),
           ("sp2 o", 849, 4096, 4096), ("sp2 down", 849, 4096, 14336), ("sp2 qkv", 849, 6144, 4096),

@@ -60,6 +60,7 @@ def _sig(lib):
         "vg_window_partition": ([P, P, I, I, I, I, I, I, P], c_int),
         "vg_window_unpartition": ([P, P, I, I, I, I, I, I, P], c_int),
         "vg_bilinear": ([P, P, I, I, I, I, I, P], c_int),
+        "vg_bilinear_mask": ([P, P, I, I, I, I, I, P], c_int),
         "vg_upsample2_add": ([P, P, P, I, I, I, I, I, P], c_int),
         "vg_connected_components": ([P, P, P, I, I, I, I, P], c_int),
         "vg_remove_small_blobs": ([P, P, P, P, I, I, I, I, P], c_int),

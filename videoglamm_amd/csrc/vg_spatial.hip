@@ -206,6 +206,16 @@ extern "C" int vg_window_unpartition(const void* win, void* x, int B, int H, int
 }
 
 // PyTorch upsample_bilinear2d, align_corners=False: src = max((dst+0.5)*scale-0.5, 0), scale = in/out.
+// One body for the logits and for the fused "logits > 0" variant, so both evaluate the identical instruction sequence.
+__device__ __forceinline__ float bilinear_at(const float* p, int Hi, int Wi, int oy, int ox, float sh, float sw) {
+  float fy = ((float)oy + 0.5f) * sh - 0.5f; if (fy < 0.f) fy = 0.f;
+  float fx = ((float)ox + 0.5f) * sw - 0.5f; if (fx < 0.f) fx = 0.f;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+  return hy * (hx * p[(int64_t)y0 * Wi + x0] + lx * p[(int64_t)y0 * Wi + x1]) +
+         ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
+}
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo) {
   const int64_t n = (int64_t)N * Ho * Wo;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
@@ -214,20 +224,46 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* in, float* o
     int64_t r = i / Wo;
     const int oy = (int)(r % Ho);
     const int b = (int)(r / Ho);
-    float fy = ((float)oy + 0.5f) * sh - 0.5f; if (fy < 0.f) fy = 0.f;
-    float fx = ((float)ox + 0.5f) * sw - 0.5f; if (fx < 0.f) fx = 0.f;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float* p = in + (int64_t)b * Hi * Wi;
-    out[i] = hy * (hx * p[(int64_t)y0 * Wi + x0] + lx * p[(int64_t)y0 * Wi + x1]) +
-             ly * (hx * p[(int64_t)y1 * Wi + x0] + lx * p[(int64_t)y1 * Wi + x1]);
+    out[i] = bilinear_at(in + (int64_t)b * Hi * Wi, Hi, Wi, oy, ox, sh, sw);
   }
 }
 extern "C" int vg_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream) {
   VG_CHECK(in && out && N >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, VG_ERR_ARG, "vg_bilinear: bad args");
   if (N == 0) return VG_OK;
   bilinear_kernel<<<sp_grid((int64_t)N * Ho * Wo), 256, 0, (hipStream_t)stream>>>(in, out, N, Hi, Wi, Ho, Wo);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+// vg_bilinear followed by vg_threshold in one pass: the fp32 logits at output resolution (4 B written + 4 B read per pixel)
+// never reach HBM; a thread produces four neighbouring pixels = one 32-bit store.
+__global__ __launch_bounds__(256) void bilinear_mask_kernel(const float* in, uint8_t* out, int N, int Hi, int Wi, int Ho, int Wo) {
+  const int Wq = (Wo + 3) / 4;
+  const int64_t n = (int64_t)N * Ho * Wq;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  SP_LOOP(i, n) {
+    const int xq = (int)(i % Wq);
+    int64_t r = i / Wq;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const float* p = in + (int64_t)b * Hi * Wi;
+    uint8_t* o = out + ((int64_t)b * Ho + oy) * Wo + xq * 4;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ox = xq * 4 + e;
+      const float v = ox < Wo ? bilinear_at(p, Hi, Wi, oy, ox, sh, sw) : 0.f;
+      bits |= (v > 0.f ? 1u : 0u) << (8 * e);
+    }
+    if ((Wo & 3) == 0) *(uint32_t*)o = bits;
+    else
+      for (int e = 0; e < 4 && xq * 4 + e < Wo; ++e) o[e] = (uint8_t)((bits >> (8 * e)) & 1u);
+  }
+}
+extern "C" int vg_bilinear_mask(const float* in, uint8_t* out, int N, int Hi, int Wi, int Ho, int Wo, vg_stream_t stream) {
+  VG_CHECK(in && out && N >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, VG_ERR_ARG, "vg_bilinear_mask: bad args");
+  VG_CHECK((Wo & 3) || (((uintptr_t)out) & 3) == 0, VG_ERR_ARG, "vg_bilinear_mask: out must be 4-byte aligned");
+  if (N == 0) return VG_OK;
+  bilinear_mask_kernel<<<sp_grid((int64_t)N * Ho * ((Wo + 3) / 4)), 256, 0, (hipStream_t)stream>>>(in, out, N, Hi, Wi, Ho, Wo);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

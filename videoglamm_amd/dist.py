@@ -65,11 +65,12 @@ class FrameSharder:
     def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None, binarize=None):
         """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W].
         frame_feats: optional precomputed Hiera features of THIS rank's frames ({frame: [3 levels]});
-        binarize: logits -> uint8 masks of this rank's frames (per-frame work, so it shards with them); default logit > 0."""
+        binarize: logits -> uint8 masks of this rank's frames (per-frame work, so it shards with them); None = logit > 0, made
+        in one pass from the low-res logits."""
         emb = self.sync_seg_embeddings(emb)
         frames = self.my_frames(images_for_sam.shape[0])
-        logits, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats)
-        local = (binarize or ops.threshold)(logits)                        # [T/world, N, H, W] uint8, on device
+        out, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats, as_masks=binarize is None)
+        local = out if binarize is None else binarize(out)                 # [T/world, N, H, W] uint8, on device
         return torch.cat(self._all_gather(local), dim=0).cpu()
 
     def gather_frame_feats(self, local_feats, T):

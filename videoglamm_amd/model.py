@@ -278,9 +278,25 @@ class VideoGLaMMForCausalLM:
 
     @staticmethod
     def _segments(mask_u8):
-        """[T,N,H,W] uint8 on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875)."""
-        m = mask_u8.numpy().astype(bool)
+        """[T,N,H,W] uint8 (0 / 1) on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875)."""
+        m = mask_u8.numpy().view(bool)       # 0 / 1 bytes ARE numpy bools: no second pass over the clip's masks
         return {t: {k: m[t, k] for k in range(m.shape[1])} for t in range(m.shape[0])}
+
+    def _fast_masks(self):
+        """thresholded masks straight from the low-res logits (vg_bilinear_mask) unless something needs the fp32 logits"""
+        return self.capture is None and self.min_blob_size == 0
+
+    def _to_host(self, masks):
+        """device uint8 masks -> fresh host tensor through a pinned staging buffer (pageable D2H of 32 x 1024^2 masks costs ~5 ms)"""
+        if masks.device.type != "cuda":
+            return masks
+        n = masks.numel()
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin.numel() < n:
+            pin = self._pin = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        pin[:n].copy_(masks.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(masks.device).synchronize()
+        return pin[:n].clone().view(masks.shape)     # the caller keeps the masks: the staging buffer is reused by the next clip
 
     def _hiera_async(self, sam, frames=None):
         """Hiera + FPN of the SAM frames on a side HIP stream.  It depends only on the pixels, not on the LLM, and it is
@@ -312,12 +328,14 @@ class VideoGLaMMForCausalLM:
             raise AttributeError("'tuple' object has no attribute 'shape'")
         hw = tuple(original_size_list[0])
         if self.comm is not None:
-            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=self._binarize)
+            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=None if self._fast_masks() else self._binarize)
+        elif self._fast_masks():
+            masks = self._to_host(self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats, as_masks=True)[0])
         else:
             logits, _ = self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats)
             if self.capture is not None:
                 self.capture["logits"] = logits
-            masks = self._binarize(logits).cpu()
+            masks = self._to_host(self._binarize(logits))
         return out_ids, [self._segments(masks)]
 
     def inference_video_branch(self, images, context_images, images_for_sam, input_ids, resize_list, original_size_list,
@@ -334,8 +352,10 @@ class VideoGLaMMForCausalLM:
         if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "0") == "1":
             # the propagation replayed from a HIP graph: same results, measured neutral (r01: 201.05 vs 200.51 ms per clip), off by default
             logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)
+        elif self._fast_masks():
+            return out_ids, [self._segments(self._to_host(self.sam2.video_branch(sam, emb, hw, frame_feats=feats, as_masks=True)))]
         else:
             logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
         if self.capture is not None:
             self.capture["logits"] = logits
-        return out_ids, [self._segments(self._binarize(logits).cpu())]
+        return out_ids, [self._segments(self._to_host(self._binarize(logits)))]

@@ -610,6 +610,17 @@ def bilinear(x, Ho, Wo):
     return out
 
 
+def bilinear_mask(x, Ho, Wo):
+    """threshold(bilinear(x, Ho, Wo)) in one pass: x fp32 [N,Hi,Wi] -> uint8 [N,Ho,Wo] (1 where the interpolated logit > 0)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    N, Hi, Wi = x.shape
+    out = torch.empty(N, Ho, Wo, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.vg_bilinear_mask(_p(x), _p(out), N, Hi, Wi, Ho, Wo, _stream()), "vg_bilinear_mask")
+    return out
+
+
 def upsample2_add(lateral, top):
     lib = _lib.load()
     lateral = lateral.contiguous()

@@ -7,6 +7,7 @@ and the reference's NCHW<->(HW)NC permutes (R/.../sam2/modeling/sam2_base.py:479
 R/ = /root/reference/VideoGLaMM/model/segment_anything_2/sam2/.
 """
 import math
+import os
 
 import torch
 
@@ -75,7 +76,7 @@ class SAM2:
         self.S = cfg["image_size"]
         self.es = self.S // 16
         self.blocks, self.stage_ends = hiera_layout(cfg["trunk"])
-        self.frame_chunk = 8  # frames batched per Hiera / framewise-decode launch group
+        self.frame_chunk = int(os.environ.get("VG_FRAME_CHUNK", "8"))  # frames batched per Hiera / framewise-decode launch group
 
     def hiera_frames(self, images, frames=None):
         """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
@@ -347,7 +348,7 @@ class SAM2:
         return ops.cast(ops.cast(mem, torch.bfloat16), self.dtype)
 
     # ------------------------------------------------------------------ S10 video branch / S11 framewise
-    def video_branch(self, images, text_embeds, video_hw, trace=None, frame_feats=None):
+    def video_branch(self, images, text_embeds, video_hw, trace=None, frame_feats=None, as_masks=False):
         """init_state_from_tensor -> add_new_text per object -> propagate_in_video for one clip
         (R/model/VideoGLaMM.py:834-877; R/sam2_video_predictor.py:108-180,415-495,520-636,674-827,921-1017;
         R/modeling/sam2_base.py:495-664,706-803).  images [T,3,S,S]; text_embeds [N,256].
@@ -421,7 +422,8 @@ class SAM2:
         if trace is not None:
             trace["low_res"] = low
             trace["obj_ptr"] = torch.stack(trace["obj_ptr"])       # [T,N,256]; trace["maskmem"][t]: [N, es*es, 64] (bf16-rounded)
-        return ops.bilinear(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
+        up = ops.bilinear_mask if as_masks else ops.bilinear       # as_masks=True: uint8 (logit > 0) in one pass
+        return up(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
 
     def video_branch_graphed(self, images, text_embeds, video_hw, frame_feats):
         """video_branch() replayed from a HIP graph.  The propagation is ~150 small launches per frame with no host decision
@@ -455,9 +457,11 @@ class SAM2:
         g.replay()
         return out
 
-    def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None):
+    def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None, as_masks=False):
         """VideoGLaMM framewise decode — R/model/VideoGLaMM.py:205-241,676-766.  One mask-decoder batch per frame
-        (N objects, repeat_image), multimask_output=False with the stability fallback.  -> logits fp32 [T,N,H,W]."""
+        (N objects, repeat_image), multimask_output=False with the stability fallback.  -> (logits fp32 [T,N,H,W], low-res logits);
+        as_masks=True: the first value is the thresholded uint8 masks (logit > 0) instead, made in one pass from the low-res
+        logits (vg_bilinear_mask) — the fp32 logits at output resolution (134 MB for 32 x 1024^2) never exist."""
         N = text_embeds.shape[0]
         es, hw = self.es, self.es * self.es
         H, W = video_hw
@@ -487,4 +491,5 @@ class SAM2:
             low, _, _, _ = ops.multimask_select(masks, iou, toks, 0)
             lows.append(low.view(Tc, N, 1, 4 * es, 4 * es))
         low = torch.cat(lows, dim=0)                                             # [T,N,1,4es,4es]
-        return ops.bilinear(low.view(len(frames) * N, 4 * es, 4 * es), H, W).view(len(frames), N, H, W), low
+        up = ops.bilinear_mask if as_masks else ops.bilinear
+        return up(low.view(len(frames) * N, 4 * es, 4 * es), H, W).view(len(frames), N, H, W), low
