@@ -540,6 +540,15 @@ def main():
                                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
                                     "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
                                     "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2)}
+        if os.environ.get("VG_BENCH_ATTN_SHAPES") and rank == 0:      # per-shape table of the attention launches (stderr)
+            by = {}
+            for fl, e0, e1, dp, shp in am.rec:
+                a = by.setdefault(shp, [0.0, 0.0, 0])
+                a[0] += fl
+                a[1] += e0.elapsed_time(e1)
+                a[2] += 1
+            for shp, (fl, ms, n) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                print(f"attn (B,H,Sq,Skv,D)={shp}: {n} launches, {ms:.2f} ms, {1e3 * ms / n:.1f} us each, {fl / ms / 1e9:.1f} TF/s", file=sys.stderr)
         # "roofline" = the kernel with the most GPU time in a step; the others ride along under their own keys
         main = max(roofs, key=lambda k: roofs[k]["kernel_ms_per_step"])
         res["roofline"] = roofs.pop(main)

@@ -97,6 +97,15 @@ int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, in
                  int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
                  int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, vg_stream_t stream);
 
+/* Self-attention inside independent 256-token windows, one workgroup per (window, head) with the window's K and V staged once:
+ * O[w,i,h,:] = softmax_j(scale * Q[w,i,h,:].K[w,j,h,:]) @ V[w,j,h,:], i, j in [0, 256).  Hiera's 16x16 windows (stage 3 of
+ * Hiera-B+/L: MultiScaleAttention on window_partition'ed tokens, R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:37-83,
+ * backbones/utils.py:16-38).  bf16 only, wtok == 256, D in {64, 72, 80}; *_sb = window stride, *_ss token, *_sh head (elements). */
+int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wtok, int D,
+                        int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                        int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                        float scale, int dtype, vg_stream_t stream);
+
 /* Same contraction with the KV range split over `nsplit` workgroups per (query tile, head) and a merge pass —
  * the decode-step shape (Sq = 1, Skv = thousands: one workgroup per head would walk the whole KV cache
  * serially).  workspace: fp32, >= B*Hq*nsplit*Sq*(D+2) floats, caller-owned.  nsplit = 1 == vg_attention. */

@@ -24,6 +24,7 @@ def _worker(rank, world, port, q):
 
     torch.set_grad_enabled(False)
     torch.set_num_threads(2)
+    os.environ["VG_TOWERS_SHARDED"] = "1"          # the opt-in tower sharding is what this test exercises
     for name in _cpu_ops.ALL:
         if hasattr(ops, name):
             setattr(ops, name, getattr(_cpu_ops, name))
@@ -41,6 +42,15 @@ def _worker(rank, world, port, q):
     masks = comm.framewise(m, images, text + 0.01 * rank, hw)
     feats = comm.hiera_all_frames(m, images)
     vid = m.video_branch(images, emb, hw, frame_feats=feats)
+    # object-sharded propagation: rank r runs the recurrence for its object, masks all-gathered along the object axis
+    vid_obj = comm.video_branch_objects(m, images, emb, hw, feats)
+    # uneven splits: 3 frames / 3 objects over 2 ranks (blocks 2 + 1), 1 frame (rank 1 has none)
+    assert FrameSharder.my_frames(comm, 3) == ([0, 1] if rank == 0 else [2]) and FrameSharder.my_frames(comm, 1) == ([0] if rank == 0 else [])
+    text3 = G.rnd((3, 256), 13, 0.5)
+    masks3 = comm.framewise(m, images[:3], text3, hw)
+    feats3 = comm.hiera_all_frames(m, images[:3])
+    vid3 = comm.video_branch_objects(m, images[:3], text3, hw, feats3)
+    masks1 = comm.framewise(m, images[:1], text, hw)
     # vision towers sharded by CLIP frame / InternVideo2 chunk (Te = 4: one chunk -> rank 1 has none; two frames each)
     from test_oracle_e2e import e2e_setup
     from videoglamm_amd.vlm import VisionTowers
@@ -72,7 +82,13 @@ def _worker(rank, world, port, q):
         q.put(("towers", ok_towers and ok_sp, (tuple(vis.shape), ok_towers, ok_sp)))
         ref_logits, _ = m.framewise_branch(images, text, hw)
         ref_vid = m.video_branch(images, text, hw)
-        q.put((bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))), bool(torch.equal(vid, ref_vid)), tuple(masks.shape)))
+        same = lambda a, b: bool(a.shape == b.shape) and float((a != b).float().mean()) < 1e-4   # noqa: E731  (per-object batches: summation order)
+        ok_obj = same(vid_obj, (ref_vid > 0).to(torch.uint8))
+        ref3, _ = m.framewise_branch(images[:3], text3, hw)
+        ok_uneven = bool(torch.equal(masks3, (ref3 > 0).to(torch.uint8))) and same(vid3, (m.video_branch(images[:3], text3, hw) > 0).to(torch.uint8))
+        ok_uneven = ok_uneven and bool(torch.equal(masks1, (ref_logits[:1] > 0).to(torch.uint8)))
+        q.put((bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))), bool(torch.equal(vid, ref_vid)) and ok_obj and ok_uneven,
+               tuple(masks.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,4 +108,4 @@ def test_frame_sharding_world2():
         assert p.exitcode == 0
     assert shape == (4, 2, 40, 56)
     assert ok_fw, "frame-sharded framewise masks differ from the single-process result"
-    assert ok_vid, "video branch on all-gathered Hiera features differs from the single-process result"
+    assert ok_vid, "video branch on all-gathered Hiera features / object-sharded propagation / uneven splits differ from the single-process result"

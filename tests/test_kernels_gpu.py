@@ -347,12 +347,17 @@ def test_gemm_window(cuda, dtype, B, H, W, ws, K, N):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("Bw,wtok,H,D", [(64, 16, 4, 72), (8, 64, 2, 72), (6, 16, 2, 32), (16, 49, 4, 72), (24, 32, 1, 64)])
+@pytest.mark.parametrize("Bw,wtok,H,D", [(64, 16, 4, 72), (8, 64, 2, 72), (6, 16, 2, 32), (16, 49, 4, 72), (24, 32, 1, 64),
+                                         (5, 256, 8, 72), (3, 256, 2, 64), (2, 256, 3, 80), (33, 256, 8, 72)])
 def test_attention_windows(cuda, dtype, Bw, wtok, H, D):
     """many small windows packed into 128-token tiles under the block-diagonal mask == per-window attention; q/k/v are
-    strided views of one fused [Bw, wtok, 3, H, D] projection as in Hiera (49 tokens / 6 windows: unpackable -> fallback)."""
+    strided views of one fused [Bw, wtok, 3, H, D] projection as in Hiera (49 tokens / 6 windows: unpackable -> fallback).
+    256-token windows (Hiera stage 3) take vg_window_attention in bf16: one workgroup per (window, head)."""
     from videoglamm_amd import ops
     qkv = rnd(Bw, wtok, 3, H, D, dtype=dtype, seed=7)
+    if wtok == 256:      # a key spike late in the window and a large-magnitude window: the single-pass softmax must hold
+        qkv[0, 200, 1] *= 20.0
+        qkv[-1] *= 4.0
     g = qkv.to(cuda)
     o = ops.attention_windows(g[:, :, 0], g[:, :, 1], g[:, :, 2], D ** -0.5)
     t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)

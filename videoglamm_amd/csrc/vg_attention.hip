@@ -352,6 +352,214 @@ static int launch_attn(const AttnArgs& p, hipStream_t st) {
   return VG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hiera's 256-token windows (stage 3 of Hiera-B+/L: 16x16 windows, head_dim 72; R/.../backbones/hieradet.py:37-83 on windows
+// made by backbones/utils.py:16-38) — one workgroup per (window, head), the WHOLE window's K and V staged once:
+//   * every global load of the workgroup (K rows, V rows, the waves' Q fragments) is requested up front, one barrier, then
+//     no further synchronisation: a wave owns 64 query rows (two 32-row passes) against all 256 keys, so the softmax is a
+//     single pass over 128 score registers per lane (no running max / rescale), P feeds the PV MFMA from registers;
+//   * K rows sit at an odd number of 16-byte slots (conflict-free ds_read_b128 without padding bytes to zero), the k-step
+//     that straddles the end of a 72-wide row reads the next row's first chunk against a ZERO Q operand;
+//   * V is staged transposed / key-permuted / swizzled exactly like attn_kernel's (pv_step_bf16t), four 64-key tiles;
+//   * 73.7 KB of LDS and <= 256 registers: two workgroups per CU, one staging while the other multiplies.
+// The generic kernel walks such a window as 2 query tiles x 4 KV tiles with two barriers and a register->LDS transpose per
+// tile: ~90 TFLOP/s on this shape (r02 C2 profile: 28 ms per 32-frame clip); this one is bounded by its MFMAs.
+struct WinAttnArgs {
+  const void* Q; const void* K; const void* V; void* O;
+  int Bw, H;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+  float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void win256_attn_kernel(WinAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int W = 256;                        // tokens per window
+  constexpr int CH = D / 8;                     // 16-byte chunks per row
+  constexpr int NG = (D + 15) / 16;             // QK^T k-steps
+  constexpr int NDT = (D + 31) / 32;            // output d-tiles
+  constexpr int RS = (CH | 1) * 16;             // K row stride: an odd number of 16-byte slots
+  constexpr int VT_BYTES = 4 * D * 128;         // four 64-key tiles of [D][64 keys]
+  char* Vs = smem;
+  char* Ks = smem + VT_BYTES;                   // (reads past the last V^T row / the last K chunk land in finite data)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x, win = blockIdx.y;
+  const bf16_t* Qg = (const bf16_t*)p.Q + (int64_t)win * p.q_sb + (int64_t)head * p.q_sh;
+  const bf16_t* Kg = (const bf16_t*)p.K + (int64_t)win * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* Vg = (const bf16_t*)p.V + (int64_t)win * p.v_sb + (int64_t)head * p.v_sh;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+  // ---- every global load up front
+  u32x4_t kreg[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int idx = tid + i * 256, row = idx / CH, c = idx - row * CH;
+    kreg[i] = *(const u32x4_t*)(Kg + (int64_t)row * p.k_ss + c * 8);
+  }
+  constexpr int NVI = (64 * CH + 255) / 256;
+  u32x4_t vreg[NVI * 4];
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int item = tid + i * 256, kq = item & 63, c = item >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      vreg[i * 4 + j] = item < 64 * CH ? *(const u32x4_t*)(Vg + (int64_t)(kq * 4 + j) * p.v_ss + c * 8) : zero4;
+  }
+  u32x4_t qf[NG];                                // Q fragments (MFMA B operand) of the wave's current 32-row pass
+  auto load_q = [&](int sub) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c = 2 * g + h;
+      qf[g] = c < CH ? *(const u32x4_t*)(Qg + (int64_t)(wave * 64 + sub * 32 + l31) * p.q_ss + c * 8) : zero4;
+    }
+  };
+  load_q(0);
+  // ---- stage K (rows) and V (transposed image)
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int idx = tid + i * 256, row = idx / CH, c = idx - row * CH;
+    *(u32x4_t*)(Ks + row * RS + c * 16) = kreg[i];
+  }
+  if (tid < 4) *(uint32_t*)(Ks + W * RS + tid * 4) = 0u;      // the chunk after the last row: read against a zero Q operand
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int item = tid + i * 256, kq64 = item & 63, c = item >> 6;
+    if (item < 64 * CH) {
+      const int tile = kq64 >> 4, kq = kq64 & 15;
+      const int b4 = (kq * 4) & 15;
+      const int pos = ((kq * 4) & ~15) + (b4 == 4 ? 8 : (b4 == 8 ? 4 : b4));   // key permutation inside a 16-block (pv_step_bf16t)
+      const int grp = pos >> 3, half = (pos >> 2) & 1;
+      char* vt = Vs + tile * D * 128;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = c * 8 + e, w = e >> 1, sh = (e & 1) * 16;
+        uint2 val;
+        val.x = ((vreg[i * 4 + 0][w] >> sh) & 0xffffu) | (((vreg[i * 4 + 1][w] >> sh) & 0xffffu) << 16);
+        val.y = ((vreg[i * 4 + 2][w] >> sh) & 0xffffu) | (((vreg[i * 4 + 3][w] >> sh) & 0xffffu) << 16);
+        *(uint2*)(vt + d * 128 + ((grp ^ ((d >> 1) & 7)) << 4) + half * 8) = val;
+      }
+    }
+  }
+  __syncthreads();
+
+  const float sl2 = p.scale * 1.4426950408889634f;
+  bf16_t* Og = (bf16_t*)p.O + (int64_t)win * p.o_sb + (int64_t)head * p.o_sh;
+#pragma unroll 1
+  for (int sub = 0; sub < 2; ++sub) {
+    // S^T[key, q] for all 256 keys: 8 key tiles x NG k-steps; the K fragments of tile kt+1 are requested before the MFMAs of
+    // tile kt issue (the compiler otherwise hoists all 8 x NG reads: 160 registers it does not have)
+    f32x16_t s[8];
+    u32x4_t ka[2][NG];
+    auto load_k = [&](int kt, int buf) {
+      const char* krow = Ks + (kt * 32 + l31) * RS + h * 16;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ka[buf][g] = *(const u32x4_t*)(krow + g * 32);
+    };
+    load_k(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      if (kt + 1 < 8) load_k(kt + 1, (kt + 1) & 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ka[kt & 1][g]), __builtin_bit_cast(bf16x8_t, qf[g]), s[kt], 0, 0, 0);
+      asm volatile("" ::: "memory");
+    }
+    if (sub == 0) load_q(1);                     // the next pass's Q rows arrive under this pass's softmax and PV
+    // softmax over the lane's 128 scores + the other half-wave's (one query per lane pair), single pass
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mo = mx * sl2;
+    float rs = 0.f;
+    uint32_t pb[8][8];                            // P^T as packed bf16 pairs: the PV MFMA's B operands
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mo));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kt][r + 1], sl2, -mo));
+        rs += p0 + p1;
+        pb[kt][r >> 1] = f2bf2(p0, p1);
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    // O^T[d, q] = V^T P^T: per 32-key tile two 16-key MFMA steps per d-tile (operand layout of pv_step_bf16t)
+    f32x16_t o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const char* vt = Vs + (kt >> 1) * D * 128;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const u32x4_t b = {pb[kt][st * 4], pb[kt][st * 4 + 1], pb[kt][st * 4 + 2], pb[kt][st * 4 + 3]};
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int d = dt * 32 + l31;
+          const u32x4_t a = *(const u32x4_t*)(vt + d * 128 + ((((kt & 1) * 4 + st * 2 + h) ^ ((d >> 1) & 7)) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), o[dt], 0, 0, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    const float inv = 1.0f / rs;
+    bf16_t* orow = Og + (int64_t)(wave * 64 + sub * 32 + l31) * p.o_ss;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = dt * 32 + r4 * 8 + h * 4;          // accumulator registers 4 r4 .. 4 r4 + 3 = four consecutive d
+        if (d0 < D) {
+          uint2 v;
+          v.x = f2bf2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv);
+          v.y = f2bf2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv);
+          *(uint2*)(orow + d0) = v;
+        }
+      }
+  }
+}
+
+template <int D>
+static int launch_win256(const WinAttnArgs& p, hipStream_t st) {
+  constexpr int CH = D / 8, RS = (CH | 1) * 16;
+  constexpr int lds = 4 * D * 128 + 256 * RS + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)win256_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  win256_attn_kernel<D><<<dim3(p.H, p.Bw), 256, lds, st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wtok, int D,
+                                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                                   int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                                   float scale, int dtype, vg_stream_t stream) {
+  VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_window_attention: null pointer");
+  VG_CHECK(dtype == VG_BF16, VG_ERR_UNSUPPORTED, "vg_window_attention: bf16 only (fp32 windows go through vg_attention)");
+  VG_CHECK(wtok == 256 && (D == 64 || D == 72 || D == 80), VG_ERR_UNSUPPORTED,
+           "vg_window_attention: %d-token windows with head_dim %d unsupported (256 tokens; head_dim 64 / 72 / 80)", wtok, D);
+  VG_CHECK(Bw > 0 && Bw <= 65535 && H > 0 && scale > 0.f, VG_ERR_ARG, "vg_window_attention: bad shape Bw=%d H=%d", Bw, H);
+  VG_CHECK(q_ss % 8 == 0 && q_sh % 8 == 0 && q_sb % 8 == 0 && k_ss % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0 && v_ss % 8 == 0 &&
+               v_sh % 8 == 0 && v_sb % 8 == 0 && o_ss % 4 == 0 && o_sh % 4 == 0 && o_sb % 4 == 0,
+           VG_ERR_ARG, "vg_window_attention: strides must keep 16-byte (q/k/v) / 8-byte (o) alignment");
+  VG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && (((uintptr_t)O) & 7) == 0, VG_ERR_ARG,
+           "vg_window_attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
+  WinAttnArgs p{Q, K, V, O, Bw, H, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 72) return launch_win256<72>(p, st);
+  if (D == 64) return launch_win256<64>(p, st);
+  return launch_win256<80>(p, st);
+}
+
 // merge the split-KV partials: O = sum_s O_s e^{m_s - m} / sum_s l_s e^{m_s - m}.  One workgroup per (q, head, b):
 // the per-split weights are formed once in LDS, then the D columns are accumulated with independent (pipelined) loads.
 template <typename T>

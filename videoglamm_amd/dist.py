@@ -12,8 +12,12 @@ What shards naturally and what does not:
     projects its block of frames / chunks, the projected, pooled tokens (a few MB) are all-gathered, so the replicated LLM
     sees identical visual tokens everywhere and the towers cost 1/world of a clip instead of a whole one per rank.
   * Results: uint8 masks of the local frames, all-gathered so that rank 0 (and everyone) holds the clip.
-  * Video-branch propagation is a recurrence over frames (memory of t-1..t-6): only the per-frame Hiera
-    features shard; they are all-gathered (8.4 MB bf16 per frame at SAM2-L) and the recurrence runs replicated.
+  * Video-branch propagation is a recurrence over frames (memory of t-1..t-6), so frames do not shard there — OBJECTS do
+    (non_overlap_masks_for_mem_enc is unset: objects never interact, R/.../sam2_video_predictor.py:571-612): the per-frame Hiera
+    features are all-gathered (8.4 MB bf16 per frame at SAM2-L), rank r propagates its block of the N [SEG] objects and the
+    uint8 masks are all-gathered along the object axis.  N = 1 is "replicas only" for this stage (every rank runs it).
+Frame / object counts need not divide by the world size: blocks differ by at most one unit and every collective is padded
+to the largest block.
 """
 import torch
 import torch.distributed as dist
@@ -29,10 +33,26 @@ class FrameSharder:
         self.world = dist.get_world_size(group)
 
     def my_frames(self, T):
-        """contiguous block split; T must divide evenly so every collective is regular."""
-        assert T % self.world == 0, f"T={T} frames must be a multiple of world_size={self.world}"
-        per = T // self.world
-        return list(range(self.rank * per, (self.rank + 1) * per))
+        """this rank's contiguous block of the T frames (sizes differ by at most one; a rank beyond T gets none)."""
+        start, n = self.block(T)
+        return list(range(start, start + n))
+
+    def counts(self, n):
+        base, extra = divmod(n, self.world)
+        return [base + (1 if r < extra else 0) for r in range(self.world)]
+
+    def gather_blocks(self, local, n, dim, shape, dtype, device):
+        """all-gather of per-rank blocks of unequal length along `dim`: `local` is this rank's block (or None when it has no
+        unit), `shape` the full result's shape with n units along dim.  Blocks are padded to the largest so the collective is regular."""
+        counts = self.counts(n)
+        most = max(counts)
+        pshape = list(shape)
+        pshape[dim] = most
+        buf = torch.zeros(pshape, dtype=dtype, device=device)
+        if local is not None and local.shape[dim]:
+            buf.narrow(dim, 0, local.shape[dim]).copy_(local)
+        parts = self._all_gather(buf)
+        return torch.cat([parts[r].narrow(dim, 0, counts[r]) for r in range(self.world) if counts[r]], dim=dim)
 
     def block(self, n):
         """contiguous block of n units for this rank (sizes differ by at most one; ranks beyond n get none) -> (start, count)."""
@@ -68,18 +88,41 @@ class FrameSharder:
         binarize: logits -> uint8 masks of this rank's frames (per-frame work, so it shards with them); None = logit > 0, made
         in one pass from the low-res logits."""
         emb = self.sync_seg_embeddings(emb)
-        frames = self.my_frames(images_for_sam.shape[0])
-        out, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats, as_masks=binarize is None)
-        local = out if binarize is None else binarize(out)                 # [T/world, N, H, W] uint8, on device
-        return torch.cat(self._all_gather(local), dim=0).cpu()
+        T, N = images_for_sam.shape[0], emb.shape[0]
+        frames = self.my_frames(T)
+        local = None
+        if frames:
+            out, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats, as_masks=binarize is None)
+            local = out if binarize is None else binarize(out)             # [frames of this rank, N, H, W] uint8, on device
+        return self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device).cpu()
+
+    def video_branch_objects(self, sam2, images_for_sam, emb, hw, frame_feats, binarize=None, **kw):
+        """object-sharded SAM2 propagation: every rank holds the Hiera features of ALL frames (gather_frame_feats) and runs the
+        recurrence for its block of the N objects (they never interact); masks all-gathered along the object axis ->
+        host uint8 [T,N,H,W].  With fewer objects than ranks the surplus ranks only take part in the collectives; N = 1:
+        replicas only — every rank propagates the single object (no exchange, identical results)."""
+        T, N = images_for_sam.shape[0], emb.shape[0]
+        if N == 1:
+            out = sam2.video_branch(images_for_sam, emb, hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
+            return (out if binarize is None else binarize(out)).cpu()
+        o0, on = self.block(N)
+        local = None
+        if on:
+            out = sam2.video_branch(images_for_sam, emb[o0:o0 + on], hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
+            local = out if binarize is None else binarize(out)             # [T, objects of this rank, H, W]
+        return self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device).cpu()
 
     def gather_frame_feats(self, local_feats, T):
         """all-gather per-frame FPN features ({frame: [3 levels]} of this rank's frames) -> the same for all T frames."""
         frames = self.my_frames(T)
+        ref = next(iter(local_feats.values())) if local_feats else None
         levels = []
         for lv in range(3):
-            stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0)      # [T/world, h, w, c]
-            levels.append(torch.cat(self._all_gather(stacked), dim=0))
+            stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0) if frames else None      # [frames of this rank, h, w, c]
+            if ref is None:
+                raise ValueError("gather_frame_feats: a rank without frames cannot describe the feature shapes (T < world size)")
+            shape = (T,) + tuple(ref[lv].shape[1:])
+            levels.append(self.gather_blocks(stacked, T, 0, shape, ref[lv].dtype, ref[lv].device))
         return {t: [levels[lv][t:t + 1] for lv in range(3)] for t in range(T)}
 
     def hiera_all_frames(self, sam2, images_for_sam):

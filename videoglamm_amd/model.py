@@ -347,8 +347,11 @@ class VideoGLaMMForCausalLM:
             return out_ids, [{}]
         hw = tuple(original_size_list[0])
         if self.comm is not None:
+            # frames shard for Hiera only (the propagation is a recurrence over frames); OBJECTS shard for the propagation
             emb = self.comm.sync_seg_embeddings(emb)
             feats = self.comm.gather_frame_feats(feats, sam.shape[0])
+            masks = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
+            return out_ids, [self._segments(masks)]
         if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "0") == "1":
             # the propagation replayed from a HIP graph: same results, measured neutral (r01: 201.05 vs 200.51 ms per clip), off by default
             logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)

@@ -76,7 +76,11 @@ class SAM2:
         self.S = cfg["image_size"]
         self.es = self.S // 16
         self.blocks, self.stage_ends = hiera_layout(cfg["trunk"])
-        self.frame_chunk = int(os.environ.get("VG_FRAME_CHUNK", "8"))  # frames batched per Hiera / framewise-decode launch group
+        # frames batched per Hiera launch group (r02, 32-frame clip: 16 frames 145.8 ms, 8 frames 156.2, 4 frames 171.8: bigger
+        # batches fill the tails of the 128-tile grids) and per framewise mask-decoder launch group (its GEMMs are M = 4096 rows
+        # per (frame, object): the more pairs per launch the better)
+        self.frame_chunk = int(os.environ.get("VG_FRAME_CHUNK", "16"))
+        self.decode_chunk = int(os.environ.get("VG_DECODE_CHUNK", "32"))
 
     def hiera_frames(self, images, frames=None):
         """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
@@ -472,8 +476,9 @@ class SAM2:
         lows = []
         # frames are independent here: a chunk of frames x all objects goes through Hiera and the mask decoder as
         # ONE batch (identical per-item arithmetic to the reference's frame-serial loop, far fewer/larger launches)
-        for c0 in range(0, len(frames), self.frame_chunk):
-            fr = frames[c0:c0 + self.frame_chunk]
+        step = max(1, self.decode_chunk // max(N, 1)) if frame_feats is not None else self.frame_chunk
+        for c0 in range(0, len(frames), step):
+            fr = frames[c0:c0 + step]
             Tc = len(fr)
             if frame_feats is not None:
                 fpn = [_stack_views([frame_feats[t][lv] for t in fr]) for lv in range(3)]

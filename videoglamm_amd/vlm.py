@@ -110,7 +110,10 @@ class VisionTowers:
         te = images.shape[0]
         assert te % 4 == 0, "the video encoder consumes 4-frame chunks (arch.py:133)"
         video = images.view(te // 4, 4, *images.shape[1:])
-        sharded = comm is not None and comm.world > 1
+        # opt-in (VG_TOWERS_SHARDED=1): a rank that encodes fewer frames runs GEMMs of another M, which can take another tile route
+        # (another fp32 summation order): in bf16 the visual tokens — and with them greedy ids — may then differ from the
+        # single-GPU run.  The default keeps the whole LLM side replicated: N-GPU ids == 1-GPU ids by construction.
+        sharded = comm is not None and comm.world > 1 and os.environ.get("VG_TOWERS_SHARDED", "0") == "1"
         if sharded:
             c0, cn = comm.block(te)
             v0, vn = comm.block(te // 4)
@@ -410,8 +413,9 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
         dec = LlamaDecoder(params, cfg["llm"], -(-need // 1024) * 1024)
         params._decoder = dec          # KV cache + captured decode graph are reused across clips
     dec.reset()
-    if comm is not None and comm.world > 1 and x.shape[0] >= 64 * comm.world and os.environ.get("VG_PREFILL_SHARDED", "1") != "0":
-        hidden = dec.forward_sharded(x, comm)   # sequence-parallel prefill: 1/world of the rows per rank
+    if comm is not None and comm.world > 1 and x.shape[0] >= 64 * comm.world and os.environ.get("VG_PREFILL_SHARDED", "0") == "1":
+        hidden = dec.forward_sharded(x, comm)   # opt-in sequence-parallel prefill: 1/world of the rows per rank (row chunks of another
+        #                                         M take other GEMM routes: bf16 ids may differ from the single-GPU run; default = replicated)
     else:
         hidden = dec.forward(x)[-1:]            # hid_all rows 0..S-1: final-norm states of the spliced prompt
     added = x.shape[0] - input_ids.numel()      # "num_newly_added_tokens" (VideoGLaMM.py:613,786)
