@@ -508,3 +508,27 @@ def gen_postproc():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("postproc", "all")):
     gen_postproc()
+
+
+def gen_ingest():
+    """checkpoint-ingest helpers: the reference's OWN interpolate_pos_embed_internvideo2_new
+    (R/model/videogpt_plus/model/internvideo/pos_embed.py:247-307) on a seeded positional embedding: 8 frames of a 4x4 grid ->
+    4 frames of a 6x6 grid (temporal linear + spatial bicubic), and the temporal-only case 8 -> 4."""
+    import logging
+    import types
+    ns = {"torch": torch, "logger": logging.getLogger("golden")}
+    (interp,) = ri.functions("model/videogpt_plus/model/internvideo/pos_embed.py", ["interpolate_pos_embed_internvideo2_new"], ns)
+    C = 8
+    pos = rnd((1, 1 + 8 * 16, C), 61)
+    out = {"pos_in": pos}
+    for tag, side in (("t_and_s", 6), ("t_only", 4)):
+        model = types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=4 * side * side), pos_embed=torch.zeros(1, 1 + 4 * side * side, C),
+                                      num_frames=4, tubelet_size=1)
+        ck = {"pos_embed": pos.clone()}
+        interp(ck, model, orig_t_size=8)
+        out["pos_" + tag] = ck["pos_embed"]
+    save("ingest.npz", **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ingest", "all")):
+    gen_ingest()

@@ -58,9 +58,12 @@ def _read_any(path):
     return _read_dir(path) if os.path.isdir(path) else _read(path)
 
 
-def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None):
+def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None, lora_dir=None, iv2_origin_num_frames=None):
     """-> ({reference name: tensor}, hf_config dict or None).  vision_tower / image_vision_tower default to the paths the
-    HF config names (`mm_vision_tower`, `image_mm_vision_tower`) when the directory does not already carry the towers."""
+    HF config names (`mm_vision_tower`, `image_mm_vision_tower`) when the directory does not already carry the towers.
+    lora_dir: a LoRA training output (adapter + non_lora_trainables.bin) merged over the base like
+    load_videogptplus_model_from_pretrained does; iv2_origin_num_frames: frame count the InternVideo2 checkpoint was trained with
+    (its pos_embed is interpolated to the model's 4 frames when it differs — the released config has 4 == 4)."""
     sd = _read_dir(model_dir)
     hf = None
     cfg_path = os.path.join(model_dir, "config.json")
@@ -78,6 +81,12 @@ def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_
         iv2 = {k: v for k, v in _read_any(vision_tower).items() if k.startswith("vision_encoder.")}
         if not iv2:
             raise KeyError(f"{vision_tower}: no vision_encoder.* tensors")
+        pe = iv2.get("vision_encoder.pos_embed")
+        if pe is not None and iv2_origin_num_frames and int(iv2_origin_num_frames) != 4:
+            side = iv2["vision_encoder.patch_embed.proj.weight"].shape[-1]
+            grid = int(round(((pe.shape[1] - 1) // int(iv2_origin_num_frames)) ** 0.5))
+            iv2["vision_encoder.pos_embed"] = interpolate_iv2_pos_embed(pe, int(iv2_origin_num_frames), 4, grid)
+            del side
         sd.update({"model.vision_tower." + k: v for k, v in iv2.items()})
     if not any(k.startswith(CLIP_PREFIX) for k in sd):
         image_vision_tower = image_vision_tower or (hf or {}).get("image_mm_vision_tower")
@@ -91,7 +100,83 @@ def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_
         sd.update({SAM2_PREFIX + k: v for k, v in _read_any(sam2_checkpoint).items()})
     if not any(k.startswith(SAM2_PREFIX) for k in sd):
         raise FileNotFoundError("the model directory has no SAM2 weights (model.visual_model.*) and no sam2_checkpoint was given")
+    if lora_dir:
+        nl = os.path.join(lora_dir, "non_lora_trainables.bin")
+        if not os.path.exists(nl):     # the reference's own error (train_ds_with_videogptplus.py:166)
+            raise FileNotFoundError("Lora is specified in the model path, however could not find non-LORA trainables weights.")
+        merge_non_lora_trainables(sd, nl)
+        merge_lora(sd, lora_dir)
     return sd, hf
+
+
+def interpolate_iv2_pos_embed(pos, orig_t, new_t, new_side, num_extra=1):
+    """interpolate_pos_embed_internvideo2_new for one tensor — R/model/videogpt_plus/model/internvideo/pos_embed.py:247-307, called
+    from setup_internvideo2V (internvideo/utils.py:83-88) when the checkpoint's frame count / patch grid differs from the model's:
+    pos [1, extra + orig_t * s * s, C] -> [1, extra + new_t * new_side^2, C]; linear along time first, then bicubic
+    (align_corners=False) over the patch grid; the extra (cls) tokens are kept."""
+    C = pos.shape[-1]
+    extra, tok = pos[:, :num_extra], pos[:, num_extra:]
+    side = int(round((tok.shape[1] // orig_t) ** 0.5))
+    assert orig_t * side * side == tok.shape[1], f"pos_embed of {tok.shape[1]} tokens is not {orig_t} frames of a square grid"
+    dt = pos.dtype
+    tok = tok.float()
+    if orig_t != new_t:
+        t = tok.view(1, orig_t, -1, C).permute(0, 2, 3, 1).reshape(-1, C, orig_t)
+        t = torch.nn.functional.interpolate(t, size=new_t, mode="linear")
+        tok = t.view(1, -1, C, new_t).permute(0, 3, 1, 2).reshape(1, -1, C)
+    if side != new_side:
+        t = tok.reshape(-1, side, side, C).permute(0, 3, 1, 2)
+        t = torch.nn.functional.interpolate(t, size=(new_side, new_side), mode="bicubic", align_corners=False)
+        tok = t.permute(0, 2, 3, 1).reshape(-1, new_t, new_side, new_side, C).flatten(1, 3)
+    return torch.cat((extra.float(), tok), dim=1).to(dt)
+
+
+def merge_non_lora_trainables(sd, path):
+    """non_lora_trainables.bin of a LoRA training run laid over the base state dict — load_videogptplus_model_from_pretrained,
+    R/train_ds_with_videogptplus.py:163-171: keys lose a leading "base_model." and, when any key starts with "model.model.", a
+    leading "model."; load_state_dict(strict=False) = known names are overwritten, unknown ones ignored.  -> number of tensors taken."""
+    extra = _read(path)
+    extra = {(k[11:] if k.startswith("base_model.") else k): v for k, v in extra.items()}
+    if any(k.startswith("model.model.") for k in extra):
+        extra = {(k[6:] if k.startswith("model.") else k): v for k, v in extra.items()}
+    n = 0
+    for k, v in extra.items():
+        if k in sd:
+            assert tuple(sd[k].shape) == tuple(v.shape), f"{k}: {tuple(v.shape)} does not fit {tuple(sd[k].shape)}"
+            sd[k] = v
+            n += 1
+    return n
+
+
+def merge_lora(sd, lora_dir):
+    """PeftModel.from_pretrained(model, dir).merge_and_unload() on a state dict (R/train_ds_with_videogptplus.py:173-178; peft==0.12.0,
+    R/requirements.txt:33 — source absent here: the published LoRA merge W += (lora_alpha / r) * B @ A, "parity unpinned").
+    Reads adapter_config.json (r, lora_alpha; use_rslora -> alpha / sqrt(r)) and adapter_model.{safetensors,bin} whose keys are
+    base_model.model.<module>.lora_A.weight / lora_B.weight.  -> number of weights merged."""
+    with open(os.path.join(lora_dir, "adapter_config.json")) as fh:
+        ac = json.load(fh)
+    r, alpha = int(ac["r"]), float(ac["lora_alpha"])
+    scaling = alpha / (r ** 0.5) if ac.get("use_rslora") else alpha / r
+    f = next((os.path.join(lora_dir, n) for n in ("adapter_model.safetensors", "adapter_model.bin") if os.path.exists(os.path.join(lora_dir, n))), None)
+    if f is None:
+        raise FileNotFoundError(f"no adapter_model.safetensors / adapter_model.bin under {lora_dir}")
+    ad = _read(f)
+    n = 0
+    for k, a in ad.items():
+        if not k.endswith("lora_A.weight") and ".lora_A." not in k:
+            continue
+        kb = k.replace("lora_A", "lora_B")
+        mod = k.split(".lora_A")[0]
+        mod = mod[len("base_model.model."):] if mod.startswith("base_model.model.") else mod
+        name = mod + ".weight"
+        if name not in sd:
+            raise KeyError(f"LoRA adapter targets {name}, which the base checkpoint does not have")
+        w = sd[name]
+        delta = (ad[kb].float() @ a.float()) * scaling
+        assert tuple(delta.shape) == tuple(w.shape), f"{name}: LoRA delta {tuple(delta.shape)} vs weight {tuple(w.shape)}"
+        sd[name] = (w.float() + delta).to(w.dtype)
+        n += 1
+    return n
 
 
 def _count(sd, prefix, pattern):

@@ -104,7 +104,7 @@ class VideoGLaMMForCausalLM:
 
     @classmethod
     def from_pretrained(cls, path, config=None, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None,
-                        seg_token_idx=None, **kwargs):
+                        seg_token_idx=None, lora_dir=None, **kwargs):
         """The released artefact layout (R/chat.py:277-319): an HF directory (*.safetensors or pytorch_model*.bin shards +
         config.json) with the LLM, the projectors, text_hidden_fcs and SAM2; the InternVideo2 .pt and the CLIP directory
         the config names under mm_vision_tower / image_mm_vision_tower (or given here); optionally a stand-alone SAM2
@@ -112,7 +112,7 @@ class VideoGLaMMForCausalLM:
         `config` — or a "videoglamm_amd" section in config.json — gives it explicitly."""
         from . import ingest
 
-        sd, hf = ingest.load_state_dict(path, vision_tower, image_vision_tower, sam2_checkpoint)
+        sd, hf = ingest.load_state_dict(path, vision_tower, image_vision_tower, sam2_checkpoint, lora_dir=lora_dir)
         if config is None:
             config = (hf or {}).get("videoglamm_amd") or ingest.derive_config(sd, hf, seg_token_idx)
         return cls(sd, config, **kwargs)
