@@ -97,11 +97,13 @@ int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, in
                  int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
                  int64_t o_ss, int64_t o_sh, float scale, int causal, int dtype, vg_stream_t stream);
 
-/* Self-attention inside independent 256-token windows, one workgroup per (window, head) with the window's K and V staged once:
- * O[w,i,h,:] = softmax_j(scale * Q[w,i,h,:].K[w,j,h,:]) @ V[w,j,h,:], i, j in [0, 256).  Hiera's 16x16 windows (stage 3 of
- * Hiera-B+/L: MultiScaleAttention on window_partition'ed tokens, R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:37-83,
- * backbones/utils.py:16-38).  bf16 only, wtok == 256, D in {64, 72, 80}; *_sb = window stride, *_ss token, *_sh head (elements). */
-int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wtok, int D,
+/* Attention inside independent windows: O[w,i,h,:] = softmax_j(scale * Q[w,i,h,:].K[w,j,h,:]) @ V[w,j,h,:], i in [0, wq), j in
+ * [0, wtok) — Hiera's MultiScaleAttention on window_partition'ed tokens (R/model/segment_anything_2/sam2/modeling/backbones/
+ * hieradet.py:37-83, backbones/utils.py:16-38; wq < wtok: the q-pooled first block of a stage, hieradet.py:64-68).  bf16 only.
+ *   wq == wtok == 256, D in {64, 72, 80}: one workgroup per (window, head), the window's K and V staged once (stage 3);
+ *   D == 72 and (wq, wtok) in {(16,16), (64,64), (4,16), (16,64)}: one wave per (window, head) on 16x16x32 MFMA tiles.
+ * *_sb = window stride, *_ss token stride, *_sh head stride (elements); O may be a strided view as well. */
+int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wq, int wtok, int D,
                         int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                         int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                         float scale, int dtype, vg_stream_t stream);

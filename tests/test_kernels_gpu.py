@@ -364,6 +364,24 @@ def test_attention_windows(cuda, dtype, Bw, wtok, H, D):
     close(o, ref.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5), **t)
 
 
+@pytest.mark.parametrize("Bw,wq,wk,H", [(37, 4, 16, 8), (64, 16, 64, 4), (5, 16, 16, 3), (9, 64, 64, 2), (1024, 16, 16, 4), (300, 64, 64, 16)])
+def test_window_attention_small(cuda, Bw, wq, wk, H):
+    """one wave per (window, head) on 16x16x32 MFMA tiles (vg_window_attention): the 16- and 64-token windows of Hiera stages 1 / 2 / 4
+    and the q-pooled first block of a stage (4 queries x 16 keys, 16 x 64); item counts that do not fill the last workgroup;
+    q is its own tensor (pooled), k / v strided views of the fused projection."""
+    from videoglamm_amd import ops
+    D = 72
+    qkv = rnd(Bw, wk, 3, H, D, dtype=torch.bfloat16, seed=9)
+    q = rnd(Bw, wq, H, D, dtype=torch.bfloat16, seed=10) if wq != wk else qkv[:, :, 0]
+    qkv[0, wk - 3, 1] *= 15.0                      # a spike among the keys
+    g = qkv.to(cuda)
+    gq = q.to(cuda) if wq != wk else g[:, :, 0]
+    o = ops.window_attention(gq, g[:, :, 1], g[:, :, 2], D ** -0.5)
+    assert o is not None and o.shape == (Bw, wq, H, D)
+    close(o, ref.attention(q, qkv[:, :, 1], qkv[:, :, 2], D ** -0.5), rtol=3e-2, atol=2e-2)
+    assert ops.window_attention(gq.float(), g[:, :, 1].float(), g[:, :, 2].float(), D ** -0.5) is None      # fp32: the generic kernel's job
+
+
 def test_errors_are_loud(cuda):
     from videoglamm_amd import _lib, ops
     with pytest.raises(_lib.VGKernelError):

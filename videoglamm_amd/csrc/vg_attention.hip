@@ -539,22 +539,182 @@ static int launch_win256(const WinAttnArgs& p, hipStream_t st) {
   return VG_OK;
 }
 
-extern "C" int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wtok, int D,
+// ---------------------------------------------------------------------------------------------------------------------
+// Hiera's SMALL windows (stage 1 / 4: 8x8 = 64 tokens, stage 2: 4x4 = 16 tokens, and the q-pooled first block of a stage:
+// 16 queries x 64 keys, 4 x 16): ONE WAVE per (window, head), 16x16x32 MFMA tiles, no workgroup-level staging of Q / K.
+//   * Q and K rows go straight from global memory into the MFMA operand layout (lane = row l&15, 16-byte chunk l>>4 of a
+//     32-wide k-step): a window's rows are contiguous in the fused projection, neighbouring waves of a workgroup take
+//     neighbouring heads, so whole lines are consumed together;
+//   * S^T = K Q^T leaves a lane with 4 keys of ONE query: the softmax needs two xor-shuffles (lanes 16 / 32 apart);
+//   * P feeds the PV MFMA from the registers it was made in: contraction slot 8g + j of the 32-deep step is key 4g + j of
+//     the 16-key tile for j < 4 and an explicit zero for j >= 4 (half of the step is padding: MFMA time is nothing here);
+//     the matching V^T operand is gathered from a wave-private row image of V in LDS (four 2-byte reads per operand);
+//   * these launches are bound by the fused projection's bytes (453 MB per 8-frame launch at stage 1): the generic kernel
+//     ran them at 1.1-1.5 TB/s (one padded 128-query tile per few windows, two barriers per KV tile).
+struct TinyAttnArgs {
+  const void* Q; const void* K; const void* V; void* O;
+  int Bw, H;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+  float scale;
+};
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+
+template <int D, int WQ, int WK>
+__global__ __launch_bounds__(256) void tiny_win_attn_kernel(TinyAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = D / 8;                 // 16-byte chunks per row
+  constexpr int NKS = (D + 31) / 32;        // 32-deep k-steps of QK^T
+  constexpr int NDT = (D + 15) / 16;        // 16-wide d tiles of the output
+  constexpr int QT = (WQ + 15) / 16, KT = WK / 16;
+  constexpr int RSV = CH * 16;              // V row image: [key][D] bf16
+  constexpr int VBYTES = WK * RSV + 64;     // + slack: d-tiles past D read (finite) bytes after the last row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+  const int64_t items = (int64_t)p.Bw * p.H;
+  int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  const bool live = item < items;
+  if (!live) item = items - 1;              // (every wave reaches the barrier; a surplus wave recomputes the last item, stores nothing)
+  const int win = (int)(item / p.H), head = (int)(item % p.H);
+  const bf16_t* Qg = (const bf16_t*)p.Q + (int64_t)win * p.q_sb + (int64_t)head * p.q_sh;
+  const bf16_t* Kg = (const bf16_t*)p.K + (int64_t)win * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* Vg = (const bf16_t*)p.V + (int64_t)win * p.v_sb + (int64_t)head * p.v_sh;
+  char* Vw = smem + wave * VBYTES;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+  u32x4_t qf[QT][NKS], kf[KT][NKS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int c = ks * 4 + g, row = qt * 16 + i16;
+      qf[qt][ks] = (c < CH && row < WQ) ? *(const u32x4_t*)(Qg + (int64_t)row * p.q_ss + c * 8) : zero4;
+    }
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int c = ks * 4 + g;
+      kf[kt][ks] = c < CH ? *(const u32x4_t*)(Kg + (int64_t)(kt * 16 + i16) * p.k_ss + c * 8) : zero4;
+    }
+  constexpr int NVI = (WK * CH + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int idx = lane + i * 64, row = idx / CH, c = idx - row * CH;
+    if (idx < WK * CH) *(u32x4_t*)(Vw + row * RSV + c * 16) = *(const u32x4_t*)(Vg + (int64_t)row * p.v_ss + c * 8);
+  }
+  if (lane < 16) *(uint32_t*)(Vw + WK * RSV + lane * 4) = 0u;
+  __syncthreads();
+
+  // S^T[key, q]: lane (q = i16 of tile qt, g) holds keys kt*16 + 4g + r
+  f32x4v_t s[KT][QT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      s[kt][qt] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[kt][ks]), __builtin_bit_cast(bf16x8_t, qf[qt][ks]),
+                                                            s[kt][qt], 0, 0, 0);
+    }
+  const float sl2 = p.scale * 1.4426950408889634f;
+  uint32_t pb[KT][QT][2];
+  float inv[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mo = mx * sl2;
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], sl2, -mo)); rs += e[r]; }
+      pb[kt][qt][0] = f2bf2(e[0], e[1]);
+      pb[kt][qt][1] = f2bf2(e[2], e[3]);
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    inv[qt] = 1.0f / rs;
+  }
+  // O^T[d, q] = V^T P^T per 16-key tile; the contraction's slots 8g + 4 .. 8g + 7 are zeros on the P side
+  f32x4v_t o[NDT][QT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const char* vp = Vw + (kt * 16 + 4 * g) * RSV + (dt * 16 + i16) * 2;
+      const uint32_t v0 = *(const uint16_t*)(vp), v1 = *(const uint16_t*)(vp + RSV), v2 = *(const uint16_t*)(vp + 2 * RSV),
+                     v3 = *(const uint16_t*)(vp + 3 * RSV);
+      const u32x4_t a = {v0 | (v1 << 16), v2 | (v3 << 16), 0u, 0u};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const u32x4_t b = {pb[kt][qt][0], pb[kt][qt][1], 0u, 0u};
+        o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), o[dt][qt], 0, 0, 0);
+      }
+    }
+  if (!live) return;
+  bf16_t* Og = (bf16_t*)p.O + (int64_t)win * p.o_sb + (int64_t)head * p.o_sh;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qt * 16 + i16;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d0 = dt * 16 + 4 * g;
+      if (q < WQ && d0 < D) {
+        uint2 v;
+        v.x = f2bf2(o[dt][qt][0] * inv[qt], o[dt][qt][1] * inv[qt]);
+        v.y = f2bf2(o[dt][qt][2] * inv[qt], o[dt][qt][3] * inv[qt]);
+        *(uint2*)(Og + (int64_t)q * p.o_ss + d0) = v;
+      }
+    }
+  }
+}
+
+template <int D, int WQ, int WK>
+static int launch_tiny_win(const TinyAttnArgs& p, hipStream_t st) {
+  constexpr int lds = 4 * (WK * (D / 8) * 16 + 64);
+  const int64_t items = (int64_t)p.Bw * p.H;
+  tiny_win_attn_kernel<D, WQ, WK><<<dim3((unsigned)((items + 3) / 4)), 256, lds, st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_window_attention(const void* Q, const void* K, const void* V, void* O, int Bw, int H, int wq, int wtok, int D,
                                    int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                                    int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                                    float scale, int dtype, vg_stream_t stream) {
   VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_window_attention: null pointer");
   VG_CHECK(dtype == VG_BF16, VG_ERR_UNSUPPORTED, "vg_window_attention: bf16 only (fp32 windows go through vg_attention)");
-  VG_CHECK(wtok == 256 && (D == 64 || D == 72 || D == 80), VG_ERR_UNSUPPORTED,
-           "vg_window_attention: %d-token windows with head_dim %d unsupported (256 tokens; head_dim 64 / 72 / 80)", wtok, D);
-  VG_CHECK(Bw > 0 && Bw <= 65535 && H > 0 && scale > 0.f, VG_ERR_ARG, "vg_window_attention: bad shape Bw=%d H=%d", Bw, H);
+  const bool big = wq == 256 && wtok == 256 && (D == 64 || D == 72 || D == 80);
+  const bool tiny = D == 72 && ((wq == 16 && wtok == 16) || (wq == 64 && wtok == 64) || (wq == 4 && wtok == 16) || (wq == 16 && wtok == 64));
+  VG_CHECK(big || tiny, VG_ERR_UNSUPPORTED,
+           "vg_window_attention: %d queries x %d keys per window with head_dim %d unsupported (256 x 256 with head_dim 64 / 72 / 80; "
+           "16 x 16, 64 x 64, 4 x 16, 16 x 64 with head_dim 72)", wq, wtok, D);
+  VG_CHECK(Bw > 0 && (Bw <= 65535 || tiny) && H > 0 && scale > 0.f, VG_ERR_ARG, "vg_window_attention: bad shape Bw=%d H=%d", Bw, H);
   VG_CHECK(q_ss % 8 == 0 && q_sh % 8 == 0 && q_sb % 8 == 0 && k_ss % 8 == 0 && k_sh % 8 == 0 && k_sb % 8 == 0 && v_ss % 8 == 0 &&
                v_sh % 8 == 0 && v_sb % 8 == 0 && o_ss % 4 == 0 && o_sh % 4 == 0 && o_sb % 4 == 0,
            VG_ERR_ARG, "vg_window_attention: strides must keep 16-byte (q/k/v) / 8-byte (o) alignment");
   VG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && (((uintptr_t)O) & 7) == 0, VG_ERR_ARG,
            "vg_window_attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
-  WinAttnArgs p{Q, K, V, O, Bw, H, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
   hipStream_t st = (hipStream_t)stream;
+  if (tiny) {
+    TinyAttnArgs t{Q, K, V, O, Bw, H, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
+    if (wq == 16 && wtok == 16) return launch_tiny_win<72, 16, 16>(t, st);
+    if (wq == 64) return launch_tiny_win<72, 64, 64>(t, st);
+    if (wq == 4) return launch_tiny_win<72, 4, 16>(t, st);
+    return launch_tiny_win<72, 16, 64>(t, st);
+  }
+  WinAttnArgs p{Q, K, V, O, Bw, H, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale};
   if (D == 72) return launch_win256<72>(p, st);
   if (D == 64) return launch_win256<64>(p, st);
   return launch_win256<80>(p, st);

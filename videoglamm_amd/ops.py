@@ -208,21 +208,35 @@ def attention(q, k, v, scale, causal=False, window=0):
     return out
 
 
+_WIN_SHAPES = {(256, 256), (16, 16), (64, 64), (4, 16), (16, 64)}
+
+
+def window_attention(q, k, v, scale):
+    """Hiera's windowed attention on the dedicated kernels (vg_window_attention): q [Bw, wq, H, D], k / v [Bw, wk, H, D] strided
+    views (head dim contiguous).  Returns None for shapes those kernels do not take (the caller falls back to vg_attention)."""
+    Bw, wq, H, D = q.shape
+    wk = k.shape[1]
+    ok = (q.dtype == torch.bfloat16 and (wq, wk) in _WIN_SHAPES and k.shape == (Bw, wk, H, D) and v.shape == k.shape
+          and all(t.stride(3) == 1 for t in (q, k, v)) and (D == 72 or (wq == 256 and D in (64, 80))) and (wq != 256 or Bw <= 65535))
+    if not ok:
+        return None
+    lib = _lib.load()
+    out = torch.empty(Bw, wq, H, D, dtype=q.dtype, device=q.device)
+    rc = lib.vg_window_attention(_p(q), _p(k), _p(v), _p(out), Bw, H, wq, wk, D, q.stride(0), q.stride(1), q.stride(2),
+                                 k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+                                 out.stride(0), out.stride(1), out.stride(2), float(scale), _dt(q), _stream())
+    _lib.check(rc, "vg_window_attention")
+    return out
+
+
 def attention_windows(q, k, v, scale):
     """Self-attention inside many small independent windows: q/k/v [Bw, wtok, H, D] views of one fused projection.
     Windows are packed back to back into 128-token sequences under a block-diagonal mask (vg_attention, causal = -wtok),
     so a 16-token window costs 1/8 of a query tile instead of a whole padded one.  Falls back to attention() when the
     windows do not pack (wtok >= 128, odd strides, or a window count that is not a multiple of the pack)."""
     Bw, wtok, H, D = q.shape
-    if (wtok == 256 and q.dtype == torch.bfloat16 and D in (64, 72, 80) and k.shape == q.shape and v.shape == q.shape and Bw <= 65535
-            and all(t.stride(3) == 1 for t in (q, k, v))):
-        # Hiera's 16x16 windows: one workgroup per (window, head), K / V of the window staged once (vg_window_attention)
-        lib = _lib.load()
-        out = torch.empty(Bw, wtok, H, D, dtype=q.dtype, device=q.device)
-        rc = lib.vg_window_attention(_p(q), _p(k), _p(v), _p(out), Bw, H, wtok, D, q.stride(0), q.stride(1), q.stride(2),
-                                     k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
-                                     out.stride(0), out.stride(1), out.stride(2), float(scale), _dt(q), _stream())
-        _lib.check(rc, "vg_window_attention")
+    out = window_attention(q, k, v, scale)
+    if out is not None:
         return out
     pack = 128 // wtok if wtok > 0 else 0
     ok = (pack >= 2 and Bw % pack == 0 and k.shape == q.shape and v.shape == q.shape

@@ -146,9 +146,10 @@ class SAM2:
             h, w = h // 2, w // 2
             q = q.view(Bw, h * w, nh, hd)
         if ws > 0 and not blk["q_stride"]:
-            o = ops.attention_windows(q, k, v, hd ** -0.5).view(Bw, h * w, do)    # 16/64-token windows share query tiles
+            o = ops.attention_windows(q, k, v, hd ** -0.5).view(Bw, h * w, do)    # per-window kernels / windows packed into query tiles
         else:
-            o = ops.attention(q, k, v, hd ** -0.5).view(Bw, h * w, do)
+            o = ops.window_attention(q, k, v, hd ** -0.5) if ws > 0 else None    # q-pooled windows (4 x 16, 16 x 64) on their own kernel
+            o = (o if o is not None else ops.attention(q, k, v, hd ** -0.5)).view(Bw, h * w, do)
         Hs, Ws = shortcut.shape[1:3]
         if ws > 0:
             # proj + window_unpartition + residual add in one pass (rows scattered to their pixels by the epilogue)
