@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvgkernels.so")
+LIB_PATH = os.environ.get("VG_KERNELS_SO") or os.path.join(_HERE, "csrc", "libvgkernels.so")      # (override: diagnostic builds)
 
 _lib = None
 

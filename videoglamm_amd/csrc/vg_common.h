@@ -84,6 +84,15 @@ __device__ __forceinline__ float vg_act(float x, int act) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences GLOBAL memory: the compiler waits for vmcnt(0),
+// i.e. for every global store the wave has issued to be acknowledged — inside a multi-pass GEMM epilogue that exposes the full
+// store latency once per pass (measured r02, 256x256-tile kernel on M = 32768, N = 2304, K = 576: 168 -> 105 us without the waits).
+__device__ __forceinline__ void vg_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // row index of accumulator register r for lane-half h in the 32x32 MFMA C/D layout
 __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -32,6 +32,7 @@ struct GemmArgs {
   // split-K (vg_gemm_splitk, 128x128 LDS-DMA kernel only): blockIdx.z = K slice of kchunk elements; raw fp32 partial tiles
   // go to part[z][M][N], a second kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
+  int stagger;  // 256x256 kernels: first-round workgroup w sleeps (w & 3) * stagger * ~4 us before its first load (phase desynchronisation knob)
 };
 
 // window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
@@ -678,12 +679,12 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if (i) __syncthreads();
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
+    vg_lds_barrier();
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int ml = pass * 8 + rsub;
@@ -854,12 +855,12 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if (i) __syncthreads();
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
+    vg_lds_barrier();
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int ml = pass * 8 + rsub;
@@ -1140,12 +1141,12 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_w128_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (i) __syncthreads();
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
+    vg_lds_barrier();
     if (p.a_op == 1) {
       // SwiGLU: waves (wm,0) / (wm,1) staged the gate / up halves of the same 32 rows x 128 outputs; each finishes 16
       // of the rows: y = round(silu(round(gate + b_g))) * round(up + b_u)  (the arithmetic of gemm_epilogue128's GLU)
@@ -1241,6 +1242,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
   const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
   const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  if (p.stagger > 0 && lin < 256) {          // first round only: later rounds inherit the phase shift
+    const int n = (lin & 3) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int bm, bn;
   gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
   const int bz = blockIdx.z;
@@ -1335,6 +1340,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   step(kt, kt & 1, false);
+#if defined(VG_W128X8_DIAG) && VG_W128X8_DIAG == 2
+  if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f;   // diagnostic build: no epilogue at all (keeps the accumulators live)
+  return;
+#endif
   __syncthreads();   // the epilogue reuses the ring as fp32 staging: 8 waves x 32 rows x 68 floats
 
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
@@ -1351,12 +1360,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (i) __syncthreads();
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
+    vg_lds_barrier();
     if (p.a_op == 1) {
       // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows
       const float* wg = (const float*)smem + (wm * 4 + (wn & 1)) * 32 * ES;
@@ -1404,6 +1413,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
       for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
       TO* cp = C + (int64_t)m * p.ldc + n0;
       const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+#if defined(VG_W128X8_DIAG) && VG_W128X8_DIAG == 1
+      if (v[0] == 12345.678f) C[0] = (TO)0;    // diagnostic build: the LDS-staged epilogue without its global stores
+      continue;
+#endif
       if (n0 + 8 <= N && p.vec_out) {
         if constexpr (sizeof(TO) == 2) {
           if (rp) {
@@ -1654,6 +1667,8 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     if (big) {
       dim3 gridw(ntw, mtw, batch);
       q.gn = pick_gn(mtw, ntw);
+      static const int stagger = env_knob("VG_W128_STAGGER", 0);
+      q.stagger = stagger;
       if (knob_w128() != 2 && knob_w128() != 5) gemm_tile_w128x8_kernel<T, TO><<<gridw, 512, 2 * 2 * 256 * 128, st>>>(q);   // 2 / 5: the 4-wave kernel
       else gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
     } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
