@@ -221,7 +221,7 @@ def test_attention_fused_qkv_strides_and_spike(cuda):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,C", [(5, 4), (1025, 1408), (64, 256), (3, 4096), (4096, 64),
-                                    (40000, 288), (70001, 144), (33000, 512), (36000, 1152), (2500, 4100)])   # more rows than any persistent grid covers in one pass
+                                    (40000, 288), (70001, 144), (33000, 512), (36000, 1152), (2500, 4100), (4101, 576), (300001, 576)])   # more rows than any persistent grid covers in one pass
 def test_norms(cuda, dtype, rows, C):
     from videoglamm_amd import ops
     x = rnd(rows, C, dtype=dtype, seed=1) + 3.0

@@ -2,6 +2,7 @@
 // fp32 statistics, two-pass variance (mean first) like torch's native_layer_norm.
 #include "vg_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 template <typename T> struct RowVec;
 template <> struct RowVec<bf16_t> {
@@ -200,6 +201,97 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
   }
 }
 
+// Short bf16 rows (Hiera's LayerNorms: C = 144 / 288 / 576 / 1152, 65536 - 1M rows per launch).  TPR lanes own a row and EVERY lane
+// carries NJ 16-byte chunks of it (576 = 8 lanes x 9 chunks: no masked lanes; the one-wave-per-row kernel above issues a second,
+// 12 %-used load per row there and holds weight / bias in 64 registers: 1.8 TB/s on stage 3).  Weight and bias live in LDS as fp32,
+// the raw row stays packed in registers (unpacked on the fly in each of the three passes), the next row group is requested before
+// the current one is reduced.  Same two-pass fp32 statistics as norm_kernel.
+template <bool RMS, int TPR, int NJ>
+__global__ __launch_bounds__(256) void norm_short_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, bf16_t* __restrict__ y, int64_t ldy,
+                                                         int64_t rows, int C, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float nwb[];      // gamma[C] | beta[C]
+  constexpr int RPB = 256 / TPR;
+  for (int i = threadIdx.x; i < C; i += 256) { nwb[i] = w ? w[i] : 1.f; nwb[C + i] = b ? b[i] : 0.f; }
+  __syncthreads();
+  const int t = threadIdx.x % TPR, sub = threadIdx.x / TPR;
+  const int64_t ngroups = (rows + RPB - 1) / RPB;
+  auto reduce = [&](float v) {
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto rowload = [&](int64_t grp, u32x4_t (&r)[NJ]) {
+    const int64_t rw = min(grp * RPB + sub, rows - 1);       // clamped: the load is unconditional
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = (t + j * TPR) * 8;
+      r[j] = *(const u32x4_t*)(x + rw * ldx + (c < C ? c : 0));
+    }
+  };
+  u32x4_t cur[NJ], nxt[NJ];
+  rowload(blockIdx.x, cur);
+  const float invC = 1.0f / (float)C;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    rowload(min(grp + (int64_t)gridDim.x, ngroups - 1), nxt);
+    const int64_t row = grp * RPB + sub;
+    float s = 0.f;
+    if (!RMS) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if ((t + j * TPR) * 8 < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s += __uint_as_float(cur[j][e] << 16) + __uint_as_float(cur[j][e] & 0xffff0000u);
+        }
+    }
+    const float mean = RMS ? 0.f : reduce(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if ((t + j * TPR) * 8 < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = __uint_as_float(cur[j][e] << 16) - mean, d1 = __uint_as_float(cur[j][e] & 0xffff0000u) - mean;
+          q += d0 * d0 + d1 * d1;
+        }
+      }
+    const float rstd = rsqrtf(reduce(q) * invC + eps);
+    if (row < rows) {
+      bf16_t* yr = y + row * ldy;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = (t + j * TPR) * 8;
+        if (c < C) {
+          const f32x4_t w0 = *(const f32x4_t*)(nwb + c), w1 = *(const f32x4_t*)(nwb + c + 4);
+          const f32x4_t b0 = *(const f32x4_t*)(nwb + C + c), b1 = *(const f32x4_t*)(nwb + C + c + 4);
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float n0 = (__uint_as_float(cur[j][e] << 16) - mean) * rstd, n1 = (__uint_as_float(cur[j][e] & 0xffff0000u) - mean) * rstd;
+            if (RMS) { n0 = bf2f(f2bf(n0)); n1 = bf2f(f2bf(n1)); }       // the reference rounds the normalised value before the weight
+            const float g0 = e < 2 ? w0[2 * e] : w1[2 * e - 4], g1 = e < 2 ? w0[2 * e + 1] : w1[2 * e - 3];
+            const float a0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], a1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+            o[2 * e] = RMS ? n0 * g0 : n0 * g0 + a0;
+            o[2 * e + 1] = RMS ? n1 * g1 : n1 * g1 + a1;
+          }
+          row_store<bf16_t, 8>(yr + c, o);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cur[j] = nxt[j];
+  }
+}
+
+template <bool RMS, int TPR, int NJ>
+static void launch_norm_short(const bf16_t* x, int64_t ldx, const float* w, const float* b, bf16_t* y, int64_t ldy, int64_t rows, int C,
+                              float eps, hipStream_t st) {
+  const int64_t ngroups = (rows + 256 / TPR - 1) / (256 / TPR);
+  const int64_t cap = 256 * (NJ >= 9 ? 4 : 8);          // resident workgroups per CU at the kernel's register footprint
+  const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
+  norm_short_kernel<RMS, TPR, NJ><<<grid, 256, 2 * C * sizeof(float), st>>>(x, ldx, w, b, y, ldy, rows, C, eps);
+}
+
 template <typename TI, typename TO, bool RMS>
 static void launch_norm_t(const void* x, int64_t ldx, const float* w, const float* b, void* y, int64_t ldy, int64_t rows,
                           int C, float eps, hipStream_t st) {
@@ -208,6 +300,17 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
   const TI* xi = (const TI*)x;
   TO* yo = (TO*)y;
   const unsigned pgrid = 256 * 8;   // persistent cap of the register-resident path: 8 workgroups per CU
+  if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2) {
+    static const bool short_rows = !getenv("VG_NORM_SHORT") || atoi(getenv("VG_NORM_SHORT")) != 0;
+    if (short_rows && vec && rows >= 4096 && (((uintptr_t)w | (uintptr_t)b) % 16 == 0)) {      // Hiera's LayerNorm widths, every lane loaded
+      const bf16_t* xs = (const bf16_t*)x;
+      bf16_t* ys = (bf16_t*)y;
+      if (C == 576) return launch_norm_short<RMS, 8, 9>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
+      if (C == 1152) return launch_norm_short<RMS, 16, 9>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
+      if (C == 288) return launch_norm_short<RMS, 8, 5>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
+      if (C == 144) return launch_norm_short<RMS, 8, 3>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
+    }
+  }
   if (rows < 1024 || (vec && C > 64 * NV * 4)) {   // few rows, or rows too long for one wave's registers
     dim3 grid((unsigned)rows);
     if (vec && C <= 256 * NV * 4 && grid.x > pgrid) grid.x = pgrid;
