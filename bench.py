@@ -12,7 +12,7 @@ dual vision encoders -> V-L adapters -> Llama-3-8B prefill + 32 greedy decode st
 Workload at N=1 = BASELINE config C2, the configuration BASELINE.json's metric is quoted on (32-frame 1024^2 clip
 -> 32 x 1024^2 SAM frames, masks returned at 1024^2, Te=16 encoder frames -> 3361-row prompt, Llama-3-8B bf16,
 InternVideo2-1B, CLIP-L/336, SAM2-L, one [SEG] object).  N>1: weak scaling, 32 SAM frames per rank (clip of 32N frames,
-frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding and of the masks).
+frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding; every rank keeps the masks of its frames on its host).
 Weights are random-init of the exact architectures (no network / no public Llama VideoGLaMM checkpoint).
 The line is self-checking ("quality"): after the timed region the same clip is re-run ONCE in fp32 parity mode on the
 GPU (same bf16-rounded weights, teacher-forced to the bf16 run's ids) and the bf16 masks / argmaxes are compared with it.
@@ -467,7 +467,7 @@ def main():
                                f"Te={args.te}, {'Llama-3-8B' if args.llm == 'llama3-8b' else 'Phi-3-mini'} bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
                                f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),
                    "frames": T, "encoder_frames": args.te, "generated_tokens": int(out_ids.shape[1] - ids.shape[1]),
-                   "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": f"frames sharded x{world}, LLM replicated",
+                   "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": f"frames sharded x{world} (masks stay with the rank that made them), LLM replicated",
                    "weights": "random-init (synthetic)"},
         "load_s": round(t_load, 1),
     }

@@ -34,23 +34,31 @@ def _worker(rank, world, port, q):
     T, N, hw = 4, 2, (40, 56)
     images = G.rnd((T, 3, 256, 256), 11)
     text = G.rnd((N, 256), 12, 0.5)
-    comm = FrameSharder()
+    comm = FrameSharder(gather_masks=True)
     assert comm.my_frames(T) == [2 * rank, 2 * rank + 1]
     # a rank-dependent perturbation must be overwritten by rank 0's copy
     emb = comm.sync_seg_embeddings(text + 0.01 * rank)
     assert torch.equal(emb, text)
-    masks = comm.framewise(m, images, text + 0.01 * rank, hw)
+    masks, fids = comm.framewise(m, images, text + 0.01 * rank, hw)
+    assert fids == [0, 1, 2, 3]
+    shard = FrameSharder()                          # default: no mask collective, every rank keeps its own frames / objects
+    local, lf = shard.framewise(m, images, text, hw)
+    assert lf == [2 * rank, 2 * rank + 1] and torch.equal(local, masks[2 * rank:2 * rank + 2])
     feats = comm.hiera_all_frames(m, images)
     vid = m.video_branch(images, emb, hw, frame_feats=feats)
     # object-sharded propagation: rank r runs the recurrence for its object, masks all-gathered along the object axis
-    vid_obj = comm.video_branch_objects(m, images, emb, hw, feats)
+    vid_obj, oids = comm.video_branch_objects(m, images, emb, hw, feats)
+    lobj, lo = shard.video_branch_objects(m, images, emb, hw, feats)
+    assert oids == [0, 1] and lo == [rank] and torch.equal(lobj, vid_obj[:, rank:rank + 1])
     # uneven splits: 3 frames / 3 objects over 2 ranks (blocks 2 + 1), 1 frame (rank 1 has none)
     assert FrameSharder.my_frames(comm, 3) == ([0, 1] if rank == 0 else [2]) and FrameSharder.my_frames(comm, 1) == ([0] if rank == 0 else [])
     text3 = G.rnd((3, 256), 13, 0.5)
-    masks3 = comm.framewise(m, images[:3], text3, hw)
+    masks3, _ = comm.framewise(m, images[:3], text3, hw)
     feats3 = comm.hiera_all_frames(m, images[:3])
-    vid3 = comm.video_branch_objects(m, images[:3], text3, hw, feats3)
-    masks1 = comm.framewise(m, images[:1], text, hw)
+    vid3, _ = comm.video_branch_objects(m, images[:3], text3, hw, feats3)
+    masks1, _ = comm.framewise(m, images[:1], text, hw)
+    l1, lf1 = shard.framewise(m, images[:1], text, hw)
+    assert lf1 == ([0] if rank == 0 else []) and l1.shape[0] == len(lf1)
     # vision towers sharded by CLIP frame / InternVideo2 chunk (Te = 4: one chunk -> rank 1 has none; two frames each)
     from test_oracle_e2e import e2e_setup
     from videoglamm_amd.vlm import VisionTowers

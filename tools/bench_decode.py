@@ -23,7 +23,7 @@ llm = cfg["llm"]
 nbytes = sum(v.numel() * 2 for k, v in sd.items() if "embed_tokens" not in k)
 for fused in ("0", "1"):
     os.environ["VG_DECODE_FUSED"] = fused
-    dec = LlamaDecoder(P, llm, 2048)
+    dec = LlamaDecoder(P, llm, -(-(S + G + 2) // 1024) * 1024)
     x = (torch.randn(S, llm["hidden"], device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.02).to(torch.bfloat16)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

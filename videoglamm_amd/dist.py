@@ -11,7 +11,9 @@ What shards naturally and what does not:
   * The two vision towers are independent per CLIP frame / per 4-frame InternVideo2 chunk: each rank encodes and
     projects its block of frames / chunks, the projected, pooled tokens (a few MB) are all-gathered, so the replicated LLM
     sees identical visual tokens everywhere and the towers cost 1/world of a clip instead of a whole one per rank.
-  * Results: uint8 masks of the local frames, all-gathered so that rank 0 (and everyone) holds the clip.
+  * Results: every rank returns the masks of ITS frames (framewise) / ITS objects (video branch) under their global indices —
+    no data-path collective; FrameSharder(gather_masks=True) all-gathers the uint8 masks so that every rank holds the whole clip
+    (33.5 MB per 32 frames at 1024^2: the host copy of an N-times larger result on every rank is what breaks weak scaling).
   * Video-branch propagation is a recurrence over frames (memory of t-1..t-6), so frames do not shard there — OBJECTS do
     (non_overlap_masks_for_mem_enc is unset: objects never interact, R/.../sam2_video_predictor.py:571-612): the per-frame Hiera
     features are all-gathered (8.4 MB bf16 per frame at SAM2-L), rank r propagates its block of the N [SEG] objects and the
@@ -26,9 +28,10 @@ from . import ops
 
 
 class FrameSharder:
-    def __init__(self, group=None):
+    def __init__(self, group=None, gather_masks=False):
         assert dist.is_initialized(), "init torch.distributed first (torchrun: one process per GPU)"
         self.group = group
+        self.gather_masks = gather_masks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -83,7 +86,8 @@ class FrameSharder:
         return self._all_gather(emb)[0]
 
     def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None, binarize=None):
-        """frame-sharded Hiera + mask decode; returns the whole clip's masks as host uint8 [T,N,H,W].
+        """frame-sharded Hiera + mask decode -> (device uint8 masks [frames, N, H, W], their global frame indices): this rank's frames,
+        or the whole clip when gather_masks is set.
         frame_feats: optional precomputed Hiera features of THIS rank's frames ({frame: [3 levels]});
         binarize: logits -> uint8 masks of this rank's frames (per-frame work, so it shards with them); None = logit > 0, made
         in one pass from the low-res logits."""
@@ -94,23 +98,27 @@ class FrameSharder:
         if frames:
             out, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats, as_masks=binarize is None)
             local = out if binarize is None else binarize(out)             # [frames of this rank, N, H, W] uint8, on device
-        return self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device).cpu()
+        if not self.gather_masks:
+            return (local if local is not None else torch.zeros((0, N) + tuple(hw), dtype=torch.uint8, device=emb.device)), frames
+        return self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(T))
 
     def video_branch_objects(self, sam2, images_for_sam, emb, hw, frame_feats, binarize=None, **kw):
         """object-sharded SAM2 propagation: every rank holds the Hiera features of ALL frames (gather_frame_feats) and runs the
-        recurrence for its block of the N objects (they never interact); masks all-gathered along the object axis ->
-        host uint8 [T,N,H,W].  With fewer objects than ranks the surplus ranks only take part in the collectives; N = 1:
-        replicas only — every rank propagates the single object (no exchange, identical results)."""
+        recurrence for its block of the N objects (they never interact) -> (device uint8 masks [T, objects, H, W], their global object
+        indices): this rank's objects, or all N (all-gathered along the object axis) when gather_masks is set.  With fewer objects
+        than ranks the surplus ranks hold none; N = 1: replicas only — every rank propagates the single object (no exchange)."""
         T, N = images_for_sam.shape[0], emb.shape[0]
         if N == 1:
             out = sam2.video_branch(images_for_sam, emb, hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
-            return (out if binarize is None else binarize(out)).cpu()
+            return (out if binarize is None else binarize(out)), [0]
         o0, on = self.block(N)
         local = None
         if on:
             out = sam2.video_branch(images_for_sam, emb[o0:o0 + on], hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
             local = out if binarize is None else binarize(out)             # [T, objects of this rank, H, W]
-        return self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device).cpu()
+        if not self.gather_masks:
+            return (local if local is not None else torch.zeros((T, 0) + tuple(hw), dtype=torch.uint8, device=emb.device)), list(range(o0, o0 + on))
+        return self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(N))
 
     def gather_frame_feats(self, local_feats, T):
         """all-gather per-frame FPN features ({frame: [3 levels]} of this rank's frames) -> the same for all T frames."""

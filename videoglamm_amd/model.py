@@ -277,10 +277,13 @@ class VideoGLaMMForCausalLM:
         return ops.remove_small_blobs(masks, self.min_blob_size) if self.min_blob_size > 0 else masks
 
     @staticmethod
-    def _segments(mask_u8):
-        """[T,N,H,W] uint8 (0 / 1) on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875)."""
+    def _segments(mask_u8, frame_ids=None, obj_ids=None):
+        """[T,N,H,W] uint8 (0 / 1) on host -> {frame: {obj: bool ndarray [H,W]}} (VideoGLaMM.py:757-766, 869-875); frame_ids / obj_ids:
+        the global indices of the rows / columns (multi-GPU shards), default 0..T-1 / 0..N-1."""
         m = mask_u8.numpy().view(bool)       # 0 / 1 bytes ARE numpy bools: no second pass over the clip's masks
-        return {t: {k: m[t, k] for k in range(m.shape[1])} for t in range(m.shape[0])}
+        frame_ids = range(m.shape[0]) if frame_ids is None else frame_ids
+        obj_ids = range(m.shape[1]) if obj_ids is None else obj_ids
+        return {t: {k: m[i, j] for j, k in enumerate(obj_ids)} for i, t in enumerate(frame_ids)}
 
     def _fast_masks(self):
         """thresholded masks straight from the low-res logits (vg_bilinear_mask) unless something needs the fp32 logits"""
@@ -328,7 +331,9 @@ class VideoGLaMMForCausalLM:
             raise AttributeError("'tuple' object has no attribute 'shape'")
         hw = tuple(original_size_list[0])
         if self.comm is not None:
-            masks = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=None if self._fast_masks() else self._binarize)
+            # this rank's frames under their global indices (the whole clip when the sharder gathers the masks)
+            masks, fids = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=None if self._fast_masks() else self._binarize)
+            return out_ids, [self._segments(self._to_host(masks), frame_ids=fids)]
         elif self._fast_masks():
             masks = self._to_host(self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats, as_masks=True)[0])
         else:
@@ -350,8 +355,8 @@ class VideoGLaMMForCausalLM:
             # frames shard for Hiera only (the propagation is a recurrence over frames); OBJECTS shard for the propagation
             emb = self.comm.sync_seg_embeddings(emb)
             feats = self.comm.gather_frame_feats(feats, sam.shape[0])
-            masks = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
-            return out_ids, [self._segments(masks)]
+            masks, oids = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
+            return out_ids, [self._segments(self._to_host(masks), obj_ids=oids)]
         if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "0") == "1":
             # the propagation replayed from a HIP graph: same results, measured neutral (r01: 201.05 vs 200.51 ms per clip), off by default
             logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)
