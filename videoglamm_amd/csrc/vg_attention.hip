@@ -11,6 +11,7 @@
 // LDS rows are padded by 16 B so the 16-byte fragment reads are bank-conflict free.
 #include "vg_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 struct AttnArgs {
   const void* Q; const void* K; const void* V; void* O;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #endif
 
 template <typename T, int DP, int BKV, int NW>
-__global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? VG_ATTN_MINW : 1))) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? VG_ATTN_MINW : 1)))) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int KPC = 16 / ES;
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(NW * 64, (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int split = blockIdx.x % p.nsplit;
-  const int q0 = (blockIdx.x / p.nsplit) * BQ, head = blockIdx.y, b = blockIdx.z;
+  // causal: the LAST query tiles walk the most keys — hand them out first, so the short ones fill the tail of the launch
+  const int qtile = (p.causal > 0 && !p.fold) ? ((int)gridDim.x / p.nsplit - 1 - (int)blockIdx.x / p.nsplit) : (int)blockIdx.x / p.nsplit;
+  const int q0 = qtile * BQ, head = blockIdx.y, b = blockIdx.z;
   const int G = p.Hq / p.Hkv;
   const int kvh = p.fold ? head : head / G;
   const int D = p.D, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
@@ -797,7 +800,15 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   hipStream_t st = (hipStream_t)stream;
   // (measured: a 1-wave workgroup for <= 32 query rows is SLOWER — 50 vs 31 us per decode launch — because the
   // K/V tile staging, not the MFMA work, dominates a few-row block and 64 threads stage 4x slower than 256)
-  int rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
+  // long bf16 sequences (LLM prefill, Hiera's global blocks): 8 waves = 256 query rows share every staged K/V tile (VG_ATTN_NW8, A/B knob)
+  // measured r02: +5 % on Hiera's global blocks (4096^2, d = 72), -6 % on the causal LLM prefill (coarser diagonal), -12 % at S = 1025
+  static const int nw8 = getenv("VG_ATTN_NW8") ? atoi(getenv("VG_ATTN_NW8")) : 1;
+  int rc;
+  if (dtype == VG_BF16 && nw8 && !p.fold && nsplit == 1 && Sq >= 2048 && D > 64 && D <= 128 && causal == 0) {
+    rc = D <= 96 ? launch_attn<bf16_t, 96, 64, 8>(p, st) : launch_attn<bf16_t, 128, 64, 8>(p, st);
+  } else {
+    rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);
+  }
   if (rc != VG_OK || nsplit == 1) return rc;
   dim3 grid(Sq, Hq, B);
   if (dtype == VG_BF16) attn_combine_kernel<bf16_t><<<grid, 256, 0, st>>>(p);
