@@ -221,7 +221,7 @@ def test_attention_fused_qkv_strides_and_spike(cuda):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,C", [(5, 4), (1025, 1408), (64, 256), (3, 4096), (4096, 64),
-                                    (40000, 288), (70001, 144), (33000, 512), (36000, 1152), (2500, 4100), (4101, 576), (300001, 576)])   # more rows than any persistent grid covers in one pass
+                                    (40000, 288), (70001, 144), (33000, 512), (36000, 1152), (2500, 4100), (4101, 576), (300001, 576), (4100, 1408), (9232, 1024), (3361, 4096), (3361, 3072)])   # more rows than any persistent grid covers in one pass
 def test_norms(cuda, dtype, rows, C):
     from videoglamm_amd import ops
     x = rnd(rows, C, dtype=dtype, seed=1) + 3.0
@@ -230,6 +230,10 @@ def test_norms(cuda, dtype, rows, C):
     close(ops.rmsnorm(x.to(cuda), w.to(cuda), 1e-5), ref.rmsnorm(x, w, 1e-5), **tol(dtype))
     close(ops.layernorm(x.to(cuda), w.to(cuda), b.to(cuda), 1e-6, out_dtype=torch.float32),
           ref.layernorm(x, w, b, 1e-6, out_dtype=torch.float32), **tol(dtype))
+    if C % 8 == 0 and rows <= 40000:      # strided rows: the q / k slices of a fused q|k|v projection (InternVideo2's QK-RMSNorm)
+        wide = rnd(rows, 3 * C, dtype=dtype, seed=4)
+        g = wide.to(cuda)
+        close(ops.rmsnorm(g[:, C:2 * C], w.to(cuda), 1e-6), ref.rmsnorm(wide[:, C:2 * C], w, 1e-6), **tol(dtype))
 
 
 @pytest.mark.parametrize("dtype", DT)
