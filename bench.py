@@ -450,7 +450,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt[0])
     out_ids, segs = out
-    n_obj = len(segs[0][0]) if segs[0] else 0
+    n_obj = len(next(iter(segs[0].values()))) if segs[0] else 0      # (a rank's dict holds ITS frames under their global indices)
     name = "C1" if (args.frames_per_gpu, args.src, args.objects, args.te) == (8, 512, 1, 8) else "C2" if (args.frames_per_gpu, args.src, args.objects, args.te) == (32, 1024, 1, 16) \
         else "C4 share of one GPU (64 frames / 8)" if (args.frames_per_gpu, args.src, args.objects) == (8, 1024, 8) else "custom"
     if args.llm != "llama3-8b":
