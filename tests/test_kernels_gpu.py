@@ -303,6 +303,10 @@ def test_spatial(cuda, dtype):
     close(ops.pool2(g, False), ref.pool2(x, False), **tol(dtype))
     fused = rnd(2, 12, 20, 24, dtype=dtype, seed=5)
     close(ops.pool2(fused.to(cuda)[..., 8:16], True), ref.pool2(fused[..., 8:16], True), rtol=0, atol=0)
+    big = rnd(3, 16, 24, 3 * 144, dtype=dtype, seed=6)         # Hiera's q slice of a fused projection: 8 channels per thread in bf16
+    close(ops.pool2(big.to(cuda)[..., :144], True), ref.pool2(big[..., :144], True), rtol=0, atol=0)
+    close(ops.pool2(big.to(cuda)[..., :144], False), ref.pool2(big[..., :144], False), **tol(dtype))
+    close(ops.pool2(big.to(cuda)[..., 4:148], True), ref.pool2(big[..., 4:148], True), rtol=0, atol=0)      # misaligned view: scalar kernel
     for ws in (4, 5, 7):
         wn = ops.window_partition(g, ws)
         close(wn, ref.window_partition(x, ws), rtol=0, atol=0)
