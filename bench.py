@@ -175,13 +175,31 @@ class AttnMeter:
             e1.record()
             del self.rec[n0:]            # (the unpacked fallback goes through ops.attention: count it once, here)
             Bw, wtok, H, D = q.shape
-            self.rec.append((4.0 * Bw * H * wtok * wtok * D, e0, e1, self.dp(D), (Bw, H, wtok, wtok, D)))
+            own = q.dtype == torch.bfloat16 and D == 72 and wtok in (16, 64, 256)        # vg_window_attention's kernels
+            self.rec.append((4.0 * Bw * H * wtok * wtok * D, e0, e1, "window" if own else self.dp(D), (Bw, H, wtok, wtok, D)))
             return y
+
+        def timed_pooled(q, k, v, scale):       # q-pooled windows (4 x 16, 16 x 64): None = not taken by the window kernels
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.o_pool(q, k, v, scale)
+            e1.record()
+            if y is not None:
+                Bw, wq, H, D = q.shape
+                self.rec.append((4.0 * Bw * H * wq * k.shape[1] * D, e0, e1, "window", (Bw, H, wq, k.shape[1], D)))
+            return y
+        self.o_pool = self.ops.window_attention
+        self._in_win = False
         self.ops.attention, self.ops.attention_windows = timed, timed_win
+
+        def pooled_or_inner(q, k, v, scale):     # attention_windows calls window_attention itself: meter only the direct (q-pooled) calls
+            return self.o_pool(q, k, v, scale) if q.shape[1] == k.shape[1] else timed_pooled(q, k, v, scale)
+        self.ops.window_attention = pooled_or_inner
         return self
 
     def __exit__(self, *exc):
         self.ops.attention, self.ops.attention_windows = self.o_attn, self.o_win
+        self.ops.window_attention = self.o_pool
 
     def summary(self):
         torch.cuda.synchronize()
@@ -532,11 +550,17 @@ def main():
                                         "avg_launch_us": round(avg, 1), "kernel_ms_per_step": round(per_step, 2),
                                         "note": "timed on eager replays of the decode step; the timed region runs it inside a HIP graph"}
         # attention kernels, one object per head-dim instantiation (the north star's "attention-GEMM roofline": QK^T and PV on the MFMA)
-        for dp, (fl, ms, n) in sorted(am.summary().items()):
+        for dp, (fl, ms, n) in sorted(am.summary().items(), key=lambda kv: str(kv[0])):
             if ms <= 0:
                 continue
             ach = fl / (ms * 1e-3) / 1e12
-            roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": f"attn_kernel<bf16, {dp}, 64, 4> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)",
+            if dp == "window":
+                roofs["attn_window"] = {"bound": "hbm", "kernel": "win256_attn_kernel<72> / tiny_win_attn_kernel<72, wq, wk> (Hiera's windows: one workgroup per 256-token window and head, "
+                                                                    "one wave per 16- / 64-token window and head; bounded by the fused q|k|v projection's bytes)",
+                                        "achieved_tflops": round(ach, 1), "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+                                        "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2), "traffic": traffic_of("attn_window")}
+                continue
+            roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": f"attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)",
                                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
                                     "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
                                     "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2)}

@@ -508,6 +508,21 @@ def _check_big_gemm(cuda, M, N, K, glu):
     close(y32, ref.linear(x, w, out_dtype=torch.float32), rtol=2e-3, atol=2e-3)
 
 
+def test_gemm_tail_rows_split(cuda):
+    """M = 13 x 256 + 33 rows on the 256x256-tile route: when dropping the last row of tiles saves a round of 256 workgroups, ops.linear sends
+    the 33 tail rows through their own launch (GLU epilogue, residual and plain) — same values as the one-launch result up to bf16 rounding."""
+    from videoglamm_amd import _lib, ops
+    M, N, K = 3361, 14336, 4096
+    assert _lib.load().vg_gemm_route(M, N, K, 1, 1, 0) == 3
+    x = rnd(M, K, dtype=torch.bfloat16, seed=1)
+    w = rnd(2 * N, K, dtype=torch.bfloat16, seed=2, scale=K ** -0.5)
+    y = ops.linear(x.to(cuda), w.to(cuda), glu=True)
+    close(y[-40:], ref.linear(x[-40:], w, glu=True), rtol=2e-2, atol=2e-2)          # the tail launch ...
+    close(y[:300], ref.linear(x[:300], w, glu=True), rtol=2e-2, atol=2e-2)          # ... and the head
+    head = ops.linear(x[:3328].to(cuda), w.to(cuda), glu=True)                       # whole tiles only: the head rows are bit-identical
+    assert torch.equal(y[:3328], head)
+
+
 @pytest.mark.parametrize("M,N,K,glu", BIG)
 def test_gemm_w128x8(cuda, M, N, K, glu):
     """the default (eight-wave) 256x256-tile kernel on the bench's heaviest bf16 GEMMs, against the fp32 statement."""

@@ -19,7 +19,8 @@ CLASSES = [
     ("attn_d96", r"attn_kernel<unsigned short, 96,"),
     ("attn_d128", r"attn_kernel<unsigned short, 128,"),
     ("attn_d256", r"attn_kernel<unsigned short, 256,"),
-    ("twoway", r"twoway_"),
+    ("attn_window", r"win256_attn_kernel|tiny_win_attn_kernel"),
+    ("norm_short", r"norm_short_kernel"),
 ]
 
 

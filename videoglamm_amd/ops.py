@@ -85,12 +85,17 @@ def _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, o
     return y
 
 
+import os as _os
+_TAILSPLIT = _os.environ.get("VG_GEMM_TAILSPLIT", "1") != "0"
+
+
 def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
     """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K).
     glu: w is [2N, K] = gate rows | up rows and y = silu(x @ gate^T) * (x @ up^T) — done in the GEMV epilogue for
     <= 16 rows (decode), as GEMM + vg_swiglu otherwise."""
     lib = _lib.load()
-    if glu and x.numel() // x.shape[-1] > 16 and ((w.shape[0] // 2) % 8 != 0 or residual is not None or gamma is not None or out is not None):
+    if glu and x.numel() // x.shape[-1] > 16 and ((w.shape[0] // 2) % 8 != 0 or residual is not None or gamma is not None
+                                                  or (out is not None and not (out.is_contiguous() and out.data_ptr() % 16 == 0))):
         return swiglu(linear(x, w, bias))     # shapes the fused epilogue does not take (odd widths)
     x2, M, lda = _rows2d(x)
     N, K = w.shape
@@ -99,6 +104,21 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     assert x2.shape[1] == K, (x.shape, w.shape)
     assert w.stride(1) == 1
     odt = out_dtype if out_dtype is not None else x.dtype
+    # a few rows past a multiple of 256 (the C2 prompt: 3361 = 13 x 256 + 33) cost the 256x256-tile kernel a whole extra row of tiles;
+    # when dropping that row of tiles saves a ROUND of 256 workgroups, the tail rows go through their own (128-tile / skinny) launch:
+    # Llama gate|up at M = 3361: 1568 tiles = 7 rounds -> 1456 tiles = 6 rounds + a 33-row launch
+    rem = M % 256
+    if (_TAILSPLIT and M > 1024 and 0 < rem <= 64 and x2.dtype == torch.bfloat16 and x2.is_contiguous() and (out is None or out.is_contiguous())
+            and lib.vg_gemm_route(M, N, K, BF16, 1 if glu else 0, 0) == 3):
+        ntw = -(-N // (128 if glu else 256))
+        if -(-((M // 256) * ntw) // 256) < -(-((M // 256 + 1) * ntw) // 256):
+            M0 = M - rem
+            y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
+            y2 = y.view(M, N)
+            r2 = None if residual is None else residual.reshape(M, N)
+            for a, b_ in ((0, M0), (M0, M)):
+                linear(x2[a:b_], w, bias, act, gamma, None if r2 is None else r2[a:b_], out_dtype, y2[a:b_], glu)
+            return y
     ks = _splitk(M, N, K, x2.element_size()) if (not glu and (out is None or (out.is_contiguous() and out.dtype == odt))) else 0
     if ks:
         return _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, out)
