@@ -87,7 +87,7 @@ class GemmMeter:
     def __enter__(self):
         def timed(x, w, *a, **k):
             M = x.numel() // x.shape[-1]
-            if M <= 16 or (k.get("glu") and (w.shape[0] // 2) % 8 != 0):   # skinny path, or the unfused GLU wrapper (its inner call is metered)
+            if M <= 16:   # skinny path
                 return self.orig(x, w, *a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -93,10 +93,14 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     """y[..., N] = ((act(x @ w^T + bias)) * gamma) + residual ; w: [N, K] (row stride may exceed K).
     glu: w is [2N, K] = gate rows | up rows and y = silu(x @ gate^T) * (x @ up^T) — done in the GEMV epilogue for
     <= 16 rows (decode), as GEMM + vg_swiglu otherwise."""
+    return _linear(x, w, bias, act, gamma, residual, out_dtype, out, glu)
+
+
+def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
     lib = _lib.load()
     if glu and x.numel() // x.shape[-1] > 16 and ((w.shape[0] // 2) % 8 != 0 or residual is not None or gamma is not None
                                                   or (out is not None and not (out.is_contiguous() and out.data_ptr() % 16 == 0))):
-        return swiglu(linear(x, w, bias))     # shapes the fused epilogue does not take (odd widths)
+        return swiglu(_linear(x, w, bias))     # shapes the fused epilogue does not take (odd widths)
     x2, M, lda = _rows2d(x)
     N, K = w.shape
     if glu:
@@ -117,7 +121,7 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
             y2 = y.view(M, N)
             r2 = None if residual is None else residual.reshape(M, N)
             for a, b_ in ((0, M0), (M0, M)):
-                linear(x2[a:b_], w, bias, act, gamma, None if r2 is None else r2[a:b_], out_dtype, y2[a:b_], glu)
+                _linear(x2[a:b_], w, bias, act, gamma, None if r2 is None else r2[a:b_], out_dtype, y2[a:b_], glu)
             return y
     ks = _splitk(M, N, K, x2.element_size()) if (not glu and (out is None or (out.is_contiguous() and out.dtype == odt))) else 0
     if ks:
