@@ -83,23 +83,30 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #define VG_ATTN_MINW96 2
 #endif
 
-template <typename T, int DP, int BKV, int NW>
+// KS = 2 (head dim 256, SAM2's memory attention): the two 32-key halves of every KV tile go to two different waves of the same
+// 32 query rows — 8 waves on the LDS footprint of 4, each with its own (O, m, l) over its half of the keys, merged through LDS
+// once after the last tile.  At head dim 256 the 128 accumulator registers of a wave leave room for one wave per SIMD only
+// when a wave owns whole tiles; two waves per SIMD let one wave's softmax / staging VALU run under the other's MFMAs.
+template <typename T, int DP, int BKV, int NW, int KS = 1>
 __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? VG_ATTN_MINW : 1)))) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int KPC = 16 / ES;
   constexpr int RS = DP * ES + 16;  // LDS row stride in bytes
   constexpr int CPR = DP * ES / 16; // 16-byte chunks per row
-  constexpr int BQ = NW * 32;
+  constexpr int NQW = NW / KS;      // waves along the query rows
+  constexpr int BQ = NQW * 32;
   constexpr int NT = NW * 64;
   constexpr int NG = DP * ES / 32;  // k-groups (two 16-byte chunks each) along the head dim
   constexpr int NDT = DP / 32;
-  constexpr int NKT = BKV / 32;
+  constexpr int NKT = BKV / 32 / KS;   // 32-key sub-tiles of a KV tile this wave multiplies
+  static_assert(KS == 1 || (KS == 2 && BKV == 64 && sizeof(T) == 2), "key split: two waves per 64-key bf16 tile");
   char* Qs = smem;
   char* Ks = Qs + BQ * RS;
   char* Vs = Ks + BKV * RS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = (tid >> 6) % NQW, kh = (tid >> 6) / NQW;   // query-row group, key half (KS == 2)
   const int split = blockIdx.x % p.nsplit;
   // causal: the LAST query tiles walk the most keys — hand them out first, so the short ones fill the tail of the launch
   const int qtile = (p.causal > 0 && !p.fold) ? ((int)gridDim.x / p.nsplit - 1 - (int)blockIdx.x / p.nsplit) : (int)blockIdx.x / p.nsplit;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const char* krow = Ks + (kt * 32 + l31) * RS + h * 16;
+      const char* krow = Ks + ((kh * NKT + kt) * 32 + l31) * RS + h * 16;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const u32x4_t a = *(const u32x4_t*)(krow + g * 32);
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kt * 32 + mfma32_row(r, h);
+          const int key = kv0 + (kh * NKT + kt) * 32 + mfma32_row(r, h);
           const bool ok = key < Skv && (p.causal <= 0 || key <= q_idx + off) && key >= wlo && key < whi && (!win || key > q_idx + off - win);
           const float v = ok ? s[kt][r] * sl2 : -INFINITY;
           s[kt][r] = v;
@@ -305,12 +312,37 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       const char* vs = Vs + kt * 32 * RS;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kt, h, s[kt], o[dt]);
+        if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
         else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
       }
     }
   }
 
+  if constexpr (KS == 2) {
+    // merge the two key halves: the kh = 1 waves park (O, m, l) in LDS (lane-major: conflict-free), their kh = 0 partners fold them in
+    float* xo = (float*)smem + (int64_t)wave * (NDT * 16 + 2) * 64 + lane;
+    __syncthreads();                                          // every wave is done with the last K / V tile
+    if (kh == 1) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xo[(dt * 16 + r) * 64] = o[dt][r];
+      xo[NDT * 16 * 64] = m_i;
+      xo[(NDT * 16 + 1) * 64] = l_i;
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m1 = xo[NDT * 16 * 64], l1 = xo[(NDT * 16 + 1) * 64];
+    const float m_new = fmaxf(m_i, m1);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float a0 = exp2f(m_i - m_safe), a1 = exp2f(m1 - m_safe);
+    l_i = l_i * a0 + l1 * a1;
+    m_i = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * a0 + xo[(dt * 16 + r) * 64] * a1;
+  }
   if (p.nsplit > 1) {
     if (q_row < nrow) {
       float* pp = p.part + ((((int64_t)b * p.Hq + q_head) * p.nsplit + split) * Sq + q_idx) * (D + 2);
@@ -338,19 +370,21 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   }
 }
 
-template <typename T, int DP, int BKV, int NW>
+template <typename T, int DP, int BKV, int NW, int KS = 1>
 static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RS = DP * sizeof(T) + 16;
   constexpr int vbytes = sizeof(T) == 2 ? DP * 128 : BKV * RS;   // bf16: transposed V image, DP rows of 64 keys
-  constexpr int lds = (NW * 32 + BKV) * RS + vbytes;
+  constexpr int BQ = NW / KS * 32;
+  constexpr int lds = (BQ + BKV) * RS + vbytes;
+  static_assert(KS == 1 || lds >= (NW / KS) * (DP / 32 * 16 + 2) * 64 * 4, "the key-half merge reuses the tile buffers");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  dim3 grid(((p.Sq + NW * 32 - 1) / (NW * 32)) * p.nsplit, p.Hq, p.B);
+  dim3 grid(((p.Sq + BQ - 1) / BQ) * p.nsplit, p.Hq, p.B);
   if (p.fold) grid = dim3(p.nsplit, p.Hkv, p.B);
-  attn_kernel<T, DP, BKV, NW><<<grid, NW * 64, lds, st>>>(p);
+  attn_kernel<T, DP, BKV, NW, KS><<<grid, NW * 64, lds, st>>>(p);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -803,8 +837,12 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   // long bf16 sequences (LLM prefill, Hiera's global blocks): 8 waves = 256 query rows share every staged K/V tile (VG_ATTN_NW8, A/B knob)
   // measured r02: +5 % on Hiera's global blocks (4096^2, d = 72), -6 % on the causal LLM prefill (coarser diagonal), -12 % at S = 1025
   static const int nw8 = getenv("VG_ATTN_NW8") ? atoi(getenv("VG_ATTN_NW8")) : 1;
+  // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD (VG_ATTN_KS2, A/B knob)
+  static const int ks2 = getenv("VG_ATTN_KS2") ? atoi(getenv("VG_ATTN_KS2")) : 1;
   int rc;
-  if (dtype == VG_BF16 && nw8 && !p.fold && nsplit == 1 && Sq >= 2048 && D > 64 && D <= 128 && causal == 0) {
+  if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
+    rc = launch_attn<bf16_t, 256, 64, 8, 2>(p, st);
+  } else if (dtype == VG_BF16 && nw8 && !p.fold && nsplit == 1 && Sq >= 2048 && D > 64 && D <= 128 && causal == 0) {
     rc = D <= 96 ? launch_attn<bf16_t, 96, 64, 8>(p, st) : launch_attn<bf16_t, 128, 64, 8>(p, st);
   } else {
     rc = (dtype == VG_BF16) ? dispatch_dp<bf16_t, 64, 4>(p, st) : dispatch_dp<float, 32, 2>(p, st);

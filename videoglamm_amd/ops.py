@@ -207,6 +207,9 @@ def _causal_code(causal, window):
     return int(window) if window else 1
 
 
+_SPLIT_WG_D256 = int(_os.environ.get("VG_ATTN_SPLIT_WG_D256", "256"))   # workgroups the KV split aims for at head dim 256: one 8-wave workgroup per CU (measured r02: 256 beats 384 / 512 / 1024 by 1.2-2.5x, the fp32 partials are the cost)
+
+
 def attention(q, k, v, scale, causal=False, window=0):
     """q: [B,Sq,Hq,D], k/v: [B,Skv,Hkv,D] (arbitrary batch/token/head strides, D contiguous) -> [B,Sq,Hq,D].
     window > 0 (with causal): every query sees its own position and the window - 1 before it (sliding-window LLMs)."""
@@ -220,7 +223,7 @@ def attention(q, k, v, scale, causal=False, window=0):
     nsplit, ws = 1, None
     blocks = -(-Sq // (128 if q.dtype == torch.bfloat16 else 64)) * Hq * B   # workgroups without splitting
     if Skv >= 512 and blocks < 384:                                           # < 1.5 workgroups per CU: split KV
-        nsplit = max(1, min(64, 512 // blocks, Skv // 128))
+        nsplit = max(1, min(64, (_SPLIT_WG_D256 if D > 128 else 512) // blocks, Skv // 128))
     if nsplit > 1:
         ws = torch.empty(B * Hq * nsplit * Sq * (D + 2), dtype=torch.float32, device=q.device)
     rc = lib.vg_attention_splitkv(_p(q), _p(k), _p(v), _p(out), B, Hq, Hkv, Sq, Skv, D,
