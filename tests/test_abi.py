@@ -62,6 +62,7 @@ def test_gemm_routing_rules():
     assert route(32768, 1728, 576) == 4                    # Hiera stage 3 qkv: single-stage whole-line kernel
     assert route(32768, 1728, 576, win=1) == 4
     assert route(524288, 432, 144) == 2                    # Hiera stage 1: 64-byte-step kernel
+    assert route(16384, 4608, 1152) == 3 and route(9232, 4096, 1024) == 4   # Hiera stage 4 fc1 (K x 2 B = 2304) takes the 256x256 kernel, CLIP's K = 1024 does not
     assert route(32768, 576, 2304) == 1                    # Hiera stage 3 fc2: N = 576 wastes a quarter of a 256-wide tile
     assert lib.vg_gemm_route(1697, 4096, 4096, 0, 0, 0) == 1   # fp32 parity mode never takes the bf16-only kernels
     # split-K (ops.linear): under-filled grids with a long K only

@@ -42,4 +42,16 @@ for win in (300e6, 600e6, 900e6):
         else: ce = max(ce, e)
     b += ce - cs
     print(f"last {win/1e6:.0f} ms: busy {b/1e6:.1f} ms = {b/win:.3f}")
+import collections, re, os
+step_ms = float(os.environ.get("STEP_MS", "308"))
+lo = t1 - 3 * step_ms * 1e6
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n in rows:
+    if s >= lo:
+        k = re.sub(r"\(.*", "", n)[:90]
+        agg[k][0] += e - s; agg[k][1] += 1
+tot = sum(v[0] for v in agg.values())
+print(f"kernel time in the last 3 steps: {tot/3e6:.1f} ms/step (sum over streams)")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{v[0]/3e6:8.2f} ms/step {v[1]/3:8.1f} launches  {v[0]/v[1]/1e3:8.1f} us  {k}")
 PY

@@ -32,6 +32,7 @@ struct GemmArgs {
   // split-K (vg_gemm_splitk, 128x128 LDS-DMA kernel only): blockIdx.z = K slice of kchunk elements; raw fp32 partial tiles
   // go to part[z][M][N], a second kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
+  int nbatch;   // persistent 256x256 kernel: batch count (tiles of all batch entries form one queue)
   int stagger;  // 256x256 kernels: first-round workgroup w sleeps (w & 3) * stagger * ~4 us before its first load (phase desynchronisation knob)
 };
 
@@ -192,6 +193,110 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
+// Output-tile store flavour of the 256x256 kernel's epilogue (A/B macro): 0 plain, 1 nontemporal (nt), 2 write-through (sc0 sc1: the
+// line is not kept in the XCD's L2), 3 sc1 only
+#ifndef VG_EPI_ST
+#define VG_EPI_ST 0
+#endif
+__device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
+#if VG_EPI_ST == 1
+  __builtin_nontemporal_store(v, (u32x4_t*)ptr);
+#elif VG_EPI_ST == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+#elif VG_EPI_ST == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+#else
+  *(u32x4_t*)ptr = v;
+#endif
+}
+
+// Row-major side of the LDS-staged epilogues, fast path: the lane's 8 columns are whole inside N, 16-byte aligned rows, no fp8 scales.
+// NP passes of 8 rows (rows m0 + 8 pass + rsub).  Measured r02 on the 256x256 kernel (Hiera stage-3 fc1, M = 65536): the previous
+// per-element form (ds_read_b32 + the activation's branch chain per element, a conditional residual load per pass that made every
+// pass wait for the previous pass's stores — loads and stores share vmcnt on gfx9) cost 90 of the GEMM's 287 us.  Here: every
+// residual load of the block is requested before its first store, the staged tile is read with two ds_read_b128 per row, the
+// activation and the presence of a residual are compile-time constants (one switch per block, epi_dispatch).
+template <typename TO, int ACT, bool RES, int NP, int ES>
+__device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws, int m0, int n0, int cg, int rsub,
+                                              const float (&bv)[8], const float (&gv)[8], TO* C, const TO* R) {
+  int64_t mo[NP];
+  bool ok[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int m = m0 + ps * 8 + rsub;
+    ok[ps] = m < p.M;
+    mo[ps] = m;
+    if (p.wmode == 2) {
+      mo[ps] = ok[ps] ? gemm_window_row(p, m) : -1;
+      ok[ps] = mo[ps] >= 0;
+    }
+  }
+  constexpr int RW = RES ? (sizeof(TO) == 2 ? 1 : 2) : 1;
+  u32x4_t rv[NP][RW];
+  if constexpr (RES) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+      for (int w = 0; w < RW; ++w) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        rv[ps][w] = ok[ps] ? *(const u32x4_t*)((const char*)(R + mo[ps] * p.ldr + n0) + 16 * w) : z;
+      }
+  }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const float* row = ws + (ps * 8 + rsub) * ES + cg * 8;
+    const f32x4_t x0 = *(const f32x4_t*)row, x1 = *(const f32x4_t*)(row + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = vg_act(x0[e] + bv[e], ACT) * gv[e];
+      v[4 + e] = vg_act(x1[e] + bv[4 + e], ACT) * gv[4 + e];
+    }
+    TO* cp = C + mo[ps] * p.ldc + n0;
+    if constexpr (sizeof(TO) == 2) {
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[ps][0][e] << 16); v[2 * e + 1] += __uint_as_float(rv[ps][0][e] & 0xffff0000u); }
+      }
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+      if (ok[ps]) epi_store16(cp, o);
+    } else {
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(rv[ps][0][e]); v[4 + e] += __uint_as_float(rv[ps][1][e]); }
+      }
+      const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+      if (ok[ps]) {
+        *(f32x4_t*)cp = o0;
+        *(f32x4_t*)(cp + 4) = o1;
+      }
+    }
+  }
+}
+
+template <int V> struct epi_ic { static constexpr int value = V; };
+// one switch per block: f(activation constant, has-residual constant)
+template <typename F>
+__device__ __forceinline__ void epi_dispatch(int act, bool res, F&& f) {
+#define VG_EPI_CASE(A) \
+  case A:              \
+    if (res) f(epi_ic<A>{}, epi_ic<1>{}); else f(epi_ic<A>{}, epi_ic<0>{}); \
+    break;
+  switch (act) {
+    VG_EPI_CASE(VG_ACT_GELU)
+    VG_EPI_CASE(VG_ACT_QUICK_GELU)
+    VG_EPI_CASE(VG_ACT_RELU)
+    VG_EPI_CASE(VG_ACT_SILU)
+    VG_EPI_CASE(VG_ACT_SIGMOID)
+    default:
+      if (res) f(epi_ic<0>{}, epi_ic<1>{}); else f(epi_ic<0>{}, epi_ic<0>{});
+      break;
+  }
+#undef VG_EPI_CASE
+}
+
 // Epilogue shared by the 128x128-tile kernels: bias/activation/LayerScale, optional residual, store.
 // The wave's 64x64 fp32 accumulator tile is staged RAW through LDS (the K loop is done with it) so that every lane then
 // owns 8 consecutive columns of one row: residual loads and C stores become 16-byte accesses and 8 lanes write a full
@@ -274,6 +379,12 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
     for (int e = 0; e < 8; ++e) {
       bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
       gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+    }
+    if (!p.sa && n0w + 64 <= N) {     // (wave-uniform) whole 16-byte groups, no fp8 scales: the straight-line form
+      epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
+        epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 8, ES>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
+      });
+      return;
     }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -1237,70 +1348,64 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
   constexpr int KPC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
   constexpr int TA = 256 * 128, STAGE = 2 * TA;
+  // LDS map (160 KB): stage 0 | 32 KB spare | stage 1.  The fp32 epilogue staging (8 waves x 32 rows x 68 floats = 69632 B) of a
+  // tile whose last K step sat in stage b covers stage b plus 4 KB of the spare, never the other stage — which is receiving the
+  // NEXT tile's first K step by then (persistent workgroups: see the tile loop below).
+  constexpr int SPARE = 32 * 1024, EPI = 8 * 32 * 68 * 4;
+  auto sbase = [](int buf) { return buf ? STAGE + SPARE : 0; };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  if (p.stagger > 0 && lin < 256) {          // first round only: later rounds inherit the phase shift
-    const int n = (lin & 3) * p.stagger;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
   const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+  const int mt = (M + 255) / 256, nt = p.a_op == 1 ? (N + 127) / 128 : (N + 255) / 256;
+  const int per = mt * nt, total = per * p.nbatch;
+  const int xq = total >> 3, xr = total & 7;
 
-  // wave w stages rows [32w, 32w+32) of each operand: 4 DMA instructions of 8 rows (8 lanes per 128-byte row) each
+  // persistent: workgroup w runs tiles w, w + gridDim.x, ... in the order the hardware would have dispatched them (same XCD
+  // remap, same column-group walk), so the tiles in flight at any time still share their A / W panels through the XCDs' L2s
+  int bm, bn, bz;
   const T* src[8];
+  auto setup = [&](int lin) {
+    const int xcd = lin & 7;
+    const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    bz = wgid / per;
+    gemm_tile_of(wgid - bz * per, mt, nt, p.gn, bm, bn);
+    const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+    const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+    // wave w stages rows [32w, 32w+32) of each operand: 4 DMA instructions of 8 rows (8 lanes per 128-byte row) each
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = bm * 256 + row, gn = bn * 256 + row;
-    gm = gm < M ? gm : M - 1;
-    gn = gn < N ? gn : N - 1;
-    if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
-      const int o = bn * 128 + (row & 127);
-      gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gm = bm * 256 + row, gn = bn * 256 + row;
+      gm = gm < M ? gm : M - 1;
+      gn = gn < N ? gn : N - 1;
+      if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
+        const int o = bn * 128 + (row & 127);
+        gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
+      }
+      src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
+      src[4 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
     }
-    src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
-    src[4 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
-  }
+  };
   auto dma = [&](int kt, int buf, int i) {      // instruction i of stage kt: 0..3 A pieces, 4..7 W pieces
-    char* dst = smem + buf * STAGE + (i >> 2) * TA + wave * 32 * 128 + (i & 3) * 1024;
+    char* dst = smem + sbase(buf) + (i >> 2) * TA + wave * 32 * 128 + (i & 3) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
 
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int ra = wm * 128 + l31, rb = wn * 64 + l31;
   const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r + 32 i share the key
   const int nk = K / BK;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma(0, 0, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  f32x16_t acc[4][2];
   u32x4_t fa[2][4], fb[2][2];          // fragment sets of two consecutive MFMA groups
   auto frag = [&](int buf, int g, int x) -> u32x4_t {       // x: 0..3 A row tiles, 4..5 W row tiles
     const int c = 2 * g + h;
-    if (x < 4) return *(const u32x4_t*)(smem + buf * STAGE + (ra + x * 32) * 128 + ((c ^ swa) << 4));
-    return *(const u32x4_t*)(smem + buf * STAGE + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
+    if (x < 4) return *(const u32x4_t*)(smem + sbase(buf) + (ra + x * 32) * 128 + ((c ^ swa) << 4));
+    return *(const u32x4_t*)(smem + sbase(buf) + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
   };
-#pragma unroll
-  for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(0, 0, x);
-
   // one K step = 4 groups x 4 slots; a slot = 2 MFMAs, then one or two fragment reads of the next group (6 per group), then
-  // (first three groups, while a next stage exists) at most one DMA instruction of the next stage (3 + 3 + 2)
+  // (first three groups, while a next stage exists) at most one DMA instruction of the next stage (3 + 3 + 2).  `kt + 1` is the
+  // K step the DMAs fetch (through src[]: on a tile's last step that is step 0 of the workgroup's NEXT tile)
   auto step = [&](int kt, int buf, bool has_next) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1329,123 +1434,177 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
       }
     }
   };
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
-    const int buf = kt & 1;
-    step(kt, buf, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  step(kt, kt & 1, false);
-#if defined(VG_W128X8_DIAG) && VG_W128X8_DIAG == 2
-  if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f;   // diagnostic build: no epilogue at all (keeps the accumulators live)
-  return;
-#endif
-  __syncthreads();   // the epilogue reuses the ring as fp32 staging: 8 waves x 32 rows x 68 floats
 
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 68;
-  float* ws = (float*)smem + wave * 32 * ES;
-  const int cg = lane & 7, rsub = lane >> 3;
-  const int n0 = (p.a_op == 1 ? bn * 128 + (wn & 1) * 64 : bn * 256 + wn * 64) + cg * 8;
-  float bv[8], gv[8];
+  auto epilogue = [&](int bm, int bn, int bz, int ebase) {
+    TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+    const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+    constexpr int ES = 68;
+    float* ws = (float*)(smem + ebase) + wave * 32 * ES;
+    const int cg = lane & 7, rsub = lane >> 3;
+    const int n0w = p.a_op == 1 ? bn * 128 + (wn & 1) * 64 : bn * 256 + wn * 64;
+    const int n0 = n0w + cg * 8;
+    const bool fast = n0w + 64 <= N && !p.sa;      // wave-uniform: whole 16-byte groups -> the straight-line forms
+    float bv[8], gv[8], bu[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-  }
+    for (int e = 0; e < 8; ++e) {
+      bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+      gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+      bu[e] = (p.a_op == 1 && p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f;
+    }
+    // (the four 32-row passes are instantiated by hand: with the dispatch lambda inside, "#pragma unroll" on a loop over i is not
+    // honoured, and a run-time acc[i] sends the accumulators to scratch)
+    auto pass32 = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+      vg_lds_barrier();
+      const int mrow = bm * 256 + wm * 128 + i * 32;
+      if (p.a_op == 1) {
+        // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows:
+        // y = round(silu(round(gate + b_g))) * round(up + b_u)  (the arithmetic of gemm_epilogue128's GLU)
+        const float* wg = (const float*)(smem + ebase) + (wm * 4 + (wn & 1)) * 32 * ES;
+        const float* wu = wg + 2 * 32 * ES;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    vg_lds_barrier();
-    if (p.a_op == 1) {
-      // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows
-      const float* wg = (const float*)smem + (wm * 4 + (wn & 1)) * 32 * ES;
-      const float* wu = wg + 2 * 32 * ES;
+        for (int pass = 0; pass < 2; ++pass) {
+          const int ml = (wn >> 1) * 16 + pass * 8 + rsub;
+          const int m = mrow + ml;
+          if (m >= M || n0 >= N) continue;
+          float gx[8], ux[8];
+          if (fast) {
+            const f32x4_t g0 = *(const f32x4_t*)(wg + ml * ES + cg * 8), g1 = *(const f32x4_t*)(wg + ml * ES + cg * 8 + 4);
+            const f32x4_t u0 = *(const f32x4_t*)(wu + ml * ES + cg * 8), u1 = *(const f32x4_t*)(wu + ml * ES + cg * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gx[e] = g0[e]; gx[4 + e] = g1[e]; ux[e] = u0[e]; ux[4 + e] = u1[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gx[e] = wg[ml * ES + cg * 8 + e]; ux[e] = wu[ml * ES + cg * 8 + e]; }
+          }
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float g = gx[e] + bv[e];
+            float u = ux[e] + bu[e];
+            if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+            g = g / (1.0f + __expf(-g));
+            if (sizeof(TO) == 2) g = bf2f(f2bf(g));
+            v[e] = g * u;
+          }
+          TO* cp = C + (int64_t)m * p.ldc + n0;
+          if (n0 + 8 <= N) {
+            if constexpr (sizeof(TO) == 2) {
+              u32x4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+              epi_store16(cp, o);
+            } else {
+              f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+              *(f32x4_t*)cp = o0;
+              *(f32x4_t*)(cp + 4) = o1;
+            }
+          } else {
+            for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+          }
+        }
+        return;
+      }
+      if (fast) {
+        epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
+          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES>(p, ws, mrow, n0, cg, rsub, bv, gv, C, R);
+        });
+        return;
+      }
 #pragma unroll 1
-      for (int pass = 0; pass < 2; ++pass) {
-        const int ml = (wn >> 1) * 16 + pass * 8 + rsub;
-        const int m = bm * 256 + wm * 128 + i * 32 + ml;
+      for (int pass = 0; pass < 4; ++pass) {     // edge tiles (N not a whole 16-byte group here)
+        const int ml = pass * 8 + rsub;
+        const int m = mrow + ml;
         if (m >= M || n0 >= N) continue;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float g = wg[ml * ES + cg * 8 + e] + bv[e];
-          float u = wu[ml * ES + cg * 8 + e] + ((p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f);
-          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-          g = g / (1.0f + __expf(-g));
-          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
-          v[e] = g * u;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
         TO* cp = C + (int64_t)m * p.ldc + n0;
-        if (n0 + 8 <= N) {
+        const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
+        if (n0 + 8 <= N && p.vec_out) {
           if constexpr (sizeof(TO) == 2) {
+            if (rp) {
+              const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+            }
             u32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            *(u32x4_t*)cp = o;
+            epi_store16(cp, o);
           } else {
+            if (rp) {
+              const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
             f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
             *(f32x4_t*)cp = o0;
             *(f32x4_t*)(cp + 4) = o1;
           }
         } else {
-          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+          for (int e = 0; e < 8 && n0 + e < N; ++e) {
+            float o = v[e];
+            if (rp) o += vg_elt<TO>::ld(rp + e);
+            vg_elt<TO>::st(cp + e, o);
+          }
         }
       }
-      continue;
+    };
+    pass32(epi_ic<0>{});
+    pass32(epi_ic<1>{});
+    pass32(epi_ic<2>{});
+    pass32(epi_ic<3>{});
+  };
+
+  int t = blockIdx.x;
+  if (t >= total) return;
+  setup(t);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int base = 0;                        // the stage holding K step 0 of the current tile
+  while (true) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(base, 0, x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+      const int buf = (base + kt) & 1;
+      step(kt, buf, true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-      const int ml = pass * 8 + rsub;
-      const int m = bm * 256 + wm * 128 + i * 32 + ml;
-      if (m >= M || n0 >= N) continue;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-      TO* cp = C + (int64_t)m * p.ldc + n0;
-      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
-#if defined(VG_W128X8_DIAG) && VG_W128X8_DIAG == 1
-      if (v[0] == 12345.678f) C[0] = (TO)0;    // diagnostic build: the LDS-staged epilogue without its global stores
-      continue;
-#endif
-      if (n0 + 8 <= N && p.vec_out) {
-        if constexpr (sizeof(TO) == 2) {
-          if (rp) {
-            const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-          }
-          u32x4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)cp = o;
-        } else {
-          if (rp) {
-            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          }
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *(f32x4_t*)cp = o0;
-          *(f32x4_t*)(cp + 4) = o1;
-        }
-      } else {
-        for (int e = 0; e < 8 && n0 + e < N; ++e) {
-          float o = v[e];
-          if (rp) o += vg_elt<TO>::ld(rp + e);
-          vg_elt<TO>::st(cp + e, o);
-        }
-      }
-    }
+    // last K step of the tile: its DMA slots fetch K step 0 of this workgroup's next tile into the other stage, so the next
+    // tile starts without a load round trip and this tile's output stores drain under the next tile's first K step
+    const int last = (base + kt) & 1;
+    const int tn = t + gridDim.x;
+    const bool more = tn < total;
+    const int cbm = bm, cbn = bn, cbz = bz;
+    if (more) setup(tn);
+    step(-1, last, more);
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                   // everyone is done reading stage `last`: the epilogue stages fp32 tiles there
+    epilogue(cbm, cbn, cbz, last ? STAGE + SPARE + STAGE - EPI : 0);
+    if (!more) break;
+    vg_lds_barrier();                  // staging reads done: stage `last` may take the next tile's K step 1
+    base = last ^ 1;
+    t = tn;
   }
 }
 
@@ -1597,7 +1756,10 @@ static bool route_w128(int64_t M, int64_t N, int64_t K, int es, int a_op, int wm
   const int ntw = (int)(a_op == 1 ? (N + 127) / 128 : (N + 255) / 256), mtw = (int)((M + 255) / 256);
   if (ntw_out) { *ntw_out = ntw; *mtw_out = mtw; }
   const int w = knob_w128();
-  if (!w || es != 2 || route_small_k(K, es, a_op) || wmode || K % (128 / es) != 0 || !vec_out) return false;
+  // (r02, persistent kernel + straight-line epilogue: from K x es = 2304 B — Hiera stage 4, InternVideo2 — the 256x256 kernel beats the
+  // single-stage 128x128 one by 2...9 %; K = 1024 / 576 stay there)
+  static const int smallk_min = env_knob("VG_W128_MINKB", 2304);
+  if (!w || es != 2 || (route_small_k(K, es, a_op) && K * es < smallk_min) || wmode || K % (128 / es) != 0 || !vec_out) return false;
   if (w == 2 || w == 4) return true;       // 2 / 4: force the 4-wave / 8-wave kernel on every eligible shape (3: 8-wave, shape rule)
   const int64_t t256 = (int64_t)ntw * mtw * batch;
   const double useful = (double)M * N / ((double)mtw * 256 * ntw * (a_op == 1 ? 128 : 256));
@@ -1659,7 +1821,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     static bool w128_attr = false;
     if (!w128_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_tile_w128_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
-      (void)hipFuncSetAttribute((const void*)gemm_tile_w128x8_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
+      (void)hipFuncSetAttribute((const void*)gemm_tile_w128x8_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       w128_attr = true;
     }
     int ntw, mtw;
@@ -1669,7 +1831,13 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       q.gn = pick_gn(mtw, ntw);
       static const int stagger = env_knob("VG_W128_STAGGER", 0);
       q.stagger = stagger;
-      if (knob_w128() != 2 && knob_w128() != 5) gemm_tile_w128x8_kernel<T, TO><<<gridw, 512, 2 * 2 * 256 * 128, st>>>(q);   // 2 / 5: the 4-wave kernel
+      q.nbatch = batch;
+      // persistent: one workgroup per CU walks the tile queue (VG_W128_PERSIST=0: one workgroup per tile, as before r02)
+      static const int persist = env_knob("VG_W128_PERSIST", 1);
+      static const int ncu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+      const int64_t tot = (int64_t)ntw * mtw * batch;
+      const int wgs = (int)(persist && tot > ncu ? ncu : tot);
+      if (knob_w128() != 2 && knob_w128() != 5) gemm_tile_w128x8_kernel<T, TO><<<wgs, 512, 160 * 1024, st>>>(q);   // 2 / 5: the 4-wave kernel
       else gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
     } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
       gemm_tile_s128_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
