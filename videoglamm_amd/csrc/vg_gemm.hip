@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 #define VG_EPI_ST 0
 #endif
 __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
+#ifdef VG_EPI_NOSTORE
+  if (v[0] != 0x12345678u) return;
+#endif
 #if VG_EPI_ST == 1
   __builtin_nontemporal_store(v, (u32x4_t*)ptr);
 #elif VG_EPI_ST == 2
@@ -662,6 +665,88 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, p.a_op == 1 ? bn * 64 : bn * GBN + wn * 64, bz, wave, lane);
 }
 
+// Epilogue of the four-workgroups-per-CU 128x128 kernels (64-byte-step and single-stage): the wave's 64x64 tile goes out 32 rows at a
+// time through 4 x 32 x 68 floats of staging (34.8 KB with the stage buffers aliased: what keeps four workgroups on a CU).
+template <typename TO>
+__device__ __forceinline__ void gemm_epilogue64x32(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int m0w, int n0w, int bz,
+                                                   int wave, int lane) {
+  const int M = p.M, N = p.N, l31 = lane & 31, h = lane >> 5;
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 68;
+  float* ws = (float*)smem + wave * 32 * ES;
+  const int cg = lane & 7, rsub = lane >> 3;
+  const int n0 = n0w + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+  const bool fast = p.vec_out && !p.sa && n0w + 64 <= N;     // wave-uniform: whole 16-byte groups -> the straight-line form
+  auto pass32 = [&](auto ic) {           // (instantiated by hand: see gemm_tile_w128x8_kernel's epilogue)
+    constexpr int i = decltype(ic)::value;
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    vg_lds_barrier();
+    if (fast) {
+      epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
+        epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES>(p, ws, m0w + i * 32, n0, cg, rsub, bv, gv, C, R);
+      });
+      return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ml = pass * 8 + rsub;
+      const int m = m0w + i * 32 + ml;
+      if (m >= M || n0 >= N) continue;
+      int64_t mo = m;
+      if (p.wmode == 2) {
+        mo = gemm_window_row(p, m);
+        if (mo < 0) continue;
+      }
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      TO* cp = C + mo * p.ldc + n0;
+      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
+      if (n0 + 8 <= N && p.vec_out) {
+        if constexpr (sizeof(TO) == 2) {
+          if (rp) {
+            const u32x4_t rv = *(const u32x4_t*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+          *(u32x4_t*)cp = o;
+        } else {
+          if (rp) {
+            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)cp = o0;
+          *(f32x4_t*)(cp + 4) = o1;
+        }
+      } else {
+        for (int e = 0; e < 8 && n0 + e < N; ++e) {
+          float o = v[e];
+          if (rp) o += vg_elt<TO>::ld(rp + e);
+          vg_elt<TO>::st(cp + e, o);
+        }
+      }
+    }
+  };
+  pass32(epi_ic<0>{});
+  pass32(epi_ic<1>{});
+}
+
 // 128x128 tile with 64-BYTE K steps and a 35 KB LDS footprint: FOUR workgroups (16 waves) per CU instead of two.
 // The SQ counters of the 128-byte-step kernel show its waves parked on the DMA wait / barrier a third of the time with
 // only two waves per SIMD to cover for each other (profiles/r01_pmc_gemm_sq_stalls.json); this variant trades half the
@@ -776,71 +861,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
   }
 
   // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 68;
-  float* ws = (float*)smem + wave * 32 * ES;
-  const int cg = lane & 7, rsub = lane >> 3;
-  const int n0 = bn * GBN + wn * 64 + cg * 8;
-  float bv[8], gv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    vg_lds_barrier();
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int ml = pass * 8 + rsub;
-      const int m = bm * GBM + wm * 64 + i * 32 + ml;
-      if (m >= M || n0 >= N) continue;
-      int64_t mo = m;
-      if (p.wmode == 2) {
-        mo = gemm_window_row(p, m);
-        if (mo < 0) continue;
-      }
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-      TO* cp = C + mo * p.ldc + n0;
-      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
-      if (n0 + 8 <= N && p.vec_out) {
-        if constexpr (sizeof(TO) == 2) {
-          if (rp) {
-            const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-          }
-          u32x4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)cp = o;
-        } else {
-          if (rp) {
-            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          }
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *(f32x4_t*)cp = o0;
-          *(f32x4_t*)(cp + 4) = o1;
-        }
-      } else {
-        for (int e = 0; e < 8 && n0 + e < N; ++e) {
-          float o = v[e];
-          if (rp) o += vg_elt<TO>::ld(rp + e);
-          vg_elt<TO>::st(cp + e, o);
-        }
-      }
-    }
-  }
+  gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
 // 128x128 tile, 128-BYTE K steps, ONE 32 KB stage (the epilogue staging aliases it: 35 KB in all): four workgroups per
@@ -952,71 +973,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
   }
 
   // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 68;
-  float* ws = (float*)smem + wave * 32 * ES;
-  const int cg = lane & 7, rsub = lane >> 3;
-  const int n0 = bn * GBN + wn * 64 + cg * 8;
-  float bv[8], gv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    vg_lds_barrier();
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int ml = pass * 8 + rsub;
-      const int m = bm * GBM + wm * 64 + i * 32 + ml;
-      if (m >= M || n0 >= N) continue;
-      int64_t mo = m;
-      if (p.wmode == 2) {
-        mo = gemm_window_row(p, m);
-        if (mo < 0) continue;
-      }
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-      TO* cp = C + mo * p.ldc + n0;
-      const TO* rp = R ? R + mo * p.ldr + n0 : nullptr;
-      if (n0 + 8 <= N && p.vec_out) {
-        if constexpr (sizeof(TO) == 2) {
-          if (rp) {
-            const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-          }
-          u32x4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)cp = o;
-        } else {
-          if (rp) {
-            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          }
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *(f32x4_t*)cp = o0;
-          *(f32x4_t*)(cp + 4) = o1;
-        }
-      } else {
-        for (int e = 0; e < 8 && n0 + e < N; ++e) {
-          float o = v[e];
-          if (rp) o += vg_elt<TO>::ld(rp + e);
-          vg_elt<TO>::st(cp + e, o);
-        }
-      }
-    }
-  }
+  gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
 // 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
