@@ -349,9 +349,13 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = dt * 32 + mfma32_row(r, h);
-          if (d < D) pp[d] = o[dt][r];
+        for (int g = 0; g < 4; ++g) {       // 4 consecutive head-dim values per register quad; a partial row starts 8-byte aligned (D + 2 is even)
+          const int d0 = dt * 32 + 8 * g + 4 * h;
+          if (d0 < D) {
+            const float2 lo = {o[dt][4 * g], o[dt][4 * g + 1]}, hi = {o[dt][4 * g + 2], o[dt][4 * g + 3]};
+            *(float2*)(pp + d0) = lo;
+            *(float2*)(pp + d0 + 2) = hi;
+          }
         }
       if (h == 0) { pp[D] = m_i * 0.6931471805599453f; pp[D + 1] = l_i; }
     }
@@ -360,13 +364,36 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   if (q_row < nrow) {
     const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
     T* Og = (T*)p.O + (int64_t)b * p.o_sb + (int64_t)q_head * p.o_sh + (int64_t)q_idx * p.o_ss;
+    // a lane holds 4 consecutive head-dim values per register quad (rows 8 g + 4 h + 0..3 of the 32x32 C layout): one 8-byte (bf16) /
+    // 16-byte (fp32) store per quad instead of four scalar ones when the output rows keep that alignment (D % 8 == 0 always holds)
+    const bool ovec = ((p.o_ss | p.o_sh | p.o_sb) & 3) == 0 && ((uintptr_t)p.O & (4 * sizeof(T) - 1)) == 0;
+    if (ovec) {
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d = dt * 32 + mfma32_row(r, h);
-        if (d < D) vg_elt<T>::st(Og + d, o[dt][r] * inv);
-      }
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = dt * 32 + 8 * g + 4 * h;
+          if (d0 < D) {
+            if constexpr (sizeof(T) == 2) {
+              uint2 v;
+              v.x = f2bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+              v.y = f2bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+              *(uint2*)(Og + d0) = v;
+            } else {
+              const f32x4_t v = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+              *(f32x4_t*)(Og + d0) = v;
+            }
+          }
+        }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = dt * 32 + mfma32_row(r, h);
+          if (d < D) vg_elt<T>::st(Og + d, o[dt][r] * inv);
+        }
+    }
   }
 }
 
