@@ -244,16 +244,45 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
     if (PF && kv0 + BKV < kv_end) fetch(kv0 + BKV);
 
     f32x16_t s[NKT];
+    // PIPE (bf16, head dim <= 128): the K / Q fragments of k-group g + 1 are requested before the MFMAs of group g issue, and the
+    // sub-tiles' independent accumulators alternate — left to itself the compiler emits read, wait, MFMA per fragment (measured r02:
+    // every MFMA of the loop then pays a full LDS round trip); head dim 256 has no registers to spare for the second fragment set
+    constexpr bool PIPE = sizeof(T) == 2 && DP <= 128;
+    if constexpr (PIPE) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const char* krow = Ks + ((kh * NKT + kt) * 32 + l31) * RS + h * 16;
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const char* krow0 = Ks + (kh * NKT * 32 + l31) * RS + h * 16;
+      u32x4_t kf[2][NKT], qf[2];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) kf[0][kt] = *(const u32x4_t*)(krow0 + kt * 32 * RS);
+      qf[0] = *(const u32x4_t*)qrow;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const u32x4_t a = *(const u32x4_t*)(krow + g * 32);
-        const u32x4_t bq = *(const u32x4_t*)(qrow + g * 32);
-        AMma<T>::qk(a, bq, s[kt]);
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt) kf[nxt][kt] = *(const u32x4_t*)(krow0 + kt * 32 * RS + (g + 1) * 32);
+          qf[nxt] = *(const u32x4_t*)(qrow + (g + 1) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) AMma<T>::qk(kf[cur][kt], qf[cur], s[kt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        const char* krow = Ks + ((kh * NKT + kt) * 32 + l31) * RS + h * 16;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const u32x4_t a = *(const u32x4_t*)(krow + g * 32);
+          const u32x4_t bq = *(const u32x4_t*)(qrow + g * 32);
+          AMma<T>::qk(a, bq, s[kt]);
+        }
       }
     }
 
@@ -307,13 +336,43 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
 
+    if constexpr (PIPE) {
+      // P packed once per 16-key step (the same B operand for every d-tile); V^T fragments of step t + 1 requested before the
+      // MFMAs of step t; the d-tiles' accumulators are independent chains (see pv_step_bf16t for the V^T image)
+      u32x4_t pb[NKT * 2];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const char* vs = Vs + kt * 32 * RS;
+      for (int t = 0; t < NKT * 2; ++t)
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
-        else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+        for (int jj = 0; jj < 4; ++jj) pb[t][jj] = f2bf2(s[t >> 1][(t & 1) * 8 + jj * 2], s[t >> 1][(t & 1) * 8 + jj * 2 + 1]);
+      u32x4_t vf[2][NDT];
+      auto vread = [&](int t, int dt) -> u32x4_t {
+        const int d = dt * 32 + l31;
+        return *(const u32x4_t*)(Vs + d * 128 + ((((kh * NKT + (t >> 1)) * 4 + (t & 1) * 2 + h) ^ ((d >> 1) & 7)) << 4));
+      };
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) vf[0][dt] = vread(0, dt);
+#pragma unroll
+      for (int t = 0; t < NKT * 2; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < NKT * 2) {
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) vf[nxt][dt] = vread(t + 1, dt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[cur][dt]), __builtin_bit_cast(bf16x8_t, pb[t]), o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const char* vs = Vs + kt * 32 * RS;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
+          else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+        }
       }
     }
   }

@@ -199,9 +199,6 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 #define VG_EPI_ST 0
 #endif
 __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
-#ifdef VG_EPI_NOSTORE
-  if (v[0] != 0x12345678u) return;
-#endif
 #if VG_EPI_ST == 1
   __builtin_nontemporal_store(v, (u32x4_t*)ptr);
 #elif VG_EPI_ST == 2
