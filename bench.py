@@ -76,6 +76,7 @@ class GemmMeter:
 
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.linear, []
+        self.skinny = {}           # VG_BENCH_SKINNY=1: the M <= 16 shapes seen (diagnostic, printed to stderr by main)
         self.scope = None          # "mask_decoder" while SAM2.mask_decoder runs (the north star's mask-decoder GEMMs)
 
     @staticmethod
@@ -88,6 +89,8 @@ class GemmMeter:
         def timed(x, w, *a, **k):
             M = x.numel() // x.shape[-1]
             if M <= 16:   # skinny path
+                if os.environ.get("VG_BENCH_SKINNY"):
+                    self.skinny[(M, w.shape[0], w.shape[1], str(k.get("out_dtype")))] = self.skinny.get((M, w.shape[0], w.shape[1], str(k.get("out_dtype"))), 0) + 1
                 return self.orig(x, w, *a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -510,6 +513,8 @@ def main():
                 else:
                     os.environ[k] = v
         dec_ms, dec_n = dm.summary()
+        if gm.skinny:
+            print("skinny GEMM shapes (M, N, K, out_dtype): count", sorted(gm.skinny.items()), file=sys.stderr)
         peak = 2500.0
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summaries made by
         # tools/collect_profiles.sh + tools/pmc_json.py): only quoted for the workload they were measured on (C2 framewise, 1 GPU)

@@ -176,6 +176,13 @@ def test_bmm(cuda, dtype):
     close(ops.bmm_nt(a.to(cuda), w.to(cuda), out_dtype=torch.float32), ref.bmm_nt(a, w, torch.float32), **tol(dtype, 32))
     a, w = rnd(2, 70, 64, dtype=dtype, seed=3), rnd(2, 50, 64, dtype=dtype, seed=4)
     close(ops.bmm_nt(a.to(cuda), w.to(cuda)), ref.bmm_nt(a, w), **tol(dtype, 64))
+    # SAM2's mask product (<= 4 hypernetwork rows x 32 channels against every upscaled pixel): the lane-per-column short-K kernel
+    # (N >= 4096), ragged N, 1..4 rows, the shared-W form
+    for B, M, N in ((3, 4, 4096 + 37), (2, 1, 8192), (2, 3, 5000)):
+        a, w = rnd(B, M, 32, dtype=dtype, seed=5 + M), rnd(B, N, 32, dtype=dtype, seed=9 + M)
+        close(ops.bmm_nt(a.to(cuda), w.to(cuda), out_dtype=torch.float32), ref.bmm_nt(a, w, torch.float32), **tol(dtype, 32))
+    a, w = rnd(2, 4, 32, dtype=dtype, seed=21), rnd(4608, 32, dtype=dtype, seed=22)
+    close(ops.bmm_nt(a.to(cuda), w.to(cuda)), ref.bmm_nt(a, w), **tol(dtype, 32))
 
 
 ATT = [  # B, Hq, Hkv, Sq, Skv, D, causal

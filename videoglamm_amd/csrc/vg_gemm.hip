@@ -1672,8 +1672,58 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   }
 }
 
+// M <= 4 rows against SHORT rows of W (K x element size <= 256 bytes: SAM2's mask product, 4 hypernetwork rows x 32 channels against
+// 65536 upscaled pixels per frame — R/.../sam2/modeling/sam/mask_decoder.py:222-234).  The wave-per-column kernel above keeps 4 of 64
+// lanes busy there (998 us per C2 clip, r02 trace); here a LANE owns an output column: 64 consecutive W rows per wave are one
+// contiguous block, the A rows sit in LDS and are read as broadcasts, the outputs of a wave are 64 consecutive elements per row.
+template <typename T, typename TO, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_shortk_kernel(GemmArgs p) {
+  constexpr int KPC = 16 / sizeof(T);
+  __shared__ __attribute__((aligned(16))) char as[MT * 256];
+  const int bz = blockIdx.z, nch = p.K / KPC;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  for (int i = threadIdx.x; i < p.M * nch; i += 256) {
+    const int m = i / nch, c = i - m * nch;
+    *(u32x4_t*)(as + m * 256 + c * 16) = *(const u32x4_t*)(A + (int64_t)m * p.lda + c * KPC);
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.N) return;
+  const T* Wr = (const T*)p.W + (int64_t)bz * p.sW + (int64_t)n * p.ldw;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    const u32x4_t wv = *(const u32x4_t*)(Wr + c * KPC);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (m < p.M) acc[m] += dot16<T>(wv, *(const u32x4_t*)(as + m * 256 + c * 16));
+  }
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  const float bv = p.bias ? p.bias[n] : 0.f;
+  const float gv = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (m < p.M) {
+      float v = vg_act(acc[m] + bv, p.act) * gv;
+      if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
+      vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
+    }
+  }
+}
+
 template <typename T, typename TO, bool GLU>
 static void launch_skinny(const GemmArgs& p, int batch, hipStream_t st) {
+  if constexpr (!GLU) {
+    constexpr int KPC = 16 / sizeof(T);
+    if (p.M <= 4 && (int64_t)p.K * sizeof(T) <= 256 && p.K % KPC == 0 && p.N >= 4096 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 &&
+        p.lda % KPC == 0 && p.ldw % KPC == 0 && p.sA % KPC == 0 && p.sW % KPC == 0) {
+      dim3 gridk((p.N + 255) / 256, 1, batch);
+      gemm_skinny_shortk_kernel<T, TO, 4><<<gridk, 256, 0, st>>>(p);
+      return;
+    }
+  }
   dim3 grid((p.N + 3) / 4, 1, batch);
   if (p.M <= 1) gemm_skinny_kernel<T, TO, 1, GLU><<<grid, 256, 0, st>>>(p);
   else if (p.M <= 4) gemm_skinny_kernel<T, TO, 4, GLU><<<grid, 256, 0, st>>>(p);
