@@ -498,7 +498,7 @@ def main():
         # with the Hiera/LLM stream overlap switched off: an event pair on one of two concurrently fed streams also
         # brackets the time the launch waits behind the other stream's kernels, which is not kernel time
         # (the rocprofv3 summary under profiles/ is taken on the timed, overlapped configuration)
-        knobs = {"VG_HIERA_START": "serial", "VG_TOWERS_OVERLAP": "0"}
+        knobs = {"VG_HIERA_START": "serial", "VG_TOWERS_OVERLAP": "0", "VG_VIDEO_GRAPH": "0"}     # (a graph replay has no per-launch host calls to bracket)
         prev = {k: os.environ.get(k) for k in knobs}
         os.environ.update(knobs)
         try:

@@ -138,3 +138,33 @@ def test_hip_bf16_mask_miou(cuda):
     print(f"bf16 mask mIoU vs reference: framewise {iou_fw:.4f} (median per-mask {med:.4f}, {flipped}/{len(per)} choices flipped), "
           f"video branch {iou_vid:.4f}")
     assert med > 0.99 and flipped <= len(per) // 3 and iou_fw > 0.90 and iou_vid > 0.95, (per, iou_vid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_video_branch_graph_replay(cuda, dtype):
+    """The HIP-graph replay of the propagation (the default on the GPU: videoglamm_amd/model.py) issues the same launches as the eager
+    loop: its logits / uint8 masks are bit-identical, on the capturing call, on a replay with new inputs, and across the
+    least-recently-used cache of configurations."""
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+
+    fx = G.fixture("sam2_micro.npz")
+    T, N, H, W = [int(v) for v in fx["meta"]]
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_overrides())
+    m = SAM2(Params(sd, cuda, dtype), "", G.sam2_cfg())
+    for seed in (11, 31):                                   # first call captures, second replays with other inputs
+        images = G.rnd((T, 3, m.S, m.S), seed).to(cuda)
+        text = G.rnd((N, 256), seed + 1, 0.5).to(cuda).to(dtype)
+        feats = m.hiera_frames(images)
+        eager = m.video_branch(images, text, (H, W), frame_feats=feats)
+        graphed = m.video_branch_graphed(images, text, (H, W), feats)
+        assert torch.equal(eager, graphed)
+        em = m.video_branch(images, text, (H, W), frame_feats=feats, as_masks=True)
+        gm = m.video_branch_graphed(images, text, (H, W), feats, as_masks=True)
+        assert gm.dtype == torch.uint8 and torch.equal(em, gm)
+    for n in (1, N):                                        # more configurations than the cache keeps: evictions, re-captures
+        for hw in ((H, W), (H + 8, W), (H, W + 8)):
+            out = m.video_branch_graphed(images, text[:n], hw, feats)
+            assert torch.equal(out, m.video_branch(images, text[:n], hw, frame_feats=feats))
+    assert len(m._video_graphs) <= 4

@@ -356,9 +356,14 @@ class VideoGLaMMForCausalLM:
             feats = self.comm.gather_frame_feats(feats, sam.shape[0])
             masks, oids = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
             return out_ids, [self._segments(self._to_host(masks), obj_ids=oids)]
-        if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "0") == "1":
-            # the propagation replayed from a HIP graph: same results, measured neutral (r01: 201.05 vs 200.51 ms per clip), off by default
-            logits = self.sam2.video_branch_graphed(sam, emb, hw, feats)
+        if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "1") == "1":
+            # the propagation replayed from a HIP graph (same launches, same results: tests/test_host_sam2.py): the eager loop leaves
+            # the GPU idle 16 % of a C2 clip waiting for Python between ~8000 small launches (r02: 378 -> 361 ms); VG_VIDEO_GRAPH=0 = eager
+            fast = self._fast_masks()
+            out = self.sam2.video_branch_graphed(sam, emb, hw, feats, as_masks=fast)
+            if fast:
+                return out_ids, [self._segments(self._to_host(out))]
+            logits = out
         elif self._fast_masks():
             return out_ids, [self._segments(self._to_host(self.sam2.video_branch(sam, emb, hw, frame_feats=feats, as_masks=True)))]
         else:

@@ -430,19 +430,21 @@ class SAM2:
         up = ops.bilinear_mask if as_masks else ops.bilinear       # as_masks=True: uint8 (logit > 0) in one pass
         return up(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
 
-    def video_branch_graphed(self, images, text_embeds, video_hw, frame_feats):
+    def video_branch_graphed(self, images, text_embeds, video_hw, frame_feats, as_masks=False):
         """video_branch() replayed from a HIP graph.  The propagation is ~150 small launches per frame with no host decision
         in between (mask selection, object scores and memory selection all stay on the device), so the launch sequence of a
         (T, N, output size) configuration is captured once — after one eager pass that packs the weights — and replayed for
-        every later clip: the GPU no longer waits for Python between launches (r01: 30 ms of idle time in two 8-frame clips).
-        Inputs are copied into the graph's static buffers; the returned logits are the graph's output buffer (valid until the
-        next call with the same configuration)."""
+        every later clip: the GPU no longer waits for Python between launches (r02, C2 clip: 16 % of the step idle in the eager
+        loop; 378 -> 361 ms).  Inputs are copied into the graph's static buffers; the result is a copy of the graph's output
+        buffer.  At most four (T, N, size) configurations are kept (least recently used goes first)."""
         T, N = images.shape[0], text_embeds.shape[0]
-        key = (T, N, tuple(video_hw), text_embeds.dtype)
+        key = (T, N, tuple(video_hw), text_embeds.dtype, bool(as_masks))
         graphs = self.__dict__.setdefault("_video_graphs", {})
-        ent = graphs.get(key)
+        ent = graphs.pop(key, None)
         if ent is None:
-            self.video_branch(images, text_embeds, video_hw, frame_feats=frame_feats)      # eager once: lazy weight packing, kernel attributes
+            while len(graphs) >= 4:
+                graphs.pop(next(iter(graphs)))
+            self.video_branch(images, text_embeds, video_hw, frame_feats=frame_feats, as_masks=as_masks)      # eager once: lazy weight packing, kernel attributes
             st_feats = {t: [torch.empty_like(f) for f in frame_feats[t]] for t in range(T)}
             st_emb = torch.empty_like(text_embeds)
             for t in range(T):
@@ -452,15 +454,16 @@ class SAM2:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self.video_branch(images, st_emb, video_hw, frame_feats=st_feats)
-            ent = graphs[key] = (g, st_feats, st_emb, out)
+                out = self.video_branch(images, st_emb, video_hw, frame_feats=st_feats, as_masks=as_masks)
+            ent = (g, st_feats, st_emb, out)
+        graphs[key] = ent                       # (re-inserted last: most recently used)
         g, st_feats, st_emb, out = ent
         for t in range(T):
             for d, f in zip(st_feats[t], frame_feats[t]):
                 d.copy_(f)
         st_emb.copy_(text_embeds)
         g.replay()
-        return out
+        return out.clone()
 
     def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None, as_masks=False):
         """VideoGLaMM framewise decode — R/model/VideoGLaMM.py:205-241,676-766.  One mask-decoder batch per frame
