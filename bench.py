@@ -77,13 +77,14 @@ class GemmMeter:
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.linear, []
         self.skinny = {}           # VG_BENCH_SKINNY=1: the M <= 16 shapes seen (diagnostic, printed to stderr by main)
+        self.shapes = []           # (M, N, K) per record (VG_BENCH_GEMM_SHAPES=1: per-shape table on stderr)
         self.scope = None          # "mask_decoder" while SAM2.mask_decoder runs (the north star's mask-decoder GEMMs)
 
     @staticmethod
     def kernel_of(M, N, K, glu, windowed):
         """the launcher's own routing (vg_gemm_route, videoglamm_amd/csrc/vg_gemm.hip): which tile kernel runs this shape"""
         from videoglamm_amd import _lib
-        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
+        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128", 5: "small64"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
 
     def __enter__(self):
         def timed(x, w, *a, **k):
@@ -100,6 +101,7 @@ class GemmMeter:
             es = x.element_size()
             nbytes = (M * K + w.shape[0] * K) * es + M * N * y.element_size() * (2 if k.get("residual") is not None else 1)
             self.rec.append((2.0 * M * w.shape[0] * K, e0, e1, nbytes, self.kernel_of(M, N, K, k.get("glu"), False), self.scope))
+            self.shapes.append((M, w.shape[0], K))
             return y
         def timed_window(x, w, bias, B, H, W, ws, scatter, **k):      # Hiera's window-folded projections: same kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,6 +112,7 @@ class GemmMeter:
             N, K = w.shape
             nbytes = (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size() * (2 if k.get("residual") is not None else 1)
             self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, True), self.scope))
+            self.shapes.append((M, N, K))
             return y
         from videoglamm_amd import sam2 as _sam2
         meter = self
@@ -513,6 +516,15 @@ def main():
                 else:
                     os.environ[k] = v
         dec_ms, dec_n = dm.summary()
+        if os.environ.get("VG_BENCH_GEMM_SHAPES"):
+            torch.cuda.synchronize()
+            tab = {}
+            for r, sh in zip(gm.rec, gm.shapes):
+                e = tab.setdefault((r[4],) + sh, [0, 0.0])
+                e[0] += 1
+                e[1] += r[1].elapsed_time(r[2])
+            for k, (n, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1])[:40]:
+                print(f"gemm {k[0]:5s} M={k[1]:8d} N={k[2]:6d} K={k[3]:6d}  x{n:5d}  {ms:8.2f} ms  {ms / n * 1e3:8.1f} us each  {2.0 * k[1] * k[2] * k[3] * n / ms / 1e9:8.1f} TF/s", file=sys.stderr)
         if gm.skinny:
             print("skinny GEMM shapes (M, N, K, out_dtype): count", sorted(gm.skinny.items()), file=sys.stderr)
         peak = 2500.0
@@ -541,7 +553,8 @@ def main():
         labels = {"glds": "gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)",
                   "k64b": "gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)",
                   "w128": "gemm_tile_w128x8_kernel<bf16> (256x256 tile, 8 waves of 128x64: grids that fill the chip)",
-                  "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)"}
+                  "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)",
+                  "small64": "gemm_small64_kernel<bf16> (64x64 tile, whole K <= 256 in one DMA burst: problems of < 256 128x128 tiles — memory attention, mask decoder)"}
         roofs = {k: roof(k, labels[k], key="gemm_" + k) for k in labels}
         roofs = {"gemm_" + k: v for k, v in roofs.items() if v["launches"]}
         gv = None if args.tiny else meter_decode_gemv(model, ops)

@@ -36,7 +36,10 @@ def close(a, b, **kw):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (257, 130, 72), (1, 512, 256), (7, 256, 2048), (16, 33, 64),
                                    (4096, 384, 144), (1025, 1408, 1408), (300, 4, 32), (17, 200, 8), (513, 96, 152),
-                                   (8192, 3072, 256), (5001, 4999 + 1, 72)])  # the last two: many tiles, ragged M and N
+                                   (8192, 3072, 256), (5001, 4999 + 1, 72),   # these two: many tiles, ragged M and N
+                                   # few tiles and a short K (64 ... 256): gemm_small64_kernel in bf16 (memory attention / mask decoder
+                                   # shapes, ragged M, an N whose last 64-wide tile is partial, a single segment)
+                                   (4096, 256, 256), (4096, 128, 256), (300, 72, 64), (1000, 200, 192), (65, 64, 128)])
 def test_gemm(cuda, dtype, M, N, K):
     from videoglamm_amd import ops
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
@@ -146,6 +149,17 @@ def test_decode_attention(cuda, dtype, H, Hkv, D, max_len):
         else:
             close(g_kc, u_kc, rtol=1e-6, atol=1e-6)
     assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0   # arrival counters reset themselves
+
+
+def test_gemm_small64_routing_and_batch(cuda):
+    """the small-problem kernel is what runs the memory-attention projections (vg_gemm_route == 5), batched launches included."""
+    from videoglamm_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.vg_gemm_route(4096, 256, 256, 1, 0, 0) == 5 and lib.vg_gemm_route(4096, 128, 256, 1, 0, 0) == 5
+    assert lib.vg_gemm_route(4096, 2048, 256, 1, 0, 0) != 5 and lib.vg_gemm_route(4096, 256, 320, 1, 0, 0) != 5    # 512 tiles; K not in {64..256}
+    assert lib.vg_gemm_route(4096, 256, 256, 0, 0, 0) != 5                                                            # fp32 parity mode
+    a, w = rnd(3, 200, 128, dtype=torch.bfloat16, seed=1), rnd(3, 136, 128, dtype=torch.bfloat16, seed=2)
+    close(ops.bmm_nt(a.to(cuda), w.to(cuda)), ref.bmm_nt(a, w), **tol(torch.bfloat16, 128))
 
 
 def test_gemm_transpose_detect(cuda):

@@ -211,19 +211,19 @@ __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
 }
 
 // Row-major side of the LDS-staged epilogues, fast path: the lane's 8 columns are whole inside N, 16-byte aligned rows, no fp8 scales.
-// NP passes of 8 rows (rows m0 + 8 pass + rsub).  Measured r02 on the 256x256 kernel (Hiera stage-3 fc1, M = 65536): the previous
+// NP passes of RPP rows (rows m0 + RPP pass + rsub; RPP = 64 / lanes per row).  Measured r02 on the 256x256 kernel (Hiera stage-3 fc1, M = 65536): the previous
 // per-element form (ds_read_b32 + the activation's branch chain per element, a conditional residual load per pass that made every
 // pass wait for the previous pass's stores — loads and stores share vmcnt on gfx9) cost 90 of the GEMM's 287 us.  Here: every
 // residual load of the block is requested before its first store, the staged tile is read with two ds_read_b128 per row, the
 // activation and the presence of a residual are compile-time constants (one switch per block, epi_dispatch).
-template <typename TO, int ACT, bool RES, int NP, int ES>
+template <typename TO, int ACT, bool RES, int NP, int ES, int RPP = 8>
 __device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws, int m0, int n0, int cg, int rsub,
                                               const float (&bv)[8], const float (&gv)[8], TO* C, const TO* R) {
   int64_t mo[NP];
   bool ok[NP];
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    const int m = m0 + ps * 8 + rsub;
+    const int m = m0 + ps * RPP + rsub;
     ok[ps] = m < p.M;
     mo[ps] = m;
     if (p.wmode == 2) {
@@ -244,7 +244,7 @@ __device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws
   }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    const float* row = ws + (ps * 8 + rsub) * ES + cg * 8;
+    const float* row = ws + (ps * RPP + rsub) * ES + cg * 8;
     const f32x4_t x0 = *(const f32x4_t*)row, x1 = *(const f32x4_t*)(row + 4);
     float v[8];
 #pragma unroll
@@ -1589,6 +1589,95 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, f
   for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
 }
 
+// Small GEMMs: 64x64 tile, the WHOLE K (64, 128, 192 or 256 bf16 elements) staged by one burst of LDS DMAs — SAM2's memory-attention and
+// mask-decoder projections ([4096, 256] x [256, 256] and relatives: R/.../sam2/modeling/memory_attention.py:23-101,
+// sam/transformer.py:118-193).  On the 128x128 kernels such a problem is 64 workgroups walking K in serialised 64-byte steps, one DMA
+// round trip (~2 us) each: 18-25 us per launch, 840 + 256 of them per C2 clip in the video branch (r02 trace).  Here it is 256
+// workgroups (the whole chip, one round), one round trip, 4-16 MFMAs per wave and the straight-line epilogue.
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_small64_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int KPC = 8, SEG = 64 * 128;          // one 64-element K segment of a 64-row operand tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
+  const int M = p.M, N = p.N, nseg = p.K / 64;
+  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
+  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
+  // wave w stages rows [16w, 16w+16) of both operands: per K segment 2 DMA instructions of 8 rows (8 lanes per 128-byte line) each
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 16 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = bm * 64 + row, gn = bn * 64 + row;
+    gm = gm < M ? gm : M - 1;
+    gn = gn < N ? gn : N - 1;
+    const T* as = A + (int64_t)gm * p.lda + chunk * KPC;
+    const T* wsrc = W + (int64_t)gn * p.ldw + chunk * KPC;
+    char* da = smem + wave * 16 * 128 + i * 1024;
+    for (int sg = 0; sg < nseg; ++sg) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(as + sg * 64),
+                                       (__attribute__((address_space(3))) void*)(da + sg * SEG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + sg * 64),
+                                       (__attribute__((address_space(3))) void*)(da + (nseg + sg) * SEG), 16, 0, 0);
+    }
+  }
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int ra = wm * 32 + l31, rb = wn * 32 + l31;
+  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int sg = 0; sg < nseg; ++sg) {
+    const char* sa = smem + sg * SEG + ra * 128;
+    const char* sb = smem + (nseg + sg) * SEG + rb * 128;
+    u32x4_t fa[4], fb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 2 * g + h;
+      fa[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+      fb[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) MmaOp<T>::run(fa[g], fb[g], acc);
+  }
+  __syncthreads();   // the fp32 staging (4 waves x 32 rows x 36 floats) aliases the operand buffers
+
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  constexpr int ES = 36;
+  float* ws = (float*)smem + wave * 32 * ES;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + l31] = acc[r];
+  vg_lds_barrier();
+  const int cg = lane & 3, rsub = lane >> 2;          // 4 column groups x 16 rows per pass
+  const int n0w = bn * 64 + wn * 32, m0w = bm * 64 + wm * 32;
+  const int n0 = n0w + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
+  if (n0w + 32 <= N) {
+    epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
+      epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
+    });
+    return;
+  }
+  for (int ps = 0; ps < 2; ++ps) {                     // the last N tile of a ragged N (N % 8 == 0 still holds: vec_out)
+    const int ml = ps * 16 + rsub, m = m0w + ml;
+    if (m >= M || n0 >= N) continue;
+    for (int e = 0; e < 8 && n0 + e < N; ++e) {
+      float o = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
+      if (R) o += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n0 + e);
+      vg_elt<TO>::st(C + (int64_t)m * p.ldc + n0 + e, o);
+    }
+  }
+}
+
 // M <= 16 rows.  One wave per output column n streams W[n,:] once (16-byte loads, 4 independent loads in flight per
 // lane) against the L1/L2-resident A rows.  a_op == 1: W is [2N, K] = gate rows | up rows and column n of the
 // output is silu(A.gate_n) * (A.up_n) (HF LlamaMLP act(gate(x)) * up(x)) — the SwiGLU never touches HBM.
@@ -1741,6 +1830,12 @@ static int knob_variant() { static const int v = env_knob("VG_GEMM_VARIANT", 128
 static int knob_k64b() { static const int v = env_knob("VG_GEMM_K64B", 1); return v; }
 static int env_knob_s128() { static const int v = env_knob("VG_GEMM_S128", 1); return v; }
 static int knob_w128() { static const int v = env_knob("VG_GEMM_W128", 1); return v; }
+// small problems with a short K: fewer than 256 tiles of 128x128 (the chip is not filled), K = 64 / 128 / 192 / 256 bf16 -> gemm_small64_kernel
+static bool route_small64(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch) {
+  static const int on = env_knob("VG_GEMM_SMALL64", 1);
+  if (!on || es != 2 || a_op || wmode || !vec_out || M <= 16 || K % 64 != 0 || K > 256) return false;
+  return ((M + 127) / 128) * ((N + 127) / 128) * batch < 256;
+}
 // few K-steps per tile (K x element size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
 // (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
 static bool route_small_k(int64_t K, int es, int a_op) {
@@ -1830,6 +1925,21 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     }
     int ntw, mtw;
     const bool big = route_w128(p.M, p.N, p.K, (int)sizeof(T), p.a_op, p.wmode, p.vec_out, batch, &ntw, &mtw);
+    if constexpr (sizeof(T) == 2) {
+      if (route_small64(p.M, p.N, p.K, 2, p.a_op, p.wmode, p.vec_out, batch) && !p.sa) {
+        const int nseg = p.K / 64;
+        const int lds = nseg * 2 * 64 * 128 > 4 * 32 * 36 * 4 ? nseg * 2 * 64 * 128 : 4 * 32 * 36 * 4;
+        dim3 grids((p.N + 63) / 64, (p.M + 63) / 64, batch);
+        static bool small_attr = false;
+        if (!small_attr) {
+          (void)hipFuncSetAttribute((const void*)gemm_small64_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+          small_attr = true;
+        }
+        gemm_small64_kernel<TO><<<grids, 256, lds, st>>>(q);
+        VG_LAUNCH_CHECK();
+        return VG_OK;
+      }
+    }
     if (big) {
       dim3 gridw(ntw, mtw, batch);
       q.gn = pick_gn(mtw, ntw);
@@ -2023,6 +2133,7 @@ extern "C" int vg_gemm_f8(const uint8_t* A8, int64_t lda, const float* a_scale, 
 extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed) {
   if (M <= 16) return 0;
   const int es = in_dtype == VG_BF16 ? 2 : 4;
+  if (route_small64(M, N, K, es, a_op, windowed, 1, 1)) return 5;
   if (route_w128(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
   if (route_s128(K, es, a_op)) return 4;
   if (route_small_k(K, es, a_op)) return 2;
