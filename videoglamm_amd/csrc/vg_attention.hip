@@ -506,7 +506,15 @@ __global__ __launch_bounds__(256, 2) void win256_attn_kernel(WinAttnArgs p) {
   char* Vs = smem;
   char* Ks = smem + VT_BYTES;                   // (reads past the last V^T row / the last K chunk land in finite data)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int head = blockIdx.x, win = blockIdx.y;
+  // XCD-aware (window, head) order: workgroup L lands on XCD L % 8; the heads of one window read neighbouring 144-byte pieces of the same
+  // rows of the fused q|k|v tensor, so a window's heads run back to back on ONE XCD and share those lines in its L2 (with head = blockIdx.x
+  // the eight heads sat on eight XCDs: PMC traffic 540 MB per launch for 301 MB algorithmic, r02)
+  int head = blockIdx.x, win = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, j = L >> 3;
+    win = (L & 7) + 8 * (j / (int)gridDim.x);
+    head = j % (int)gridDim.x;
+  }
   const bf16_t* Qg = (const bf16_t*)p.Q + (int64_t)win * p.q_sb + (int64_t)head * p.q_sh;
   const bf16_t* Kg = (const bf16_t*)p.K + (int64_t)win * p.k_sb + (int64_t)head * p.k_sh;
   const bf16_t* Vg = (const bf16_t*)p.V + (int64_t)win * p.v_sb + (int64_t)head * p.v_sh;
