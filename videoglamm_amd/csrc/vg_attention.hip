@@ -19,6 +19,7 @@ struct AttnArgs {
   int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
   float scale;
   int nsplit, split_len;   // split-KV: blockIdx.x = q_tile * nsplit + split; partials go to `part`
+  int xcd;                 // 1: (batch, head) blocks per XCD (see attn_kernel); needs (Hq * B) % 8 == 0
   float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
   const int* skv_dev;      // optional: Skv = *skv_dev + Sq read on the device (graph-replayable decode step)
   int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
@@ -107,10 +108,22 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = (tid >> 6) % NQW, kh = (tid >> 6) / NQW;   // query-row group, key half (KS == 2)
-  const int split = blockIdx.x % p.nsplit;
+  // XCD-aware order (VG_ATTN_XCD, p.xcd): workgroup L of the launch runs on XCD L % 8.  Every query tile of a (batch, head) walks the same
+  // K / V, and the G query heads of a KV head share them too: XCD x takes a contiguous block of (batch, head) pairs and runs each
+  // pair's query tiles back to back, so K / V are fetched into ONE L2 instead of eight
+  int bx = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (p.xcd) {
+    const int nx = gridDim.x, BH = gridDim.y * gridDim.z;
+    const int L = (blockIdx.z * gridDim.y + blockIdx.y) * nx + blockIdx.x, j = L >> 3;
+    const int bh = (L & 7) * (BH >> 3) + j / nx;
+    bx = j % nx;
+    head = bh % (int)gridDim.y;
+    b = bh / (int)gridDim.y;
+  }
+  const int split = bx % p.nsplit;
   // causal: the LAST query tiles walk the most keys — hand them out first, so the short ones fill the tail of the launch
-  const int qtile = (p.causal > 0 && !p.fold) ? ((int)gridDim.x / p.nsplit - 1 - (int)blockIdx.x / p.nsplit) : (int)blockIdx.x / p.nsplit;
-  const int q0 = qtile * BQ, head = blockIdx.y, b = blockIdx.z;
+  const int qtile = (p.causal > 0 && !p.fold) ? ((int)gridDim.x / p.nsplit - 1 - bx / p.nsplit) : bx / p.nsplit;
+  const int q0 = qtile * BQ;
   const int G = p.Hq / p.Hkv;
   const int kvh = p.fold ? head : head / G;
   const int D = p.D, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
@@ -920,11 +933,13 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
              "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(D+2) floats)");
   }
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
-             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, workspace, skv_dev, 0};
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, 0, workspace, skv_dev, 0};
   // fold the G query heads of a KV head into one query tile when they all fit (decode: G*Sq = 4 rows): K/V staged
   // once per KV head instead of once per query head
   const int tile_rows = dtype == VG_BF16 ? 128 : 64;
   if (Hq > Hkv && (Hq / Hkv) * Sq <= tile_rows) p.fold = 1;
+  static const int xcd_on = getenv("VG_ATTN_XCD") ? atoi(getenv("VG_ATTN_XCD")) : 1;
+  p.xcd = xcd_on && !p.fold && ((int64_t)Hq * B) % 8 == 0;
   hipStream_t st = (hipStream_t)stream;
   // (measured: a 1-wave workgroup for <= 32 query rows is SLOWER — 50 vs 31 us per decode launch — because the
   // K/V tile staging, not the MFMA work, dominates a few-row block and 64 threads stage 4x slower than 256)
