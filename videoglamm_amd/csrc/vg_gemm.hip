@@ -1378,8 +1378,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
             if (x < 4) fa[nxt][x] = v; else fb[nxt][x - 4] = v;
           }
         }
+#ifndef VG_W128X8_PLAN
+#define VG_W128X8_PLAN 0
+#endif
+#if VG_W128X8_PLAN == 0
         const int di = g * 3 + sl;                          // 3 + 3 + 2 DMA instructions over groups 0..2
         if (has_next && g < 3 && sl < (g < 2 ? 3 : 2)) dma(kt + 1, buf ^ 1, di);
+#elif VG_W128X8_PLAN == 1
+        if (has_next && g < 2) dma(kt + 1, buf ^ 1, g * 4 + sl);          // 4 + 4 over groups 0..1
+#elif VG_W128X8_PLAN == 2
+        if (has_next && g == 0) { dma(kt + 1, buf ^ 1, 2 * sl); dma(kt + 1, buf ^ 1, 2 * sl + 1); }   // all eight in group 0
+#else
+        if (has_next && g == 0 && sl == 0) {                                // all eight before the step's first fragment read returns
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dma(kt + 1, buf ^ 1, i);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (g < 3) {
