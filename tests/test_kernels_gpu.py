@@ -552,6 +552,21 @@ def test_gemm_w128x8(cuda, M, N, K, glu):
     _check_big_gemm(cuda, M, N, K, glu)
 
 
+def test_gemm_w128x8_persistent_queue(cuda):
+    """the persistent 256x256 kernel's tile queue: more tiles than CUs over a BATCH of problems (tiles of all batch entries form one
+    queue; every workgroup walks several tiles and prefetches the next tile's first K step under the last), K = 1152 (18 K steps: the
+    short-K shapes r02 routes here), against the per-entry GEMMs that take other kernels."""
+    from videoglamm_amd import _lib, ops
+    B, M, N, K = 24, 1024, 1024, 1152
+    a = (torch.randn(B, M, K, device=cuda, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(B, N, K, device=cuda, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    y = ops.bmm_nt(a, w)
+    for b in (0, 7, B - 1):
+        assert _lib.load().vg_gemm_route(M, N, K, 1, 0, 0) != 3          # one entry alone does not fill the chip: another kernel
+        close(y[b], ops.linear(a[b], w[b]).float().cpu(), rtol=2e-2, atol=0.3)
+        close(y[b], a[b].float().cpu() @ w[b].float().cpu().t(), rtol=2e-2, atol=0.3)
+
+
 def test_gemm_w128_four_wave(cuda):
     """the four-wave variant (VG_GEMM_W128=5) of the same kernel: the knob is read once per process, so a child process runs it."""
     import os
