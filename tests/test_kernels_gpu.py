@@ -264,6 +264,8 @@ def test_pointwise(cuda, dtype):
     close(ops.axpby(a.to(cuda), b.to(cuda), 1.0, 0.1), ref.axpby(a, b, 1.0, 0.1), **tol(dtype))
     close(ops.add(a.to(cuda), a.to(cuda)), ref.add(a, a), **tol(dtype))
     close(ops.axpby(a.to(cuda), rnd(32, seed=3).to(cuda), 2.0, 1.0), ref.axpby(a, rnd(32, seed=3), 2.0, 1.0), **tol(dtype))
+    odd, ob = rnd(7, 5, 3, dtype=dtype, seed=5), rnd(5, 3, dtype=dtype, seed=6)          # sizes off the 8-element vector path
+    close(ops.axpby(odd.to(cuda), ob.to(cuda), 0.5, -1.5), ref.axpby(odd, ob, 0.5, -1.5), **tol(dtype))
     for act in (1, 2, 3, 4, 5):
         close(ops.activation(a.to(cuda), act), ref.activation(a, act), **tol(dtype))
     gu = rnd(9, 2 * 48, dtype=dtype, seed=4)

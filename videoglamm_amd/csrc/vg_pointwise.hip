@@ -19,10 +19,42 @@ __global__ __launch_bounds__(256) void axpby_kernel(const void* a, const void* b
     st_any(out, i, odt, alpha * av + beta * bv);
   }
 }
+// bf16 a / out, 8 elements (16 bytes) per thread; b bf16 or fp32 with a period that is a multiple of 8 (position embeddings, residuals)
+template <bool BF32>
+__global__ __launch_bounds__(256) void axpby_vec_kernel(const bf16_t* a, const void* b, bf16_t* out, int64_t n8, float alpha, float beta, int64_t bp8) {
+  PW_LOOP(i, n8) {
+    const u32x4_t av = *(const u32x4_t*)(a + i * 8);
+    float bv[8];
+    const int64_t j = i % bp8;
+    if constexpr (BF32) {
+      const f32x4_t b0 = *(const f32x4_t*)((const float*)b + j * 8), b1 = *(const f32x4_t*)((const float*)b + j * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+    } else {
+      const u32x4_t bw = *(const u32x4_t*)((const bf16_t*)b + j * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[2 * e] = __uint_as_float(bw[e] << 16); bv[2 * e + 1] = __uint_as_float(bw[e] & 0xffff0000u); }
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
+      o[e] = f2bf2(alpha * a0 + beta * bv[2 * e], alpha * a1 + beta * bv[2 * e + 1]);
+    }
+    *(u32x4_t*)(out + i * 8) = o;
+  }
+}
 extern "C" int vg_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta,
                         int64_t b_period, int a_dtype, int b_dtype, int out_dtype, vg_stream_t stream) {
   VG_CHECK(a && out && n >= 0 && (!b || b_period > 0), VG_ERR_ARG, "vg_axpby: bad args");
   if (n == 0) return VG_OK;
+  if (b && a_dtype == VG_BF16 && out_dtype == VG_BF16 && n % 8 == 0 && b_period % 8 == 0 &&
+      (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) {
+    if (b_dtype == VG_F32) axpby_vec_kernel<true><<<pw_grid(n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, b, (bf16_t*)out, n / 8, alpha, beta, b_period / 8);
+    else axpby_vec_kernel<false><<<pw_grid(n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, b, (bf16_t*)out, n / 8, alpha, beta, b_period / 8);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   axpby_kernel<<<pw_grid(n), 256, 0, (hipStream_t)stream>>>(a, b, out, n, alpha, beta, b ? b_period : 1, a_dtype, b_dtype, out_dtype);
   VG_LAUNCH_CHECK();
   return VG_OK;
