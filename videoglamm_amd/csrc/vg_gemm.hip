@@ -4,13 +4,17 @@
 //   gemm_tile_glds_kernel    128x128 tile, 4 waves, 128-byte K steps staged by LDS-DMA into swizzled unpadded rows, two stages,
 //                            two workgroups per CU.  Carries the window gather/scatter (vg_gemm_window), the SwiGLU epilogue,
 //                            split-K (vg_gemm_splitk) and, instantiated on bytes, the fp8 x fp8 GEMM (vg_gemm_f8).
-//   gemm_tile_w128x8_kernel  256x256 tile, 8 waves of 128x64 (two per SIMD), whole-line DMAs issued between MFMAs: grids that fill the
-//   gemm_tile_w128_kernel    chip (the 4-wave variant, 128x128 per wave, is the A/B twin).
+//   gemm_tile_w128x8_kernel  256x256 tile, 8 waves of 128x64 (two per SIMD), whole-line DMAs issued between MFMAs, persistent (one workgroup
+//   gemm_tile_w128_kernel    per CU walks the tile queue): grids that fill the chip (the 4-wave variant, 128x128 per wave, is the A/B twin).
 //   gemm_tile_s128_kernel    128x128 tile, ONE 128-byte-row stage, four workgroups per CU: 1024 <= K*es <= 3072 bytes.
 //   gemm_tile_k64b_kernel    128x128 tile, 64-byte K steps, four workgroups per CU: K*es < 1024 bytes.
-//   gemm_tile_kernel / gemm_tile_ring_kernel   register-staged and 3-stage-ring variants kept as measured A/B knobs.
+//   (r01's register-staged and 3-stage-ring A/B twins were removed at the end of r02; their measurements are in DESIGN.md section 5)
+//   gemm_small64_kernel      64x64 tile, the whole K (<= 256) in one DMA burst: problems of fewer than 256 128x128 tiles (memory attention,
+//                            mask decoder).
 //   gemm_skinny_kernel       M <= 16 rows (LLM decode lm_head, mask-decoder token MLPs): one wave per output column streams its
-//                            W row once with 16-byte loads; HBM-bound by construction.
+//                            W row once with 16-byte loads; HBM-bound by construction.  gemm_skinny_shortk_kernel: <= 4 rows against
+//                            short W rows (the mask product), a lane per output column.
+//   epi_rows_fast / epi_dispatch: the straight-line row-major side shared by every LDS-staged epilogue.
 // Routing: launch_gemm / route_* below (and vg_gemm_route for the bench).
 #include "vg_common.h"
 #include <stdlib.h>
@@ -86,112 +90,6 @@ constexpr int GBM = 128, GBN = 128;
 template <typename TO>
 __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&acc)[2][2], char* smem, int m0w, int n0w, int bz,
                                                  int wave, int lane);
-
-// BKB = bytes of K per step (128: 64 bf16 / 32 f32; 64: half of that, half the LDS -> more workgroups per CU).
-// PF  = register prefetch depth: 1 = next tile loaded while computing the current one; 2 = two tiles in flight
-//       (tile t+2 is issued before tile t is computed and written to LDS a full iteration later).
-template <typename T, typename TO, int BKB, int PF>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);     // elements per 16-byte chunk
-  constexpr int BK = BKB / sizeof(T);     // K elements per step
-  constexpr int ROWB = BKB + 16;          // padded LDS row: conflict-free ds_read_b128 fragments
-  constexpr int TILEB = 128 * ROWB;
-  constexpr int CPR = BKB / 16;           // 16-byte chunks per row
-  constexpr int NCH = 128 * CPR / 256;    // chunks per thread per operand
-  constexpr int NG = BKB / 32;            // MFMA k-groups per step
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  // XCD-aware tile order (guide T1): workgroup id b lands on XCD b % 8; give every XCD a contiguous run of the
-  // row-major tile order so tiles sharing an A row-panel / W column-panel hit the same L2.  Bijective for any grid.
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-
-  u32x4_t ra0[NCH], rb0[NCH], ra1[PF == 2 ? NCH : 1], rb1[PF == 2 ? NCH : 1];
-  auto gload = [&](int kt, u32x4_t* ra, u32x4_t* rb) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
-      const int k = kt * BK + kc * KPC;
-      const int gm = bm * GBM + row, gn = bn * GBN + row;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      ra[i] = (gm < M && k < K) ? *(const u32x4_t*)(A + (int64_t)gm * p.lda + k) : z;
-      rb[i] = (gn < N && k < K) ? *(const u32x4_t*)(W + (int64_t)gn * p.ldw + k) : z;
-    }
-  };
-  auto swrite = [&](int buf, const u32x4_t* ra, const u32x4_t* rb) {
-    char* sa = smem + buf * 2 * TILEB;
-    char* sb = sa + TILEB;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
-      *(u32x4_t*)(sa + row * ROWB + kc * 16) = ra[i];
-      *(u32x4_t*)(sb + row * ROWB + kc * 16) = rb[i];
-    }
-  };
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * 2 * TILEB + (wm * 64 + l31) * ROWB + h * 16;
-    const char* sb = smem + buf * 2 * TILEB + TILEB + (wn * 64 + l31) * ROWB + h * 16;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      u32x4_t a0 = *(const u32x4_t*)(sa + g * 32);
-      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * ROWB + g * 32);
-      u32x4_t b0 = *(const u32x4_t*)(sb + g * 32);
-      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * ROWB + g * 32);
-      MmaOp<T>::run(a0, b0, acc[0][0]);
-      MmaOp<T>::run(a0, b1, acc[0][1]);
-      MmaOp<T>::run(a1, b0, acc[1][0]);
-      MmaOp<T>::run(a1, b1, acc[1][1]);
-    }
-  };
-
-  const int nk = (K + BK - 1) / BK;
-  gload(0, ra0, rb0);
-  swrite(0, ra0, rb0);
-  if constexpr (PF == 2) {
-    if (nk > 1) gload(1, ra1, rb1);
-  }
-  __syncthreads();
-  if constexpr (PF == 1) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) gload(kt + 1, ra0, rb0);
-      compute(buf);
-      if (kt + 1 < nk) swrite(buf ^ 1, ra0, rb0);
-      __syncthreads();
-    }
-  } else {
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) gload(kt + 2, ra0, rb0);     // even tile kt lives in buf 0; tile kt+1 waits in set 1
-      compute(0);
-      if (kt + 1 < nk) swrite(1, ra1, rb1);
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) gload(kt + 3, ra1, rb1);     // odd tile kt+1 in buf 1; tile kt+2 waits in set 0
-      compute(1);
-      if (kt + 2 < nk) swrite(0, ra0, rb0);
-      __syncthreads();
-    }
-  }
-
-  gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
-}
 
 // Output-tile store flavour of the 256x256 kernel's epilogue (A/B macro): 0 plain, 1 nontemporal (nt), 2 write-through (sc0 sc1: the
 // line is not kept in the XCD's L2), 3 sc1 only
@@ -971,102 +869,6 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
 
   // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
   gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
-}
-
-// 256x128 output tile / 512 threads (8 waves as 4(M) x 2(N), each 64x64 as above) with a THREE-stage LDS ring filled
-// by LDS-DMA two K-steps ahead.  The 128x128 kernels drain their DMA queue at every barrier (vmcnt(0) inside
-// __syncthreads) with only one K-step (~0.2 us of MFMA) of prefetch distance against ~1-2 us of L2/HBM latency; here
-// the loads of stage kt+1 stay in flight across the barrier (counted vmcnt + raw s_barrier) and each staged byte feeds
-// 1.33x the MFMA work.  Needs K % (128/sizeof(T)) == 0; the launcher falls back to the 128x128 kernel otherwise.
-// LDS: 3 x (256 + 128) rows x 128 B = 144 KB (1 workgroup per CU); the epilogue staging (8 x 64 x 68 fp32) reuses it.
-template <typename T, typename TO>
-__global__ __launch_bounds__(512) void gemm_tile_ring_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);
-  constexpr int BK = 128 / sizeof(T);
-  constexpr int TA = 256 * 128, STAGE = (256 + 128) * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-
-  // this wave's DMA pieces per stage: A rows [32w, 32w+32) in 4 instructions of 8 rows, W rows [16w, 16w+16) in 2
-  const T* asrc[4];
-  const T* wsrc[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = bm * 256 + row;
-    gm = gm < M ? gm : M - 1;
-    asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 16 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gn = bn * 128 + row;
-    gn = gn < N ? gn : N - 1;
-    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
-  }
-  auto issue = [&](int kt, int buf) {
-    char* sa = smem + buf * STAGE + wave * 32 * 128;
-    char* sb = smem + buf * STAGE + TA + wave * 16 * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
-  };
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
-  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
-  const int nk = K / BK;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of stage kt have landed once at most the 6 DMAs of stage kt+1 are still outstanding
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone is done reading buffer (kt+2)%3 = (kt-1)%3
-    if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
-    const char* sa = smem + buf * STAGE + ra * 128;
-    const char* sb = smem + buf * STAGE + TA + rb * 128;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = 2 * g + h;
-      u32x4_t a0 = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
-      u32x4_t a1 = *(const u32x4_t*)(sa + 32 * 128 + ((c ^ swa) << 4));
-      u32x4_t b0 = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
-      u32x4_t b1 = *(const u32x4_t*)(sb + 32 * 128 + ((c ^ swb) << 4));
-      MmaOp<T>::run(a0, b0, acc[0][0]);
-      MmaOp<T>::run(a0, b1, acc[0][1]);
-      MmaOp<T>::run(a1, b0, acc[1][0]);
-      MmaOp<T>::run(a1, b1, acc[1][1]);
-    }
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  __syncthreads();   // the epilogue reuses the ring as fp32 staging
-  gemm_epilogue128<TO>(p, acc, smem, bm * 256 + wm * 64, bn * 128 + wn * 64, bz, wave, lane);
 }
 
 // 256x256 output tile / 256 threads: FOUR waves, each owning 128x128 (4x4 MFMA tiles, 256 accumulator registers), one
@@ -1899,37 +1701,18 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     };
     GemmArgs q = p;
     q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + GBN - 1) / GBN);
-    // main-loop variant (A/B knob, the default is the measured best): VG_GEMM_VARIANT = 1284 LDS-DMA staging with all 16
-    // fragment reads of a K-step requested up front (default), 1283 the same with reads group by group;
-    // "<K-step bytes><prefetch depth>" in {1281, 1282, 641, 642} = the register-staged kernel
+    // VG_GEMM_VARIANT = 644: the 64-byte-step kernel for every shape (A/B knob); default: the 128x128 LDS-DMA kernel with all 16 fragment
+    // reads of a K step requested up front.  (The register-staged kernels 1281 / 1282 / 641 / 642, the group-by-group fragment reads 1283
+    // and the 256x128 three-stage ring, r01's A/B twins, were removed at the end of r02: -10 % / 0 / +-3 %)
     const int variant = knob_variant();
-    static bool tile_attr = false;
-    if (!tile_attr) {
-      tile_attr = true;
-      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
-      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 144);
-      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
-      (void)hipFuncSetAttribute((const void*)gemm_tile_kernel<T, TO, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 80);
-    }
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
     // the fp32 epilogue staging needs 4 x 64 x 68 floats = 69632 B of LDS whatever the K step
-    const int lds128 = 4 * 128 * 144, lds64 = 4 * 64 * 68 * 4;
+    const int lds128 = 4 * 128 * 144;
     static bool glds_attr = false;
     if (!glds_attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
       (void)hipFuncSetAttribute((const void*)gemm_tile_glds_kernel<T, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
       glds_attr = true;
     }
-    // 256x128 ring kernel (VG_GEMM_RING=2 enables it where K is whole K-steps and there are >= 200 tiles): measured r01
-    // within +-3% of the 128x128 kernel on the C1 shapes (+5% only at 8192^3) -- both sit at the LDS-read ceiling of a
-    // 64x64-per-wave tiling -- so it stays an A/B knob
-    static int ring = -1;
-    if (ring < 0) {
-      const char* e = getenv("VG_GEMM_RING");
-      ring = e ? atoi(e) : 1;
-      (void)hipFuncSetAttribute((const void*)gemm_tile_ring_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 128);
-    }
-    const int64_t tiles_ring = (int64_t)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
     const bool small_k = route_small_k(p.K, (int)sizeof(T), p.a_op);
     static bool w128_attr = false;
     if (!w128_attr) {
@@ -1977,17 +1760,8 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       gemm_tile_glds_kernel<T, TO, true><<<gridg, 256, lds128, st>>>(q);
     } else if (p.wmode) {
       gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
-    } else if ((variant == 1283 || variant == 1284) && ring == 2 && p.K % (128 / (int)sizeof(T)) == 0 && p.M > 128 && tiles_ring >= 200) {
-      dim3 gridr((p.N + 127) / 128, (p.M + 255) / 256, batch);
-      q.gn = pick_gn((p.M + 255) / 256, (p.N + 127) / 128);
-      gemm_tile_ring_kernel<T, TO><<<gridr, 512, 3 * 384 * 128, st>>>(q);
-    } else if (variant == 1283) gemm_tile_glds_kernel<T, TO><<<grid, 256, lds128, st>>>(q);
-    else if (variant == 1284) gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
-    else if (variant == 644) gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
-    else if (variant == 1282) gemm_tile_kernel<T, TO, 128, 2><<<grid, 256, lds128, st>>>(q);
-    else if (variant == 641) gemm_tile_kernel<T, TO, 64, 1><<<grid, 256, lds64, st>>>(q);
-    else if (variant == 642) gemm_tile_kernel<T, TO, 64, 2><<<grid, 256, lds64, st>>>(q);
-    else gemm_tile_kernel<T, TO, 128, 1><<<grid, 256, lds128, st>>>(q);
+    } else if (variant == 644) gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
+    else gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
