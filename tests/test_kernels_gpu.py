@@ -584,6 +584,18 @@ def test_gemm_w128_four_wave(cuda):
             "print('four-wave ok')\n") % (os.path.dirname(here), here)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_GEMM_W128="5"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "four-wave ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the eight-wave kernel with one workgroup per tile (VG_W128_PERSIST=0: no tile queue, no cross-tile prefetch) and the attention
+    # kernels in plain dispatch order (VG_ATTN_XCD=0) are the other halves of this round's A/B knobs: same results
+    code2 = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
+             "import test_kernels_gpu as t\n"
+             "from videoglamm_amd import _lib\n"
+             "assert _lib.load().vg_init(0) > 0\n"
+             "dev = torch.device('cuda:0')\n"
+             "for c in t.BIG[:2]: t._check_big_gemm(dev, *c)\n"
+             "for c in t.ATT: t.test_attention(dev, torch.bfloat16, c)\n"
+             "print('knobs ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, VG_W128_PERSIST="0", VG_ATTN_XCD="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 WIN = [  # (Hq, Hkv, Sq, Skv, D, window): causal + sliding window (the query's own position and the window - 1 before it)
