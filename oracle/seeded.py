@@ -35,3 +35,11 @@ def sam2_overrides(prefix=""):
     """Random-init SAM2 predicts 'no object' (object_score_logits < 0 -> all masks = -1024):
     bias the object-score head positive so the mask path is exercised."""
     return {prefix + "sam_mask_decoder.pred_obj_score_head.layers.2.bias": lambda t: t * 0 + 4.0}
+
+
+def sam2_noobj_overrides(c, k, prefix=""):
+    """score head rescaled so that objects disappear and reappear over a clip: the random-init head answers ~ -0.5 with a spread
+    of 0.01 between frames / objects; score' = k * (score + c) puts the values on both sides of 0 with a usable margin
+    (tests/golden/make_golden.py:gen_sam2_noobj picks c on the reference and stores it in the fixture)."""
+    h = prefix + "sam_mask_decoder.pred_obj_score_head.layers.2."
+    return {h + "weight": lambda t: t * k, h + "bias": lambda t: t * 0 + c * k}

@@ -174,6 +174,60 @@ def gen_sam2_long():
     save("sam2_video_long.npz", **out)
 
 
+def _run_ref_video(m, images, text, H, W):
+    state = m.init_state_from_tensor(images, H, W)
+    m.reset_state(state)
+    for k in range(text.shape[0]):
+        m.add_new_text(inference_state=state, frame_idx=0, obj_id=k, text=text.unsqueeze(1)[k].unsqueeze(0))
+    vid = [logits.clone() for _, _, logits in m.propagate_in_video(state)]
+    od = state["output_dict"]
+    T = images.shape[0]
+    frames = [od["cond_frame_outputs"][0]] + [od["non_cond_frame_outputs"][t] for t in range(1, T)]
+    return torch.stack(vid)[:, :, 0], frames
+
+
+def gen_sam2_noobj():
+    """video branch with objects that DISAPPEAR (object_score_logits <= 0): NO_OBJ_SCORE fill of the masks, the no_obj_ptr mix
+    of the pointers, the -1024 mask through the bilinear upsample + memory encoder — R/.../sam2_base.py:355-364,390-401,
+    sam2_video_predictor.py:571-612.  The random-init score head barely tells objects / frames apart (spread 0.01 around -0.5),
+    so its last layer is rescaled: score' = K (score + c), seeded.sam2_noobj_overrides(c, K).  c is searched on the reference
+    itself among values that split the two objects on frame 0, for the largest margin |score'| over all (frame, object) pairs
+    (a margin far above fp32 summation noise keeps every present / absent decision implementation-independent); c, K and the
+    score table are stored in the fixture."""
+    m = build_ref_sam2()
+    S = SAM2_MICRO["image_size"]
+    T, N, H, W = 9, 2, 40, 56
+    images = rnd((T, 3, S, S), 71)
+    text = rnd((N, 256), 72, 0.5)
+    rec = []
+    hook = m.sam_mask_decoder.pred_obj_score_head.register_forward_hook(lambda mod, i, o: rec.append(o.flatten().clone()))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    K, best = 30.0, None
+    for c in [0.556 + 0.0005 * i for i in range(23)]:
+        sd = dict(sd0)
+        for name, fn in seeded.sam2_noobj_overrides(c, K).items():
+            sd[name] = fn(sd0[name])
+        m.load_state_dict(sd)
+        rec.clear()
+        vid, frames = _run_ref_video(m, images, text, H, W)
+        sc = torch.stack([torch.cat(rec[:N])] + rec[N:])                           # [T,N]: frame 0 is one call per object
+        pres = sc > 0
+        ok = bool(pres.any(0).all() and (~pres).any(0).all() and (pres[:, 0] != pres[:, 1]).sum() >= 2 and pres[0, 0] != pres[0, 1])
+        margin = float(sc.abs().min())
+        print(f"c {c:.4f} margin {margin:.4f} ok {ok} pattern {pres.int().tolist()}")
+        if ok and (best is None or margin > best[0]):
+            best = (margin, c, vid, frames, sc)
+    hook.remove()
+    margin, c, vid, frames, sc = best
+    assert margin > 0.03, margin
+    print("chosen c", c, "margin", margin, "scores", sc.tolist())
+    out = dict(meta=np.array([T, N, H, W]), score_c=np.float64(c), score_k=np.float64(K), obj_scores=sc, video_logits=vid,
+               low_res=torch.stack([f["pred_masks"] for f in frames]), obj_ptr=torch.stack([f["obj_ptr"] for f in frames]))
+    for t in range(T):
+        out[f"maskmem_{t}"] = frames[t]["maskmem_features"].float()
+    save("sam2_noobj.npz", **out)
+
+
 def gen_vlm():
     ri.install()
     from model.videogpt_plus.model.internvideo.internvideo2 import PretrainInternVideo2
@@ -423,6 +477,8 @@ if __name__ == "__main__":
         gen_sam2()
     if what in ("sam2_long", "all"):
         gen_sam2_long()
+    if what in ("sam2_noobj", "all"):
+        gen_sam2_noobj()
     if what in ("vlm", "all"):
         gen_vlm()
     if what in ("phi3", "all"):

@@ -89,6 +89,48 @@ def run_long(device, tol):
     torch.testing.assert_close(vid9.cpu(), fx["video_logits"][:9], **tol)
 
 
+def run_noobj(device, tol):
+    """objects that disappear and come back (tests/golden/sam2_noobj.npz): where_rows row selection, the NO_OBJ_SCORE fill through
+    the bilinear upsample + memory encoder, the no_obj_ptr mix — R/.../sam2_base.py:355-364,390-401."""
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2, NO_OBJ_SCORE
+    fx = G.fixture("sam2_noobj.npz")
+    T, N, H, W = [int(v) for v in fx["meta"]]
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_noobj_overrides(float(fx["score_c"]), float(fx["score_k"])))
+    m = SAM2(Params(sd, device, torch.float32), "", G.sam2_cfg())
+    images, text = G.rnd((T, 3, m.S, m.S), 71).to(device), G.rnd((N, 256), 72, 0.5).to(device)
+    trace = {}
+    vid = m.video_branch(images, text, (H, W), trace)
+    scores = torch.stack([trace["frame0_obj_logits"].view(-1)] + [trace[f"obj_logits_{t}"].view(-1) for t in range(1, T)]).cpu()
+    pres = fx["obj_scores"] > 0
+    assert pres.any() and (~pres).any() and (pres[:, 0] != pres[:, 1]).any()
+    assert torch.equal(scores > 0, pres)
+    torch.testing.assert_close(scores, fx["obj_scores"], rtol=1e-3, atol=2e-3)
+    low = trace["low_res"].cpu()
+    torch.testing.assert_close(low, fx["low_res"], **tol)
+    assert (low[~pres] == NO_OBJ_SCORE).all()
+    torch.testing.assert_close(trace["obj_ptr"].float().cpu(), fx["obj_ptr"], **tol)
+    torch.testing.assert_close(vid.cpu(), fx["video_logits"], **tol)
+    for t in range(T):
+        got = trace["maskmem"][t].float().cpu().view(N, 16, 16, 64).permute(0, 3, 1, 2)
+        torch.testing.assert_close(got, fx[f"maskmem_{t}"], rtol=1e-2, atol=2e-3)
+    return m, images, text, (H, W), vid
+
+
+def test_video_noobj_cpu(cpu_ops):
+    run_noobj(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
+
+
+@pytest.mark.gpu
+def test_video_noobj_hip_fp32(cuda):
+    m, images, text, hw, vid = run_noobj(cuda, dict(rtol=1e-3, atol=1e-3))
+    # the graph-replayed propagation (the product default) takes the same present / absent decisions on the device
+    feats = m.hiera_frames(images)
+    assert torch.equal(m.video_branch_graphed(images, text, hw, feats), vid)
+    masks = m.video_branch_graphed(images, text, hw, feats, as_masks=True)
+    assert torch.equal(masks.bool(), vid > 0)
+
+
 def test_video_long_cpu(cpu_ops):
     run_long(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
 

@@ -86,3 +86,27 @@ def test_video_branch_long():
         torch.testing.assert_close(trace["maskmem"][t], fxl[f"maskmem_{t}"], rtol=1e-2, atol=2e-3)
     vid9, _ = O.video_branch(sd, "", cfg, imgs[:9], txt, (Hl, Wl))
     torch.testing.assert_close(torch.stack(vid9)[:, :, 0], fxl["video_logits"][:9], **tol)
+
+
+def test_video_branch_no_object():
+    """objects that disappear and come back (tests/golden/sam2_noobj.npz, T = 9, N = 2; presence pattern per frame
+    [[1,0],[0,1],[0,0],[0,0],[1,1],[0,0],[0,0],[1,1],[0,1]]): NO_OBJ_SCORE fill, no_obj_ptr mix, the -1024 mask through the
+    upsample + memory encoder — R/.../sam2_base.py:355-364,390-401, sam2_video_predictor.py:571-612."""
+    fxn = G.fixture("sam2_noobj.npz")
+    Tn, Nn, Hn, Wn = [int(v) for v in fxn["meta"]]
+    sdn = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_noobj_overrides(float(fxn["score_c"]), float(fxn["score_k"])))
+    S = cfg["image_size"]
+    imgs, txt = G.rnd((Tn, 3, S, S), 71), G.rnd((Nn, 256), 72, 0.5)
+    vid, trace = O.video_branch(sdn, "", cfg, imgs, txt, (Hn, Wn))
+    scores = torch.stack([trace["frame0_obj_logits"].view(-1)] + [trace[f"obj_logits_{t}"].view(-1) for t in range(1, Tn)])
+    pres = fxn["obj_scores"] > 0
+    assert pres.any() and (~pres).any() and (pres[:, 0] != pres[:, 1]).any(), "fixture must mix present and absent objects"
+    assert torch.equal(scores > 0, pres)
+    tol = dict(rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(scores, fxn["obj_scores"], rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(trace["low_res"], fxn["low_res"], **tol)
+    assert (trace["low_res"][~pres] == O.NO_OBJ_SCORE).all()
+    torch.testing.assert_close(trace["obj_ptr"], fxn["obj_ptr"], **tol)
+    torch.testing.assert_close(torch.stack(vid)[:, :, 0], fxn["video_logits"], **tol)
+    for t in range(Tn):
+        torch.testing.assert_close(trace["maskmem"][t], fxn[f"maskmem_{t}"], rtol=1e-2, atol=2e-3)

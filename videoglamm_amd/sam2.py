@@ -420,6 +420,7 @@ class SAM2:
             if trace is not None:
                 trace["obj_ptr"].append(o["obj_ptr"])
                 trace["maskmem"].append(non_cond[t]["mem"])
+                trace[f"obj_logits_{t}"] = o["obj_logits"]
             if trace is not None and t == 1:
                 trace["frame1_pix_feat_with_mem"] = pix
                 trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
