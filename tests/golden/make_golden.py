@@ -380,6 +380,52 @@ def build_ref_e2e(use_video_branch):
     return m
 
 
+def _capture_seam(m):
+    """record what crosses the LLM -> SAM2 seam inside the reference's inference(): the [SEG] embeddings handed to the prompt
+    encoder (text_embeds, R/model/VideoGLaMM.py:692-695 / sam2_video_predictor.py:415-495) and the mask logits at output
+    resolution BEFORE the `> 0` (postprocess_masks, VideoGLaMM.py:746-749; propagate_in_video, :869-875)."""
+    cap = dict(emb=[], logits=[])
+    vm = m.model.visual_model
+    vm.sam_prompt_encoder.register_forward_pre_hook(
+        lambda mod, args, kw: cap["emb"].append(kw["text_embeds"].detach().float().reshape(-1, 256).clone()) if kw.get("text_embeds") is not None else None,
+        with_kwargs=True)
+    post = m.model.postprocess_masks
+
+    def post_rec(*a, **k):
+        out = post(*a, **k)
+        cap["logits"].append(out[:, 0].detach().float().clone())
+        return out
+
+    m.model.postprocess_masks = post_rec
+    if hasattr(vm, "propagate_in_video"):
+        prop = vm.propagate_in_video
+
+        def prop_rec(*a, **k):
+            for fidx, oids, logits in prop(*a, **k):
+                cap["logits"].append(logits[:, 0].detach().float().clone())
+                yield fidx, oids, logits
+
+        vm.propagate_in_video = prop_rec
+    return cap
+
+
+def _run_e2e(m, branch, images, context, sam, ids, H, W, S, max_new_tokens, fixtures, key):
+    cap = _capture_seam(m)
+    out_ids, segs = m.inference(images=[images], context_images=[context], images_for_sam=[sam], input_ids=ids,
+                                resize_list=[(S, S)], original_size_list=[(H, W)], max_new_tokens=max_new_tokens,
+                                use_sam2_video_branch=branch)
+    fixtures[f"{key}_output_ids"] = out_ids[0].numpy()
+    seg = segs[0]
+    frames = sorted(seg.keys())
+    objs = sorted(seg[frames[0]].keys()) if frames else []
+    fixtures[f"{key}_masks"] = np.stack([np.stack([seg[t][k] for k in objs]) for t in frames]) if frames else np.zeros((0,))
+    fixtures[f"{key}_seg_emb"] = torch.cat(cap["emb"]).numpy()                       # [N,256]
+    fixtures[f"{key}_logits"] = torch.stack(cap["logits"]).numpy()                  # [T,N,H,W] before the threshold
+    assert fixtures[f"{key}_seg_emb"].shape == (len(objs), 256) and fixtures[f"{key}_logits"].shape[:2] == (len(frames), len(objs))
+    assert np.array_equal(fixtures[f"{key}_logits"] > 0, fixtures[f"{key}_masks"])
+    print(key, "output_ids", out_ids[0].tolist(), "n_seg", len(objs), "mask px", [int(seg[t][k].sum()) for t in frames for k in objs][:8])
+
+
 def gen_e2e():
     from configs import E2E
 
@@ -408,6 +454,7 @@ def gen_e2e():
         assert len(ctower.vision_tower(context[:1], output_hidden_states=True).hidden_states) == E2E["clip"]["num_layers"] + 1
         clip_feats = ctower(context, select_feature="patch")
         ctower.forward = lambda imgs, select_feature="patch", batch_size=128: clip_feats if imgs.shape == context.shape else (_ for _ in ()).throw(RuntimeError("unexpected CLIP input"))
+        key = "video" if branch else "framewise"
         with torch.no_grad():
             # a random LM never emits token 300: pick as [SEG] a token it DOES emit (SURVEY §8c gotcha);
             # the choice is recorded in the fixture so the tests use the same index
@@ -418,17 +465,14 @@ def gen_e2e():
             m.config.seg_token_idx = seg_idx
             fixtures["seg_token_idx"] = np.array(seg_idx)
             print("generated", gen, "-> seg_token_idx", seg_idx)
-            out_ids, segs = m.inference(images=[images], context_images=[context], images_for_sam=[sam], input_ids=ids,
-                                        resize_list=[(S, S)], original_size_list=[(H, W)], max_new_tokens=E2E["max_new_tokens"],
-                                        use_sam2_video_branch=branch)
-        key = "video" if branch else "framewise"
-        fixtures[f"{key}_output_ids"] = out_ids[0].numpy()
-        seg = segs[0]
-        frames = sorted(seg.keys())
-        objs = sorted(seg[frames[0]].keys()) if frames else []
-        fixtures[f"{key}_masks"] = np.stack([np.stack([seg[t][k] for k in objs]) for t in frames]) if frames else np.zeros((0,))
-        print(key, "output_ids", out_ids[0].tolist(), "n_seg", len(objs), "mask px", [int(seg[t][k].sum()) for t in frames for k in objs][:8])
-        fixtures["input_ids"] = ids[0].numpy()
+            _run_e2e(m, branch, images, context, sam, ids, H, W, S, E2E["max_new_tokens"], fixtures, key)
+            fixtures["input_ids"] = ids[0].numpy()
+            # C4's shape: EIGHT [SEG] objects.  seg_token_mask covers the prompt as well (output_ids[:, 1:] == seg_token_idx,
+            # R/model/VideoGLaMM.py:630-633,803-806), so eight [SEG] ids in the prompt's text give eight objects whose embeddings come
+            # from prompt rows (the multi-turn case), plus whatever the model emits on top
+            ids8 = torch.cat([ids[0, :3 + te + 4], torch.full((8,), seg_idx), ids[0, 3 + te + 4:]])[None]
+            _run_e2e(m, branch, images, context, sam, ids8, H, W, S, E2E["max_new_tokens"], fixtures, key + "8")
+            fixtures["input_ids8"] = ids8[0].numpy()
     save("e2e_tiny.npz", **fixtures)
 
 

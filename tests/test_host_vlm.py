@@ -83,23 +83,33 @@ def check_modules(device, tol):
     torch.testing.assert_close(torch.cat(rows).cpu(), ref, **tol)
 
 
-def check_e2e(device, branch):
-    from test_oracle_e2e import e2e_setup
+def check_e2e(device, branch, eight=False):
+    """eight: C4's shape — eight [SEG] ids in the prompt + the six the model emits = 14 objects (fixture keys *8)."""
+    from test_oracle_e2e import check_seam, e2e_setup
     from videoglamm_amd.model import VideoGLaMMForCausalLM
 
     fx, sd, cfg, inp = e2e_setup()
+    key = ("video" if branch else "framewise") + ("8" if eight else "")
+    ids_in = (fx["input_ids8"] if eight else inp["input_ids"]).long()[None]
     m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device)
-    out_ids, segs = m.inference([inp["images"]], [inp["context_images"]], [inp["images_for_sam"]], inp["input_ids"][None],
-                                [(1024, 1024)], [inp["original_size"]], max_new_tokens=inp["max_new_tokens"],
-                                use_sam2_video_branch=branch)
-    key = "video" if branch else "framewise"
-    assert out_ids[0].tolist() == fx[f"{key}_output_ids"].long().tolist()        # token ids bit-exact
-    seg = segs[0]
-    got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
-    ref = fx[f"{key}_masks"].numpy() > 0.5
-    assert got.shape == ref.shape
-    iou = (got & ref).sum() / (got | ref).sum()
-    assert iou > 0.999, iou
+
+    def run():
+        out_ids, segs = m.inference([inp["images"]], [inp["context_images"]], [inp["images_for_sam"]], ids_in,
+                                    [(1024, 1024)], [inp["original_size"]], max_new_tokens=inp["max_new_tokens"],
+                                    use_sam2_video_branch=branch)
+        assert out_ids[0].tolist() == fx[f"{key}_output_ids"].long().tolist()        # token ids bit-exact
+        seg = segs[0]
+        got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
+        ref = fx[f"{key}_masks"].numpy() > 0.5
+        assert got.shape == ref.shape and (not eight or ref.shape[1] >= 8)
+        iou = (got & ref).sum() / (got | ref).sum()
+        assert iou > 0.999, iou
+
+    if device.type == "cuda":
+        run()                   # the product default: masks straight from the low-res logits (vg_bilinear_mask), graph-replayed propagation
+    m.capture = {}              # the same clip with the seam exposed: [SEG] embeddings and logits before the threshold, within 1e-3
+    run()
+    check_seam(fx, key, m.capture["emb"], m.capture["logits"])
 
 
 def check_e2e_min_blob(device):
@@ -215,6 +225,12 @@ def test_e2e_cpu(cpu_ops, branch, monkeypatch):
     check_e2e(torch.device("cpu"), branch)
 
 
+def test_e2e_8_objects_cpu(cpu_ops, monkeypatch):
+    from videoglamm_amd import _lib
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    check_e2e(torch.device("cpu"), False, eight=True)     # (the 14-object video branch on the CPU twins takes minutes: -m gpu only)
+
+
 @pytest.mark.gpu
 def test_modules_hip_fp32(cuda):
     check_modules(cuda, dict(rtol=1e-3, atol=1e-3))
@@ -224,6 +240,14 @@ def test_modules_hip_fp32(cuda):
 @pytest.mark.parametrize("branch", [False, True])
 def test_e2e_hip_fp32(cuda, branch):
     check_e2e(cuda, branch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("branch", [False, True])
+def test_e2e_8_objects_hip_fp32(cuda, branch):
+    """C4's object count on the HIP kernels, both branches, vs the reference's own inference(): ids exact, [SEG] embeddings and
+    mask logits within 1e-3, masks IoU > 0.999."""
+    check_e2e(cuda, branch, eight=True)
 
 
 def check_e2e_image(device):

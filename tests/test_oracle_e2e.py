@@ -25,16 +25,30 @@ def e2e_setup():
     return fx, sd, cfg, inputs
 
 
-def _check(branch):
+SEAM_TOL = dict(rtol=1e-3, atol=1e-3)     # BASELINE.md: mask logits within 1e-3 (fp32), through the LLM -> text_hidden_fcs -> SAM2 seam
+
+
+def check_seam(fx, key, emb, logits):
+    """[SEG] embeddings [N,256] and the mask logits BEFORE the `> 0` vs what the reference's own inference() handed across the seam
+    (make_golden.py:_capture_seam)."""
+    torch.testing.assert_close(emb.float().cpu(), fx[f"{key}_seg_emb"], **SEAM_TOL)
+    torch.testing.assert_close(logits.float().cpu(), fx[f"{key}_logits"], **SEAM_TOL)
+
+
+def _check(branch, eight=False):
     fx, sd, cfg, inputs = e2e_setup()
-    key = "video" if branch else "framewise"
-    ids, seg = pipeline.inference(sd, cfg, use_sam2_video_branch=branch, **inputs)
+    key = ("video" if branch else "framewise") + ("8" if eight else "")
+    if eight:       # C4's shape: eight [SEG] ids in the prompt + the emitted ones = 14 objects
+        inputs = dict(inputs, input_ids=fx["input_ids8"].long())
+    cap = {}
+    ids, seg = pipeline.inference(sd, cfg, use_sam2_video_branch=branch, capture=cap, **inputs)
     assert ids.tolist() == fx[f"{key}_output_ids"].long().tolist()
     ref = fx[f"{key}_masks"].numpy() > 0.5
     got = np.stack([np.stack([seg[t][k] for k in sorted(seg[t])]) for t in sorted(seg)])
-    assert got.shape == ref.shape
+    assert got.shape == ref.shape and (not eight or ref.shape[1] >= 8)
     inter, union = (got & ref).sum(), (got | ref).sum()
     assert inter / union > 0.9995, inter / union  # IoU as R/eval_gcg_metrics.py:26-35
+    check_seam(fx, key, cap["emb"], cap["logits"])
 
 
 def test_e2e_framewise():
@@ -43,6 +57,14 @@ def test_e2e_framewise():
 
 def test_e2e_video_branch():
     _check(True)
+
+
+def test_e2e_framewise_8_objects():
+    _check(False, True)
+
+
+def test_e2e_video_branch_8_objects():
+    _check(True, True)
 
 
 def image_setup():
