@@ -574,6 +574,24 @@ def gen_host():
         c.append_message(c.roles[0], "<image>" * 4 + "\n" + "Please segment the red car .")
         c.append_message(c.roles[1], "")
         out[f"ids_{key}"] = tokenizer_image_token(c.get_prompt(), tok, return_tensors="pt").numpy()
+    # CLIP stream of H1: the reference's own EncPreprocessor_VideoGPTPlus.preprocess (R/utils/enc_preprocessors.py:120-166) with the
+    # processor it would fetch from the hub ("openai/clip-vit-large-patch14-336": no network here) constructed offline from that
+    # checkpoint's published preprocessor_config.json values (size 336 shortest edge, bicubic = resample 3, centre crop 336, CLIP mean /
+    # std), and the cv2-based InternVideo2 processor (cv2 absent) replaced by an empty stand-in: only "context_images" is taken
+    from transformers import CLIPImageProcessor
+    from utils.enc_preprocessors import EncPreprocessor_VideoGPTPlus
+    enc = EncPreprocessor_VideoGPTPlus.__new__(EncPreprocessor_VideoGPTPlus)
+    enc.num_frames, enc.frame_resolution_iv, enc.frame_resolution_clip = 4, 224, 336
+    enc.image_processor = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}, do_resize=True, do_center_crop=True,
+                                             do_normalize=True, do_rescale=True, do_convert_rgb=True, resample=3,
+                                             image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711])
+    enc.video_processor = type("NoIV2", (), {"preprocess": staticmethod(lambda frames: {"pixel_values": []})})()
+    clip_frames = [g.randint(0, 256, size=s).astype(np.uint8) for s in ((60, 80, 3), (500, 400, 3), (336, 336, 3))]   # up-, down-scaling, identity
+    ctx = enc.preprocess(list(clip_frames))["context_images"]
+    assert len(ctx) == 4 and torch.equal(ctx[2], ctx[3])                           # three frames padded to num_frames by repeating the last
+    out["clip_pre_sub"] = torch.stack(ctx)[:, :, ::7, ::7]
+    out["clip_pre_mean"] = torch.stack(ctx).mean(dim=(2, 3))
+    out["clip_pre_patch"] = torch.stack(ctx)[:, :, 100:132, 200:232]
     save("host_rows.npz", **out)
 
 

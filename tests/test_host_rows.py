@@ -30,6 +30,22 @@ def test_sam_preprocess_matches_reference():
     torch.testing.assert_close(x.mean(dim=(1, 2)), fx["sam_pre_mean"], rtol=1e-5, atol=1e-5)
 
 
+def test_clip_preprocess_matches_reference():
+    """CLIP stream of H1 vs the reference's EncPreprocessor_VideoGPTPlus.preprocess run on transformers' CLIPImageProcessor
+    (constructed offline with the hub checkpoint's preprocessor values, make_golden.py:gen_host): up-scaling, down-scaling with a
+    centre crop on both axes, identity, pad-by-repeat to num_frames.  1e-6: fp32 rounding of (x/255 - mean)/std only."""
+    fx = G.fixture("host_rows.npz")
+    g = np.random.RandomState(7)
+    g.randint(0, 256, size=(60, 80, 3))                                   # (the SAM frame drawn first by the generator)
+    frames = [g.randint(0, 256, size=s).astype(np.uint8) for s in ((60, 80, 3), (500, 400, 3), (336, 336, 3))]
+    ctx = torch.stack([host.clip_preprocess(f) for f in host.pad_or_truncate(frames, 4)])
+    assert ctx.shape == (4, 3, 336, 336)
+    tol = dict(rtol=0, atol=1e-6)
+    torch.testing.assert_close(ctx[:, :, ::7, ::7], fx["clip_pre_sub"], **tol)
+    torch.testing.assert_close(ctx[:, :, 100:132, 200:232], fx["clip_pre_patch"], **tol)
+    torch.testing.assert_close(ctx.mean(dim=(2, 3)), fx["clip_pre_mean"], rtol=0, atol=1e-6)
+
+
 def test_prompt_and_image_tokens_match_reference():
     fx = G.fixture("host_rows.npz")
     tok = ToyTokenizer()
