@@ -106,7 +106,8 @@ def test_config_ids_are_live_and_refusals(tmp_path, cpu_ops, monkeypatch):
 
 
 def test_eos_id_sets(tmp_path):
-    """config.json + generation_config.json EOS ids are merged (HF generate stops on any of them)"""
+    """HF generate()'s precedence: generation_config.json's eos ids when that file names them (config.json's are then not consulted, and
+    a later assignment on model.config is ignored), config.json's otherwise (and then an assignment on model.config replaces them)"""
     import json
     from videoglamm_amd import ingest
     assert ingest.eos_ids(2, [32000, 32001, 32007], None) == [2, 32000, 32001, 32007]
@@ -118,4 +119,16 @@ def test_eos_id_sets(tmp_path):
     json.dump(hf, open(model_dir / "config.json", "w"))
     json.dump({"eos_token_id": [7, 9]}, open(model_dir / "generation_config.json", "w"))
     got, hf2 = ingest.load_state_dict(str(model_dir), sam2_checkpoint=str(tmp_path / "sam2_hiera.pt"))
-    assert ingest.derive_config(got, hf2, seg_token_idx=300)["eos_token_id"] == [2, 7, 9]
+    c = ingest.derive_config(got, hf2, seg_token_idx=300)
+    assert c["eos_token_id"] == [7, 9] and c["eos_from_generation_config"]
+    hf2.pop("_generation_eos_token_id")
+    c2 = ingest.derive_config(got, hf2, seg_token_idx=300)
+    assert c2["eos_token_id"] == [2] and not c2["eos_from_generation_config"]
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+    m = VideoGLaMMForCausalLM.__new__(VideoGLaMMForCausalLM)
+    m.cfg, m.config = c, type("C", (), {"eos_token_id": 5})()
+    assert m._eos() == [7, 9]
+    m.cfg = c2
+    assert m._eos() == [5]
+    m.config.eos_token_id = None
+    assert m._eos() == [2]

@@ -34,14 +34,18 @@ def _worker(rank, world, port, q):
     T, N, hw = 4, 2, (40, 56)
     images = G.rnd((T, 3, 256, 256), 11)
     text = G.rnd((N, 256), 12, 0.5)
-    comm = FrameSharder(gather_masks=True)
+    comm = FrameSharder()                           # default = the reference's contract: every rank returns the whole clip
+    assert comm.gather_masks is True
     assert comm.my_frames(T) == [2 * rank, 2 * rank + 1]
     # a rank-dependent perturbation must be overwritten by rank 0's copy
     emb = comm.sync_seg_embeddings(text + 0.01 * rank)
     assert torch.equal(emb, text)
     masks, fids = comm.framewise(m, images, text + 0.01 * rank, hw)
     assert fids == [0, 1, 2, 3]
-    shard = FrameSharder()                          # default: no mask collective, every rank keeps its own frames / objects
+    shard = FrameSharder(gather_masks=False)        # explicit opt-in: no mask collective, every rank keeps its own frames / objects
+    r0 = FrameSharder(gather_masks="rank0")         # rank 0 (the rank a caller reads) gets the whole clip, the others their own frames
+    m0, f0 = r0.framewise(m, images, text, hw)
+    assert (f0 == [0, 1, 2, 3] and torch.equal(m0, masks)) if rank == 0 else (f0 == [2, 3] and torch.equal(m0, masks[2:4]))
     local, lf = shard.framewise(m, images, text, hw)
     assert lf == [2 * rank, 2 * rank + 1] and torch.equal(local, masks[2 * rank:2 * rank + 2])
     feats = comm.hiera_all_frames(m, images)
@@ -59,6 +63,10 @@ def _worker(rank, world, port, q):
     masks1, _ = comm.framewise(m, images[:1], text, hw)
     l1, lf1 = shard.framewise(m, images[:1], text, hw)
     assert lf1 == ([0] if rank == 0 else []) and l1.shape[0] == len(lf1)
+    # T < world in the video branch: rank 1 owns no frame and joins the feature all-gather with an empty block (shapes from the config)
+    feats1 = comm.hiera_all_frames(m, images[:1])
+    assert sorted(feats1) == [0] and [tuple(f.shape) for f in feats1[0]] == [(1, 64, 64, 32), (1, 32, 32, 64), (1, 16, 16, 256)]
+    assert all(torch.equal(a, b) for a, b in zip(feats1[0], feats[0]))
     # vision towers sharded by CLIP frame / InternVideo2 chunk (Te = 4: one chunk -> rank 1 has none; two frames each)
     from test_oracle_e2e import e2e_setup
     from videoglamm_amd.vlm import VisionTowers

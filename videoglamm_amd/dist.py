@@ -11,9 +11,12 @@ What shards naturally and what does not:
   * The two vision towers are independent per CLIP frame / per 4-frame InternVideo2 chunk: each rank encodes and
     projects its block of frames / chunks, the projected, pooled tokens (a few MB) are all-gathered, so the replicated LLM
     sees identical visual tokens everywhere and the towers cost 1/world of a clip instead of a whole one per rank.
-  * Results: every rank returns the masks of ITS frames (framewise) / ITS objects (video branch) under their global indices —
-    no data-path collective; FrameSharder(gather_masks=True) all-gathers the uint8 masks so that every rank holds the whole clip
-    (33.5 MB per 32 frames at 1024^2: the host copy of an N-times larger result on every rank is what breaks weak scaling).
+  * Results: gather_masks=True (default = the reference's contract: inference() returns the whole clip's video_segments) all-gathers
+    the uint8 masks on the devices and every rank copies the whole clip to its host; "rank0": the same device all-gather, but only
+    rank 0 — the rank a caller reads — pays the host copy of the whole clip, the others keep their own frames / objects; False
+    (explicit opt-in, bench.py --scaling weak): no data-path collective, every rank returns the masks of ITS frames (framewise) /
+    ITS objects (video branch) under their global indices (33.5 MB per 32 frames at 1024^2: the host copy of an N-times larger
+    result on every rank is what breaks weak scaling).
   * Video-branch propagation is a recurrence over frames (memory of t-1..t-6), so frames do not shard there — OBJECTS do
     (non_overlap_masks_for_mem_enc is unset: objects never interact, R/.../sam2_video_predictor.py:571-612): the per-frame Hiera
     features are all-gathered (8.4 MB bf16 per frame at SAM2-L), rank r propagates its block of the N [SEG] objects and the
@@ -21,6 +24,8 @@ What shards naturally and what does not:
 Frame / object counts need not divide by the world size: blocks differ by at most one unit and every collective is padded
 to the largest block.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,8 +33,9 @@ from . import ops
 
 
 class FrameSharder:
-    def __init__(self, group=None, gather_masks=False):
+    def __init__(self, group=None, gather_masks=True):
         assert dist.is_initialized(), "init torch.distributed first (torchrun: one process per GPU)"
+        assert gather_masks in (True, False, "rank0")
         self.group = group
         self.gather_masks = gather_masks
         self.rank = dist.get_rank(group)
@@ -77,9 +83,21 @@ class FrameSharder:
         return torch.cat([parts[r][:counts[r] * rows_per_unit] for r in range(self.world) if counts[r]], dim=0)
 
     def _all_gather(self, t):
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # plumbing runs with several ranks on ONE GPU (VG_DIST_BACKEND=gloo; tests/test_dist_hip.py): gloo moves host memory
+            host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+            dist.all_gather(host, t.contiguous().cpu(), group=self.group)
+            return [h.to(t.device) for h in host]
         bufs = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(bufs, t.contiguous(), group=self.group)
         return bufs
+
+    def all_gather_into(self, recv, send):
+        """recv [world * m, ...] <- every rank's send [m, ...], in rank order."""
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            recv.copy_(torch.cat(self._all_gather(send), dim=0))
+        else:
+            dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)
 
     def sync_seg_embeddings(self, emb):
         """all-gather of the [N,256] [SEG] embeddings; every rank adopts rank 0's copy."""
@@ -98,9 +116,11 @@ class FrameSharder:
         if frames:
             out, _ = sam2.framewise_branch(images_for_sam, emb, hw, frames=frames, frame_feats=frame_feats, as_masks=binarize is None)
             local = out if binarize is None else binarize(out)             # [frames of this rank, N, H, W] uint8, on device
+        mine = (local if local is not None else torch.zeros((0, N) + tuple(hw), dtype=torch.uint8, device=emb.device)), frames
         if not self.gather_masks:
-            return (local if local is not None else torch.zeros((0, N) + tuple(hw), dtype=torch.uint8, device=emb.device)), frames
-        return self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(T))
+            return mine
+        full = self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(T))
+        return full if (self.gather_masks is True or self.rank == 0) else mine
 
     def video_branch_objects(self, sam2, images_for_sam, emb, hw, frame_feats, binarize=None, **kw):
         """object-sharded SAM2 propagation: every rank holds the Hiera features of ALL frames (gather_frame_feats) and runs the
@@ -108,32 +128,43 @@ class FrameSharder:
         indices): this rank's objects, or all N (all-gathered along the object axis) when gather_masks is set.  With fewer objects
         than ranks the surplus ranks hold none; N = 1: replicas only — every rank propagates the single object (no exchange)."""
         T, N = images_for_sam.shape[0], emb.shape[0]
+
+        def propagate(e):
+            # the same launch sequence as the single-GPU path (model.inference_video_branch): replayed from a HIP graph unless
+            # VG_VIDEO_GRAPH=0 (the graph key includes the number of objects, so per-rank object blocks get their own capture)
+            if emb.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "1") == "1" and not kw:
+                return sam2.video_branch_graphed(images_for_sam, e, hw, frame_feats, as_masks=binarize is None)
+            return sam2.video_branch(images_for_sam, e, hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
+
         if N == 1:
-            out = sam2.video_branch(images_for_sam, emb, hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
+            out = propagate(emb)
             return (out if binarize is None else binarize(out)), [0]
         o0, on = self.block(N)
         local = None
         if on:
-            out = sam2.video_branch(images_for_sam, emb[o0:o0 + on], hw, frame_feats=frame_feats, as_masks=binarize is None, **kw)
+            out = propagate(emb[o0:o0 + on])
             local = out if binarize is None else binarize(out)             # [T, objects of this rank, H, W]
+        mine = (local if local is not None else torch.zeros((T, 0) + tuple(hw), dtype=torch.uint8, device=emb.device)), list(range(o0, o0 + on))
         if not self.gather_masks:
-            return (local if local is not None else torch.zeros((T, 0) + tuple(hw), dtype=torch.uint8, device=emb.device)), list(range(o0, o0 + on))
-        return self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(N))
+            return mine
+        full = self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(N))
+        return full if (self.gather_masks is True or self.rank == 0) else mine
 
-    def gather_frame_feats(self, local_feats, T):
-        """all-gather per-frame FPN features ({frame: [3 levels]} of this rank's frames) -> the same for all T frames."""
+    def gather_frame_feats(self, local_feats, T, sam2):
+        """all-gather per-frame FPN features ({frame: [3 levels]} of this rank's frames) -> the same for all T frames.
+        The level shapes come from the SAM2 configuration (forward_image: [S/4,S/4,32], [S/8,S/8,64], [S/16,S/16,256]), not from
+        a local frame, so a rank without frames (T < world size) takes part in the collective with an empty block."""
         frames = self.my_frames(T)
-        ref = next(iter(local_feats.values())) if local_feats else None
+        S = sam2.S
+        level_shapes = [(S // 4, S // 4, 32), (S // 8, S // 8, 64), (S // 16, S // 16, 256)]
         levels = []
         for lv in range(3):
             stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0) if frames else None      # [frames of this rank, h, w, c]
-            if ref is None:
-                raise ValueError("gather_frame_feats: a rank without frames cannot describe the feature shapes (T < world size)")
-            shape = (T,) + tuple(ref[lv].shape[1:])
-            levels.append(self.gather_blocks(stacked, T, 0, shape, ref[lv].dtype, ref[lv].device))
+            assert stacked is None or tuple(stacked.shape[1:]) == level_shapes[lv], (tuple(stacked.shape), level_shapes[lv])
+            levels.append(self.gather_blocks(stacked, T, 0, (T,) + level_shapes[lv], sam2.dtype, sam2.device))
         return {t: [levels[lv][t:t + 1] for lv in range(3)] for t in range(T)}
 
     def hiera_all_frames(self, sam2, images_for_sam):
         """frame-sharded Hiera + FPN, features all-gathered level by level -> {frame: fpn levels}."""
         T = images_for_sam.shape[0]
-        return self.gather_frame_feats(sam2.hiera_frames(images_for_sam, self.my_frames(T)), T)
+        return self.gather_frame_feats(sam2.hiera_frames(images_for_sam, self.my_frames(T)), T, sam2)

@@ -81,12 +81,14 @@ def load_state_dict(model_dir, vision_tower=None, image_vision_tower=None, sam2_
         iv2 = {k: v for k, v in _read_any(vision_tower).items() if k.startswith("vision_encoder.")}
         if not iv2:
             raise KeyError(f"{vision_tower}: no vision_encoder.* tensors")
-        pe = iv2.get("vision_encoder.pos_embed")
-        if pe is not None and iv2_origin_num_frames and int(iv2_origin_num_frames) != 4:
-            side = iv2["vision_encoder.patch_embed.proj.weight"].shape[-1]
-            grid = int(round(((pe.shape[1] - 1) // int(iv2_origin_num_frames)) ** 0.5))
-            iv2["vision_encoder.pos_embed"] = interpolate_iv2_pos_embed(pe, int(iv2_origin_num_frames), 4, grid)
-            del side
+        origin = iv2_origin_num_frames if iv2_origin_num_frames is not None else (hf or {}).get("iv2_origin_num_frames")
+        if origin and int(origin) != 4:
+            # every *pos_embed / clip_pos_embed tensor but img_pos_embed, like interpolate_pos_embed_internvideo2_new's key loop
+            # (pos_embed.py:248-252); time only: the patch grid of the checkpoint is the model's (224 / 14 = 16 per side)
+            for k in [k for k in iv2 if "pos_embed" in k and "img_pos_embed" not in k]:
+                pe = iv2[k]
+                grid = int(round(((pe.shape[1] - 1) // int(origin)) ** 0.5))
+                iv2[k] = interpolate_iv2_pos_embed(pe, int(origin), 4, grid)
         sd.update({"model.vision_tower." + k: v for k, v in iv2.items()})
     if not any(k.startswith(CLIP_PREFIX) for k in sd):
         image_vision_tower = image_vision_tower or (hf or {}).get("image_mm_vision_tower")
@@ -246,9 +248,12 @@ def derive_config(sd, hf=None, seg_token_idx=None):
     if seg_token_idx is None:
         seg_token_idx = hf.get("seg_token_idx", emb.shape[0] - 1)     # "[SEG]" is the last added token (R/chat.py:297-300)
     cfg = dict(seg_token_idx=int(seg_token_idx), iv2=iv2, clip=clip, llm=llm, sam2=sam2, projector_depth=depth)
-    eos = eos_ids(hf.get("eos_token_id"), hf.get("_generation_eos_token_id"))
+    # HF generate() stops on generation_config.json's eos ids when that file has them, on config.json's otherwise
+    gen_eos = eos_ids(hf.get("_generation_eos_token_id"))
+    eos = gen_eos or eos_ids(hf.get("eos_token_id"))
     if eos:
-        cfg["eos_token_id"] = eos     # every id HF's generate() would stop on (config.json + generation_config.json)
+        cfg["eos_token_id"] = eos
+        cfg["eos_from_generation_config"] = bool(gen_eos)
     for k in ("bos_token_id", "pad_token_id"):
         if hf.get(k) is not None:
             cfg[k] = hf[k]

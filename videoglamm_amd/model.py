@@ -104,7 +104,7 @@ class VideoGLaMMForCausalLM:
 
     @classmethod
     def from_pretrained(cls, path, config=None, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None,
-                        seg_token_idx=None, lora_dir=None, **kwargs):
+                        seg_token_idx=None, lora_dir=None, iv2_origin_num_frames=None, **kwargs):
         """The released artefact layout (R/chat.py:277-319): an HF directory (*.safetensors or pytorch_model*.bin shards +
         config.json) with the LLM, the projectors, text_hidden_fcs and SAM2; the InternVideo2 .pt and the CLIP directory
         the config names under mm_vision_tower / image_mm_vision_tower (or given here); optionally a stand-alone SAM2
@@ -112,7 +112,8 @@ class VideoGLaMMForCausalLM:
         `config` — or a "videoglamm_amd" section in config.json — gives it explicitly."""
         from . import ingest
 
-        sd, hf = ingest.load_state_dict(path, vision_tower, image_vision_tower, sam2_checkpoint, lora_dir=lora_dir)
+        sd, hf = ingest.load_state_dict(path, vision_tower, image_vision_tower, sam2_checkpoint, lora_dir=lora_dir,
+                                        iv2_origin_num_frames=iv2_origin_num_frames)
         if config is None:
             config = (hf or {}).get("videoglamm_amd") or ingest.derive_config(sd, hf, seg_token_idx)
         return cls(sd, config, **kwargs)
@@ -191,9 +192,14 @@ class VideoGLaMMForCausalLM:
         return c if seg == c["seg_token_idx"] else dict(c, seg_token_idx=seg)
 
     def _eos(self):
-        """ids generation stops on: the checkpoint's (config.json + generation_config.json) and model.config.eos_token_id."""
+        """ids generation stops on, with HF generate()'s precedence (transformers 4.41 GenerationMixin._prepare_generation_config): a
+        generation_config.json that names eos ids wins; without one the generation config is derived from model.config, so ids the
+        caller assigned on model.config.eos_token_id after load (R/chat.py:305-307) REPLACE the checkpoint's config.json ids."""
         from .ingest import eos_ids
-        return eos_ids(self.cfg.get("eos_token_id"), getattr(self.config, "eos_token_id", None)) or None
+        live = getattr(self.config, "eos_token_id", None)
+        if self.cfg.get("eos_from_generation_config") or live is None:
+            return eos_ids(self.cfg.get("eos_token_id")) or None
+        return eos_ids(live) or None
 
     # ------------------------------------------------------------------ forward surface
     def forward(self, **kwargs):
@@ -353,7 +359,7 @@ class VideoGLaMMForCausalLM:
         if self.comm is not None:
             # frames shard for Hiera only (the propagation is a recurrence over frames); OBJECTS shard for the propagation
             emb = self.comm.sync_seg_embeddings(emb)
-            feats = self.comm.gather_frame_feats(feats, sam.shape[0])
+            feats = self.comm.gather_frame_feats(feats, sam.shape[0], self.sam2)
             masks, oids = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
             return out_ids, [self._segments(self._to_host(masks), obj_ids=oids)]
         if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "1") == "1":

@@ -301,8 +301,6 @@ class LlamaDecoder:
         row attends causally to the keys [0, its position].  The projections of a row do not depend on the other rows, so the
         prefill costs 1/world per rank (plus one weight pass) instead of a whole one on every rank; the final-norm rows are
         all-gathered at the end (the replicated decode continues from the last one)."""
-        import torch.distributed as dist
-
         c = self.c
         S, W, r = x.shape[0], comm.world, comm.rank
         m = -(-S // W)
@@ -316,7 +314,7 @@ class LlamaDecoder:
             if n:
                 send[:n, 0].copy_(self.kc[i][a:a + n])
                 send[:n, 1].copy_(self.vc[i][a:a + n])
-            dist.all_gather(list(recv.chunk(W)), send, group=comm.group)
+            comm.all_gather_into(recv, send)
             self.kc[i][:W * m].copy_(recv[:, 0])        # rows >= S are padding: never read, overwritten by the decode appends
             self.vc[i][:W * m].copy_(recv[:, 1])
 
@@ -329,7 +327,7 @@ class LlamaDecoder:
         # every rank gets every final-norm row: the decode continues from the last one, and [SEG] tokens that sit INSIDE the prompt
         # (multi-turn) take their hidden state from prompt rows (S x D elements once per clip: 14 MB at S = 1697)
         hrecv = torch.empty(W * m, self.D, dtype=x.dtype, device=x.device)
-        dist.all_gather(list(hrecv.chunk(W)), hsend, group=comm.group)
+        comm.all_gather_into(hrecv, hsend)
         self.hid_all[:W * m].copy_(hrecv)
         last = self.hid_all[S - 1:S].clone()
         self.pos = S
