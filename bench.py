@@ -11,8 +11,12 @@ dual vision encoders -> V-L adapters -> Llama-3-8B prefill + 32 greedy decode st
 -> L-V adapter -> SAM2-L (Hiera + FPN + mask decoder) over every frame.
 Workload at N=1 = BASELINE config C2, the configuration BASELINE.json's metric is quoted on (32-frame 1024^2 clip
 -> 32 x 1024^2 SAM frames, masks returned at 1024^2, Te=16 encoder frames -> 3361-row prompt, Llama-3-8B bf16,
-InternVideo2-1B, CLIP-L/336, SAM2-L, one [SEG] object).  N>1: weak scaling, 32 SAM frames per rank (clip of 32N frames,
-frames sharded, LLM replicated, RCCL all-gather of the [SEG] embedding; every rank keeps the masks of its frames on its host).
+InternVideo2-1B, CLIP-L/336, SAM2-L, one [SEG] object).  N>1 (default --scaling strong) = BASELINE config C3: the SAME 32-frame clip,
+frames sharded N-way for Hiera + the mask decode, the vision towers sharded by frame / chunk and the LLM prefill by rows
+(--replicate-llm switches both off: then every rank emits the single-GPU ids by construction), the decode loop replicated, RCCL
+all-gather of the [SEG] embedding; the masks are all-gathered on the devices and rank 0 — the rank a caller reads — returns the
+whole clip (the reference's contract).  --scaling weak: 32 SAM frames PER RANK (clip of 32N frames), LLM side replicated, every
+rank keeps the masks of its own frames (no data-path collective).
 Weights are random-init of the exact architectures (no network / no public Llama VideoGLaMM checkpoint).
 The line is self-checking ("quality"): after the timed region the same clip is re-run ONCE in fp32 parity mode on the
 GPU (same bf16-rounded weights, teacher-forced to the bf16 run's ids) and the bf16 masks / argmaxes are compared with it.
@@ -37,7 +41,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--branch", default="framewise", choices=["framewise", "video"],
                     help="framewise = the reference's default path (chat.py without --use_sam2_video_branch)")
-    ap.add_argument("--frames-per-gpu", type=int, default=32)
+    ap.add_argument("--frames", "--frames-per-gpu", dest="frames", type=int, default=32,
+                    help="SAM frames of the clip (strong scaling: of the whole clip; --scaling weak: per rank)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = BASELINE config C3 (the same clip sharded N-way, default); weak = --frames per rank")
+    ap.add_argument("--replicate-llm", action="store_true",
+                    help="N > 1, strong scaling: keep the vision towers and the LLM prefill replicated on every rank (ids == single-GPU ids by construction)")
     ap.add_argument("--te", type=int, default=16, help="encoder frames (NUM_FRAMES; the reference's default 16)")
     ap.add_argument("--src", type=int, default=1024, help="source (output mask) resolution")
     ap.add_argument("--max-new-tokens", type=int, default=32)
@@ -59,7 +68,7 @@ def parse():
 
 def make_inputs(cfg, args, world, device):
     g = torch.Generator().manual_seed(1234)
-    te, T = args.te, args.frames_per_gpu * world
+    te, T = args.te, args.frames * (world if args.scaling == "weak" else 1)
     S = cfg["sam2"]["image_size"]
     iv, cl = cfg["iv2"]["img_size"], cfg["clip"]["img_size"]
     images = torch.randn(te, 3, iv, iv, generator=g).to(device)
@@ -281,7 +290,7 @@ def meter_decode_gemv(model, ops, reps=3):
         return None
     return rec[0][2], [1e3 * a.elapsed_time(b) for a, b, _ in rec]
 
-PMC_TAG = "r02_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
+PMC_TAG = "r03_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
 
 
 def quality(cfg, args, model, step, device):
@@ -389,7 +398,7 @@ def cpu_baseline(cfg, args):
     ovlm.llama_forward(sdl, pl, dict(c, num_layers=1), x)
     t_layer = time.time() - t0
     del sdl
-    T, G, L = args.frames_per_gpu, args.max_new_tokens, c["num_layers"]
+    T, G, L = args.frames, args.max_new_tokens, c["num_layers"]
     t_vision = T * t_sam + args.te * t_clip + args.te * t_iv2
     t_llm = (G + 1) * L * t_layer                     # G + 1 full re-forwards of the sequence, L layers each
     return dict(value=round(T / (t_vision + t_llm), 5), unit="frames/sec", cores=cores, kind="port",
@@ -422,7 +431,11 @@ def main():
         else:
             dist.init_process_group(backend)
         from videoglamm_amd.dist import FrameSharder
-        comm = FrameSharder()
+        # strong scaling (C3): rank 0 returns the whole clip like the reference's inference(); weak scaling: explicit opt-out of the mask exchange
+        comm = FrameSharder(gather_masks="rank0" if args.scaling == "strong" else False)
+        if args.scaling == "strong" and not args.replicate_llm:
+            os.environ.setdefault("VG_TOWERS_SHARDED", "1")
+            os.environ.setdefault("VG_PREFILL_SHARDED", "1")
 
     from videoglamm_amd import ops, synth
     from videoglamm_amd.model import VideoGLaMMForCausalLM
@@ -475,8 +488,23 @@ def main():
         dt = float(tt[0])
     out_ids, segs = out
     n_obj = len(next(iter(segs[0].values()))) if segs[0] else 0      # (a rank's dict holds ITS frames under their global indices)
-    name = "C1" if (args.frames_per_gpu, args.src, args.objects, args.te) == (8, 512, 1, 8) else "C2" if (args.frames_per_gpu, args.src, args.objects, args.te) == (32, 1024, 1, 16) \
-        else "C4 share of one GPU (64 frames / 8)" if (args.frames_per_gpu, args.src, args.objects) == (8, 1024, 8) else "custom"
+    shape = (args.frames, args.src, args.objects, args.te)
+    strong = args.scaling == "strong"
+    name = "C1" if shape == (8, 512, 1, 8) else ("C2" if world == 1 or not strong else f"C3 (C2's clip sharded {world}-way)") if shape == (32, 1024, 1, 16) \
+        else "C4 share of one GPU (64 frames / 8)" if (args.frames, args.src, args.objects, world) == (8, 1024, 8, 1) \
+        else "C4 clip (64 frames, 8 [SEG])" if (args.frames, args.src, args.objects) == (64, 1024, 8) and strong else "custom"
+    llm_sharded = world > 1 and os.environ.get("VG_TOWERS_SHARDED", "0") == "1" and os.environ.get("VG_PREFILL_SHARDED", "0") == "1"
+    if world == 1:
+        par = "1 GPU"
+    elif strong:
+        par = (f"one clip over {world} GPUs: SAM frames sharded (Hiera + FPN, mask decode"
+               + ("; video branch: objects sharded for the propagation, FPN features all-gathered" if use_video else "") + "), "
+               + ("vision towers sharded by frame / chunk + sequence-parallel LLM prefill (a rank's row chunks take other GEMM tile routes: "
+                  "bf16 ids can differ from the single-GPU run on near-ties; --replicate-llm restores id equality by construction)" if llm_sharded
+                  else "vision towers + LLM prefill replicated (ids == single-GPU ids by construction)")
+               + ", decode loop replicated, [SEG] embedding all-gathered, masks all-gathered on the devices and returned whole by rank 0")
+    else:
+        par = f"weak scaling: {args.frames} frames per rank sharded x{world} (masks stay with the rank that made them: gather_masks=False), LLM side replicated"
     if args.llm != "llama3-8b":
         name += " with the Phi-3-mini LLM"
     if args.decode_weights == "fp8" or args.prefill == "fp8":
@@ -484,14 +512,15 @@ def main():
     res = {
         "metric": "frames/sec end-to-end (text+masks)", "value": round(T * args.steps / dt, 3), "unit": "frames/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
         "dtype": "bf16" if (args.decode_weights, args.prefill) == ("bf16", "bf16") else
                  f"bf16 model; LLM prefill GEMMs {args.prefill}, decode-step MLP / lm_head weights {args.decode_weights} (e4m3, row scales)", "data": "synthetic",
-        "config": {"workload": f"{name}: {args.frames_per_gpu}-frame {args.src}^2-source clip per GPU ({T} x 1024^2 SAM frames total), "
+        "config": {"workload": f"{name}: {T}-frame {args.src}^2-source clip ({T} x 1024^2 SAM frames over {world} GPU(s)), "
                                f"Te={args.te}, {'Llama-3-8B' if args.llm == 'llama3-8b' else 'Phi-3-mini'} bf16 + InternVideo2-1B + CLIP-L/336 + SAM2-L, {n_obj} [SEG] object(s), "
                                f"{args.max_new_tokens} greedy tokens, {args.branch} SAM2 branch" + (" [TINY plumbing config]" if args.tiny else ""),
                    "frames": T, "encoder_frames": args.te, "generated_tokens": int(out_ids.shape[1] - ids.shape[1]),
-                   "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": f"frames sharded x{world} (masks stay with the rank that made them), LLM replicated",
+                   "seq_len": 208 * args.te + ids.shape[1] - args.te, "parallelism": par,
+                   "masks_returned": "whole clip" if world == 1 else ("whole clip on rank 0 (gather_masks='rank0')" if strong else "each rank its own frames (gather_masks=False)"),
                    "weights": "random-init (synthetic)"},
         "load_s": round(t_load, 1),
     }
@@ -509,12 +538,29 @@ def main():
             #             and a hipMalloc between an event pair's records would be billed to the launch it brackets
             with GemmMeter(ops) as gm, DecodeMeter() as dm, AttnMeter(ops) as am:
                 step()
+            # per-stage split of one more serial pass (device sync + host clock between the stages): which stages shard with N and
+            # which are replicated on every rank — the Amdahl term of the strong-scaling configuration
+            model.stages = []
+            step()
+            marks, model.stages = model.stages, None
         finally:
             for k, v in prev.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+        dur = {b[0]: 1e3 * (b[1] - a[1]) for a, b in zip(marks, marks[1:]) if b[0] not in ("start", "begin")}
+        if world > 1:      # a stage takes as long as its slowest rank
+            tt = torch.tensor([dur[k] for k in sorted(dur)], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dur = dict(zip(sorted(dur), tt.tolist()))
+        shards = {"hiera_fpn": world > 1, "towers": llm_sharded, "prefill": llm_sharded, "decode": False, "mask_decode": world > 1,
+                  "feature_all_gather": False, "propagation": world > 1 and args.objects > 1}
+        res["stages"] = {"note": "one extra pass with the streams serialised and a device sync between the stages (outside the timed region; max over ranks): "
+                                 "ms per stage on a rank and whether the stage's work divides by the number of GPUs (sharded) or is repeated on every rank",
+                         **{k: {"ms": round(v, 2), "sharded": bool(shards.get(k, False))} for k, v in dur.items()},
+                         "replicated_ms": round(sum(v for k, v in dur.items() if not shards.get(k, False)), 2),
+                         "sharded_ms": round(sum(v for k, v in dur.items() if shards.get(k, False)), 2)}
         dec_ms, dec_n = dm.summary()
         if os.environ.get("VG_BENCH_GEMM_SHAPES"):
             torch.cuda.synchronize()
@@ -530,7 +576,7 @@ def main():
         peak = 2500.0
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, committed summaries made by
         # tools/collect_profiles.sh + tools/pmc_json.py): only quoted for the workload they were measured on (C2 framewise, 1 GPU)
-        pmc_ok = (world == 1 and not args.tiny and args.branch == "framewise" and (args.frames_per_gpu, args.te, args.src, args.objects) == (32, 16, 1024, 1)
+        pmc_ok = (world == 1 and not args.tiny and args.branch == "framewise" and (args.frames, args.te, args.src, args.objects) == (32, 16, 1024, 1)
                   and args.llm == "llama3-8b" and (args.decode_weights, args.prefill) == ("bf16", "bf16"))
 
         def traffic_of(key):
@@ -540,15 +586,37 @@ def main():
                     return round(json.load(fh)["traffic_bytes_per_launch"])
             return None
 
+        def trace_of(key, mode):
+            """per-launch average of this kernel class in the committed rocprofv3 kernel trace of the same command (tools/collect_profiles.sh +
+            tools/kt_json.py): mode "overlapped" = the timed configuration (Hiera on its side stream), "serial" = the configuration of the
+            instrumented pass the live `frac` is measured in."""
+            path = os.path.join(ROOT, "profiles", f"{PMC_TAG}_kt_{mode}.json")
+            if pmc_ok and key and os.path.exists(path):
+                with open(path) as fh:
+                    return json.load(fh)["kernels"].get(key)
+            return None
+
         def roof(kernel, label, scope=None, key=None):
             flops, ms, n, nbytes = gm.summary(kernel, scope)
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            return {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(key) if key else None,
-                    "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
-                    "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
-                    "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
-                    "kernel_ms_per_step": round(ms, 2)}
+            r = {"bound": "mfma", "kernel": label, "achieved": round(ach, 1), "peak": peak,
+                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(key) if key else None,
+                 "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
+                 "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
+                 "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                 "kernel_ms_per_step": round(ms, 2),
+                 "frac_serial": round(ach / peak, 4)}       # = frac: HIP events per launch in the serial-stream instrumented pass
+            for mode in ("serial", "overlapped"):
+                t = trace_of(key, mode)
+                if t and n:
+                    # the same algorithmic flops per launch over the rocprofv3 average of the committed trace of that stream configuration
+                    r[f"avg_launch_us_trace_{mode}"] = t["avg_us"]
+                    r[f"frac_trace_{mode}"] = round(flops / n / (t["avg_us"] * 1e-6) / 1e12 / peak, 4)
+                    if t.get("mfma_busy_frac") is not None:
+                        r[f"mfma_busy_frac_{mode}"] = t["mfma_busy_frac"]
+            if "frac_trace_overlapped" in r:
+                r["frac_overlapped"] = r["frac_trace_overlapped"]
+            return r
         # one object per tile kernel; "roofline" is the one with the most GPU time in the step
         labels = {"glds": "gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)",
                   "k64b": "gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)",

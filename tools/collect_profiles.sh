@@ -1,11 +1,13 @@
 #!/bin/bash
-# Runs ON the GPU box (gpurun -- 'bash tools/collect_profiles.sh TAG [all|kt|pmc]'): the bench lines and rocprofv3 passes that
-# profiles/ is made from.  Outputs under gpurun_out/TAG_*; tools/prof_summary.py turns the rocpd databases into tables,
-# tools/pmc_json.py the two PMC databases into per-kernel traffic files.
-#   1. bench.py defaults (C2 framewise, quality + cpu_baseline included)  -> TAG_bench.json
-#   2. rocprofv3 --kernel-trace --stats of bench.py --steps 3 --warmup 1  -> TAG_kt.txt (+ bench line of the traced run)
-#   3. two PMC passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only)         -> TAG_pmc_fetch.txt / TAG_pmc_write.txt / TAG_pmc_<kernel>.json
-#   4. bench lines of the video branch, C1 and the Phi-3-mini composition -> TAG_bench_video.json / TAG_bench_c1.json / TAG_bench_phi3.json
+# Runs ON the GPU box (gpurun -- 'bash tools/collect_profiles.sh TAG [all|kt|pmc|mfma|bench]'): the bench lines and rocprofv3 passes that
+# profiles/ is made from.  Outputs under gpurun_out/TAG_*.
+#   bench: bench.py defaults (C2 framewise, quality + cpu_baseline included)            -> TAG_bench.json
+#   kt:    TWO kernel traces of `bench.py --steps 3 --warmup 1 --no-roofline ...` (4 passes each, nothing else in the process):
+#          the timed stream configuration (Hiera on its side stream)                     -> TAG_kt_overlapped.txt / .json
+#          VG_HIERA_START=serial VG_TOWERS_OVERLAP=0 (the instrumented pass's config)    -> TAG_kt_serial.txt / .json
+#   mfma:  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass in both configurations    -> mfma_busy_frac inside TAG_kt_*.json
+#   pmc:   two PMC passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only)                    -> TAG_pmc_fetch.txt / TAG_pmc_write.txt / TAG_pmc_<kernel>.json
+#   all:   everything above + bench lines of the video branch, C1 and Phi-3-mini         -> TAG_bench_video.json / _c1.json / _phi3.json
 set -u
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -13,21 +15,35 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 db() { find "$1" -name '*.db' | head -1; }
+has() { [ $ONLY = all ] || [ $ONLY = $1 ]; }
 
 ONLY=${2:-all}
-if [ $ONLY = all ]; then
+if has bench; then
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 tail -c 900 $O/${TAG}_bench.json
 fi
-if [ $ONLY = all ] || [ $ONLY = kt ]; then
-rm -rf $O/${TAG}_kt
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality > $O/${TAG}_kt.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality   (C2 framewise, 1 x MI355X; passes of the hot path: 1 warm-up + 3 timed + 2 instrumented (serial streams) + 3 eager decode steps; ms/step columns are totals / 5)"; echo "# bench line of the traced run:"; grep '^{"metric' $O/${TAG}_kt.log; echo;
-  python $R/tools/prof_summary.py "$(db $O/${TAG}_kt)" 5; } > $O/${TAG}_kt.txt
-head -14 $O/${TAG}_kt.txt | cut -c1-200
-rm -rf $O/${TAG}_kt
+BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality --no-roofline"
+PASSES=4
+if has kt || has mfma; then
+for MODE in overlapped serial; do
+  if [ $MODE = serial ]; then export VG_HIERA_START=serial VG_TOWERS_OVERLAP=0; ENVS="VG_HIERA_START=serial VG_TOWERS_OVERLAP=0 "; else unset VG_HIERA_START VG_TOWERS_OVERLAP; ENVS=""; fi
+  rm -rf $O/${TAG}_kt_$MODE $O/${TAG}_mfma_$MODE
+  rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_$MODE -o kt -- python $R/$BENCH > $O/${TAG}_kt_$MODE.log 2>&1
+  MF=""
+  if has mfma; then
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${TAG}_mfma_$MODE -o pmc -- python $R/$BENCH > $O/${TAG}_mfma_$MODE.log 2>&1
+    MF="$(db $O/${TAG}_mfma_$MODE)"
+  fi
+  CMD="${ENVS}rocprofv3 --kernel-trace --stats -- python $BENCH"
+  { echo "# $CMD   (C2 framewise, 1 x MI355X; $PASSES passes of the hot path, all in the '$MODE' stream configuration: 1 warm-up + 3 timed; per-pass columns = totals / $PASSES)"
+    echo "# bench line of the traced run:"; grep '^{"metric' $O/${TAG}_kt_$MODE.log; echo
+    python $R/tools/prof_summary.py "$(db $O/${TAG}_kt_$MODE)" $PASSES; } > $O/${TAG}_kt_$MODE.txt
+  (cd $R/tools && python kt_json.py "$(db $O/${TAG}_kt_$MODE)" $O/${TAG}_kt_$MODE.json $PASSES $MODE "$CMD  (+ a --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace pass of the same command for mfma_busy_frac); tools/collect_profiles.sh" $MF)
+  rm -rf $O/${TAG}_kt_$MODE $O/${TAG}_mfma_$MODE
+done
+unset VG_HIERA_START VG_TOWERS_OVERLAP
 fi
-if [ $ONLY = all ] || [ $ONLY = pmc ]; then
+if has pmc; then
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality"
 for C in FETCH_SIZE WRITE_SIZE; do
   c=$(echo $C | tr A-Z a-z | cut -d_ -f1)
@@ -43,6 +59,6 @@ fi
 [ $ONLY = all ] || exit 0
 
 python $R/bench.py --branch video --no-cpu-baseline > $O/${TAG}_bench_video.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --frames-per-gpu 8 --te 8 --src 512 --no-cpu-baseline > $O/${TAG}_bench_c1.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 8 --te 8 --src 512 --no-cpu-baseline > $O/${TAG}_bench_c1.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --llm phi3-mini --no-cpu-baseline > $O/${TAG}_bench_phi3.json 2>> $O/${TAG}_bench.err
 cut -c1-140 $O/${TAG}_bench_video.json $O/${TAG}_bench_c1.json $O/${TAG}_bench_phi3.json

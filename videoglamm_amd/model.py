@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .params import Params
 from .sam2 import SAM2
-from .vlm import VisionTowers, generate
+from .vlm import VisionTowers, generate, stage_mark
 
 
 class _Cfg:
@@ -101,6 +101,9 @@ class VideoGLaMMForCausalLM:
         # diagnostics only: when set to a dict, inference() leaves the fp32 mask logits ("logits", device), the [SEG] embeddings
         # ("emb") and the model's own per-step argmaxes ("argmax") in it (bench.py's self-check, tests)
         self.capture = None
+        # diagnostics only: when set to a list, the stages of inference() append (name, host time) after a device sync
+        # (bench.py's per-stage replicated / sharded split; meaningful with VG_HIERA_START=serial)
+        self.stages = None
 
     @classmethod
     def from_pretrained(cls, path, config=None, vision_tower=None, image_vision_tower=None, sam2_checkpoint=None,
@@ -247,7 +250,7 @@ class VideoGLaMMForCausalLM:
         out_ids, emb = generate(self.P, self._live_cfg(), self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self._eos(),
                                 forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm,
-                                trace=self.capture)
+                                trace=self.capture, stages=self.stages)
         if self.capture is not None:
             self.capture["emb"] = emb
         return out_ids.unsqueeze(0), emb
@@ -266,7 +269,9 @@ class VideoGLaMMForCausalLM:
         # after the prefill (VG_HIERA_START=prefill) and 211 with no overlap at all.
         mode = os.environ.get("VG_HIERA_START", "first")
         if mode == "serial":      # no overlap (per-kernel timing runs: bench.py's instrumented step)
+            stage_mark(self.stages, "begin")
             feats = self.sam2.hiera_frames(sam, frames)
+            stage_mark(self.stages, "hiera_fpn")
             out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
             return out_ids, emb, feats
         if mode == "first":
@@ -338,9 +343,12 @@ class VideoGLaMMForCausalLM:
         if self.comm is not None:
             # this rank's frames under their global indices (the whole clip when the sharder gathers the masks)
             masks, fids = self.comm.framewise(self.sam2, sam, emb, hw, frame_feats=feats, binarize=None if self._fast_masks() else self._binarize)
-            return out_ids, [self._segments(self._to_host(masks), frame_ids=fids)]
+            host = self._to_host(masks)
+            stage_mark(self.stages, "mask_decode")
+            return out_ids, [self._segments(host, frame_ids=fids)]
         elif self._fast_masks():
             masks = self._to_host(self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats, as_masks=True)[0])
+            stage_mark(self.stages, "mask_decode")
         else:
             logits, _ = self.sam2.framewise_branch(sam, emb, hw, frame_feats=feats)
             if self.capture is not None:
@@ -360,15 +368,20 @@ class VideoGLaMMForCausalLM:
             # frames shard for Hiera only (the propagation is a recurrence over frames); OBJECTS shard for the propagation
             emb = self.comm.sync_seg_embeddings(emb)
             feats = self.comm.gather_frame_feats(feats, sam.shape[0], self.sam2)
+            stage_mark(self.stages, "feature_all_gather")
             masks, oids = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
-            return out_ids, [self._segments(self._to_host(masks), obj_ids=oids)]
+            host = self._to_host(masks)
+            stage_mark(self.stages, "propagation")
+            return out_ids, [self._segments(host, obj_ids=oids)]
         if self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "1") == "1":
             # the propagation replayed from a HIP graph (same launches, same results: tests/test_host_sam2.py): the eager loop leaves
             # the GPU idle 16 % of a C2 clip waiting for Python between ~8000 small launches (r02: 378 -> 361 ms); VG_VIDEO_GRAPH=0 = eager
             fast = self._fast_masks()
             out = self.sam2.video_branch_graphed(sam, emb, hw, feats, as_masks=fast)
             if fast:
-                return out_ids, [self._segments(self._to_host(out))]
+                host = self._to_host(out)
+                stage_mark(self.stages, "propagation")
+                return out_ids, [self._segments(host)]
             logits = out
         elif self._fast_masks():
             return out_ids, [self._segments(self._to_host(self.sam2.video_branch(sam, emb, hw, frame_feats=feats, as_masks=True)))]

@@ -390,8 +390,17 @@ def splice(params, input_ids, visual):
     return torch.cat(parts, dim=0).contiguous()
 
 
+def stage_mark(stages, name):
+    """diagnostics (bench.py's per-stage split): when `stages` is a list, wait for the device and append (name, host time)."""
+    if stages is not None:
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        stages.append((name, time.perf_counter()))
+
+
 def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
-             forced_tokens=None, after_prefill=None, comm=None, trace=None):
+             forced_tokens=None, after_prefill=None, comm=None, trace=None, stages=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
@@ -402,8 +411,10 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
     seg_idx = cfg["seg_token_idx"]
     eos = set() if eos_token_id is None else ({int(eos_token_id)} if isinstance(eos_token_id, int) else {int(e) for e in eos_token_id})
+    stage_mark(stages, "start")
     if visual is None:
         visual = towers.encode(images, context_images, comm)
+    stage_mark(stages, "towers")
     x = splice(params, input_ids, visual)
     need = x.shape[0] + max_new_tokens + 1
     dec = getattr(params, "_decoder", None)
@@ -420,6 +431,7 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     ids = input_ids.tolist()
     if max_new_tokens > 0:
         dec.next_token(hidden)
+    stage_mark(stages, "prefill")
     if after_prefill is not None:
         after_prefill()   # e.g. enqueue the (LLM-independent, MFMA-bound) Hiera pass on a side stream so that it
         #                   overlaps the HBM-bound decode loop below
@@ -439,8 +451,11 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     # the row picked for a [SEG] at output position j is j-1+added, i.e. the state that emitted it
     rows = [j - 1 + added for j in range(1, len(ids)) if ids[j] == seg_idx]
     if not rows:
+        stage_mark(stages, "decode")
         return out_ids, torch.empty(0, 256, dtype=params.dtype, device=params.device)
     h = dec.hid_all[torch.tensor(rows, device=params.device)]
     fc = "model.text_hidden_fcs.0."
     h = ops.linear(h, params.w(fc + "0"), params.b(fc + "0"), act=ops.ACT_RELU)
-    return out_ids, ops.linear(h, params.w(fc + "2"), params.b(fc + "2"))
+    emb = ops.linear(h, params.w(fc + "2"), params.b(fc + "2"))
+    stage_mark(stages, "decode")
+    return out_ids, emb
