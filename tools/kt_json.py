@@ -5,8 +5,12 @@ launch duration, launches and kernel time PER PASS of the hot path, for ONE stre
                       live per-launch HIP events — `roofline.frac` — are taken in).
 Every pass in the traced command runs in that one configuration (bench.py --no-roofline: warm-up + timed passes only), so the
 per-pass columns divide by the true number of passes.  Optional third database: a --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
-pass of the same command -> mfma_busy_frac per class = sum(MFMA busy cycles) / (sum(GRBM_GUI_ACTIVE) x 256 CUs x 4 SIMDs), i.e. the
-fraction of the matrix pipes' cycles (at the clock the kernel actually ran at) that an MFMA occupied.
+pass of the same command -> mfma_busy_frac per class = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) / 8 x 1024 SIMDs): the fraction
+of the matrix pipes' cycles, at the clock the kernel actually ran at, that an MFMA occupied.  Calibration (r03, MI355X): rocprofv3 reports
+GRBM_GUI_ACTIVE summed over the 8 XCDs (16-18 k "cycles" per microsecond of kernel time = 8 x 2.0-2.2 GHz) and the SQ counter summed over
+every SIMD of the chip (the 256x256-tile GEMM: 286.0 M busy cycles per launch against 32 cycles x 0.2692 TFLOP / 32768 flop = 263 M for the
+algorithmic MFMAs + 6.6 % of row padding at M = 3361).  A PMC pass serialises the dispatches, so the counter fraction is a property of the
+kernel running alone (the "serial" configuration) whichever stream configuration the command asks for.
 usage: python tools/kt_json.py <kt.db> <out.json> <passes> <mode> "<command>" [<mfma_pmc.db>]"""
 import json
 import re
@@ -15,7 +19,7 @@ import sys
 
 from pmc_json import CLASSES
 
-SIMDS = 256 * 4
+SIMDS_PER_XCD_SUM = 1024 / 8.0     # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs
 
 
 def main():
@@ -43,7 +47,7 @@ def main():
         busy = sum(pm.get(r[0], {}).get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0.0))[1] for r in sel)
         act = sum(pm.get(r[0], {}).get("GRBM_GUI_ACTIVE", (0, 0.0))[1] for r in sel)
         if act > 0:
-            ent.update(mfma_busy_cycles_sum=busy, grbm_gui_active_sum=act, mfma_busy_frac=round(busy / (act * SIMDS), 4))
+            ent.update(mfma_busy_cycles_sum=busy, grbm_gui_active_sum=act, mfma_busy_frac=round(busy / (act * SIMDS_PER_XCD_SUM), 4))
         res["kernels"][key] = ent
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
