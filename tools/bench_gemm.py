@@ -23,6 +23,8 @@ shapes = [("llm qkv/o", 1697, 4096, 4096), ("llm gate|up", 1697, 28672, 4096), (
           ("sp8 qkv", 213, 6144, 4096), ("sp8 o", 213, 4096, 4096), ("sp8 gate|up", 213, 28672, 4096), ("sp8 down", 213, 4096, 14336),
           ("sp4 gate|up", 425, 28672, 4096), ("sp4 down", 425, 4096, 14336),
           ("sp2 o", 849, 4096, 4096), ("sp2 down", 849, 4096, 14336), ("sp2 qkv", 849, 6144, 4096),
+          ("c2 s1 qkv", 1048576, 432, 144), ("c2 s1 fc1", 1048576, 576, 144), ("c2 s1 proj", 1048576, 144, 144), ("c2 s2 qkv", 262144, 864, 288),
+          ("c2 s2 fc1", 262144, 1152, 288), ("c2 s2 proj", 262144, 288, 288), ("c2 patch", 1048576, 144, 152),
           ("c2 llm qkv", 3361, 6144, 4096), ("c2 llm o", 3361, 4096, 4096), ("c2 llm gate|up", 3361, 28672, 4096), ("c2 llm down", 3361, 4096, 14336)]
 if os.environ.get("VG_BENCH_SHAPES"):
     shapes = [s for s in shapes if any(t in s[0] for t in os.environ["VG_BENCH_SHAPES"].split(","))]
@@ -31,7 +33,12 @@ for name, M, N, K in shapes:
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ms = t(lambda: ops.linear(a, w, out=out))
+    if os.environ.get("VG_BENCH_GEMM_ONLY"):
+        print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s  {(M*K+N*K+M*N)*2/ms/1e9:7.2f} TB/s algorithmic")
+        continue
     print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s")
+if os.environ.get("VG_BENCH_GEMM_ONLY"):
+    sys.exit(0)
 if os.environ.get('VG_BENCH_ONLY') in ('gemm', 'f8'):
     for name, M, N, K, glu in [("llm qkv", 1697, 6144, 4096, False), ("llm o", 1697, 4096, 4096, False), ("llm gate|up+glu", 1697, 14336, 4096, True),
                                ("llm down", 1697, 4096, 14336, False), ("c2 gate|up+glu", 3361, 14336, 4096, True), ("c2 down", 3361, 4096, 14336, False),

@@ -10,7 +10,7 @@ import sys
 
 CLASSES = [
     ("gemm_glds", r"gemm_tile_glds_kernel<unsigned short"),
-    ("gemm_k64b", r"gemm_tile_k64b_kernel<unsigned short"),
+    ("gemm_k64b", r"gemm_tile_k64b_kernel<unsigned short|gemm_tile_ring64_kernel<unsigned short"),
     ("gemm_w128", r"gemm_tile_w128x8_kernel<unsigned short"),
     ("gemm_s128", r"gemm_tile_s128_kernel<unsigned short"),
     ("gemm_mlp", r"hiera_mlp_kernel"),
