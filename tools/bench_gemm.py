@@ -32,7 +32,12 @@ for name, M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    ms = t(lambda: ops.linear(a, w, out=out))
+    if os.environ.get("VG_BENCH_ACT"):      # the epilogue of Hiera's fc1 (bias + exact GELU) / qkv (bias)
+        bias = torch.randn(N, device="cuda", dtype=torch.float32)
+        act = ops.ACT_GELU if os.environ["VG_BENCH_ACT"] == "gelu" else ops.ACT_NONE
+        ms = t(lambda: ops.linear(a, w, bias, act, out=out))
+    else:
+        ms = t(lambda: ops.linear(a, w, out=out))
     if os.environ.get("VG_BENCH_GEMM_ONLY"):
         print(f"gemm {name:14s} M={M:7d} N={N:6d} K={K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s  {(M*K+N*K+M*N)*2/ms/1e9:7.2f} TB/s algorithmic")
         continue

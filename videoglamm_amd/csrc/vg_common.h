@@ -93,12 +93,6 @@ __device__ __forceinline__ void vg_lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// Wave-local ordering point for LDS traffic through a wave-PRIVATE staging region (GEMM epilogues: a wave writes its accumulators to its own
-// rows and reads them back row-major).  The LDS unit processes one wave's instructions in issue order, so a ds_read issued after a ds_write
-// of the same wave sees the data whichever lane wrote it; no workgroup barrier is needed — only the compiler must not reorder.  (r03: the
-// workgroup barriers around the staging passes made the four waves of a tile wait for each other two to three times per tile.)
-__device__ __forceinline__ void vg_lds_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 // row index of accumulator register r for lane-half h in the 32x32 MFMA C/D layout
 __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

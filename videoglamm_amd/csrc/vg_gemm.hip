@@ -38,6 +38,7 @@ struct GemmArgs {
   int ksplit, kchunk; float* part;
   int nbatch;   // persistent 256x256 kernel: batch count (tiles of all batch entries form one queue)
   int stagger;  // 256x256 kernels: first-round workgroup w sleeps (w & 3) * stagger * ~4 us before its first load (phase desynchronisation knob)
+  int nt;       // output tiles leave with non-temporal (streaming) stores: large outputs whose rows are whole 64-byte sectors (launch_gemm)
 };
 
 // window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
@@ -96,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
 #ifndef VG_EPI_ST
 #define VG_EPI_ST 0
 #endif
-__device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
+__device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v, int nt = 0) {
 #if VG_EPI_ST == 1
   __builtin_nontemporal_store(v, (u32x4_t*)ptr);
 #elif VG_EPI_ST == 2
@@ -104,7 +105,14 @@ __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v) {
 #elif VG_EPI_ST == 3
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
 #else
-  *(u32x4_t*)ptr = v;
+  // nt (wave-uniform): a streaming store.  Measured r03 (tools/bench_gemm.py with VG_BENCH_ACT, same-box A/B against the r02 library) on
+  // Hiera's stage-2 GEMMs, whose outputs (150-600 MB) are read by the next kernel long after they have left the caches: the 128x128
+  // kernels are bound by their output stores (a build without them: -35...50 %), and with nt stores qkv runs 389 -> 252 us, fc1 487 -> 338,
+  // proj 132 -> 112; stage 1's fc1 773 -> 646.  Rows that are not whole 64-byte sectors (N = 432, 144: partial sectors want the cache to
+  // merge them) lose 3-7 %, hence the rule in launch_gemm.  Inline asm: hipcc merges "if (nt) __builtin_nontemporal_store(...) else
+  // plain store" into one plain store — the hint is dropped.
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+  else *(u32x4_t*)ptr = v;
 #endif
 }
 
@@ -159,11 +167,7 @@ __device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws
       u32x4_t o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-#ifdef VG_LAB
-      if (ok[ps] && !((p.stagger & 1) && o[0] != 0x12345u)) epi_store16(cp, o);
-#else
-      if (ok[ps]) epi_store16(cp, o);
-#endif
+      if (ok[ps]) epi_store16(cp, o, p.nt);
     } else {
       if constexpr (RES) {
 #pragma unroll
@@ -564,140 +568,6 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   gemm_epilogue128<TO>(p, acc, smem, bm * GBM + wm * 64, p.a_op == 1 ? bn * 64 : bn * GBN + wn * 64, bz, wave, lane);
 }
 
-// ---- register epilogue on TRANSPOSED accumulators (r03) -------------------------------------------------------------------------------
-// The SQ counters of the 128x128-tile kernels on Hiera's shapes (tools/lab/pmc_smallk.sh) show them bound by INSTRUCTION ISSUE, not by
-// the MFMA pipe, the LDS or HBM: a wave of the 64-byte-step kernel issues ~1070 instructions per tile (510 VALU, 390 SALU, 100 LDS) around
-// its 40 MFMAs, four waves per SIMD keep the issue port ~80 % busy, and more than half of those instructions are the LDS-staged epilogue
-// (accumulator -> LDS -> row-major -> bias / activation -> 16-byte stores, with per-pass row arithmetic).  Multiplying the operands the
-// other way round — D^T = W_tile . A_tile^T — leaves a lane with ONE output row (m = lane & 31) and, per 32x32 block, the columns
-// n = 8q + 4h + e (q, e < 4; h = lane >> 5): four consecutive columns per q.  fp32 outputs are then 16-byte pieces as they stand; bf16
-// pairs are packed and one v_permlane32_swap per dword hands the upper lane half its (q + 2) pieces in exchange for the lower half's
-// odd 8-byte halves, after which every lane holds two whole 16-byte pieces of its row (columns 8q + 16h .. + 7).  No LDS, no barrier,
-// no per-pass row arithmetic: one row offset (and one window-row mapping) per lane and 32-row block; bias / LayerScale are 16-byte loads
-// of four consecutive columns.  ~35 instructions per 32x32 block instead of ~170.
-__device__ __forceinline__ void vg_swap_halves(uint32_t& x, uint32_t& y) {     // x[lanes 32..63] <-> y[lanes 0..31]
-  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-  const u32x2_t r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-  x = r[0];
-  y = r[1];
-}
-
-// one 32x32 block: acc[r] = D^T[n = nb + mfma32_row(r, h)][m = this lane's row]; mo = the row's offset in C / R rows (already window-mapped),
-// rowok = the row exists.  Requires 16-byte aligned rows (vec_out) and N % 8 == 0.
-// fp32 outputs: stored from here (16-byte pieces of four columns).  bf16 outputs: the lane's two 16-byte pieces (columns nb + 8q + 16h .. + 7,
-// q = 0, 1) come back in `out` and the caller stores them.
-template <typename TO, int ACT, bool RES>
-__device__ __forceinline__ void epi_regs_block(const GemmArgs& p, const f32x16_t& acc, int64_t mo, bool rowok, int nb, int h, TO* C, const TO* R,
-                                               u32x4_t (&out)[2]) {
-  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-  const int N = p.N;
-  uint32_t P[4][2];
-  // one q (four consecutive columns) at a time: few values live at once — the kernels that end here run four workgroups per CU on 128 VGPRs
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = nb + 8 * q + 4 * h;
-    const bool nok = n < N;
-    f32x4_t v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-    if (p.bias) {
-      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4_t b = nok ? *(const f32x4_t*)(p.bias + n) : z;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += b[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = vg_act(v[e], ACT);
-    if (p.gamma) {
-      const f32x4_t o1 = {1.f, 1.f, 1.f, 1.f};
-      const f32x4_t g = nok ? *(const f32x4_t*)(p.gamma + n) : o1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= g[e];
-    }
-    if constexpr (sizeof(TO) == 4) {
-      if (rowok && nok) {
-        if constexpr (RES) {
-          const f32x4_t r = *(const f32x4_t*)(R + mo * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r[e];
-        }
-        *(f32x4_t*)(C + mo * p.ldc + n) = v;
-      }
-    } else {
-      if constexpr (RES) {
-        const u32x2_t z = {0u, 0u};
-        const u32x2_t rr = (rowok && nok) ? *(const u32x2_t*)(R + mo * p.ldr + n) : z;
-        v[0] += __uint_as_float(rr[0] << 16);
-        v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-        v[2] += __uint_as_float(rr[1] << 16);
-        v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-      }
-      P[q][0] = f2bf2(v[0], v[1]);
-      P[q][1] = f2bf2(v[2], v[3]);
-    }
-  }
-  if constexpr (sizeof(TO) == 2) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      vg_swap_halves(P[q][0], P[q + 2][0]);
-      vg_swap_halves(P[q][1], P[q + 2][1]);
-      out[q] = u32x4_t{P[q][0], P[q][1], P[q + 2][0], P[q + 2][1]};
-    }
-  }
-}
-
-// The wave's 64x64 tile (2 x 2 blocks, transposed accumulators): rows m0w + 32 i + (lane & 31), columns n0w + 32 j + ...
-// bf16: the packed 16-byte pieces of 32 rows go through a wave-private LDS image (32 rows x 128 B, row stride 144 B: conflict-free
-// ds_write_b128 / ds_read_b128) so that a store instruction writes 8 whole 128-byte lines — a lane storing its own two pieces
-// touches 32 lines per instruction with 16 + 16 bytes each, and the partial-line writes cost more than the LDS-staged epilogue they
-// replaced (measured r03 on Hiera's stage-1/2 shapes: +20 % with the plain stores, the arithmetic alone -30 %).
-template <typename TO>
-__device__ __forceinline__ void gemm_epilogue_regs64(const GemmArgs& p, f32x16_t (&acc)[2][2], char* stage, int m0w, int n0w, int bz, int lane) {
-  const int l31 = lane & 31, h = lane >> 5;
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  if (n0w >= p.N) return;
-  constexpr int RS = 144;                         // bytes per staged row (128 + 16)
-  const int cg = lane & 7, rsub = lane >> 3;
-  epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0w + i * 32 + l31;
-      bool ok = m < p.M;
-      int64_t mo = m;
-      if (p.wmode == 2) {
-        mo = ok ? gemm_window_row(p, m) : -1;
-        ok = mo >= 0;
-      }
-      if (!ok) mo = -1;                           // (the row-major store pass below tells a missing row by its offset)
-      if (i) vg_lds_wave_fence();                 // (the previous block's reads are done before its image is overwritten)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        u32x4_t pc[2];
-        epi_regs_block<TO, decltype(act)::value, decltype(res)::value != 0>(p, acc[i][j], mo, ok, n0w + j * 32, h, C, R, pc);
-        if constexpr (sizeof(TO) == 2) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) *(u32x4_t*)(stage + l31 * RS + (j * 32 + 8 * q + 16 * h) * 2) = pc[q];
-        }
-      }
-      if constexpr (sizeof(TO) == 2) {
-        vg_lds_wave_fence();
-        const int c = n0w + cg * 8;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int rl = ps * 8 + rsub;
-          // the row offset lives in the lane that owns the row (lanes rl and rl + 32 hold the same value)
-          const int64_t ro = ((int64_t)__shfl((int)(mo >> 32), rl, 64) << 32) | (uint32_t)__shfl((int)mo, rl, 64);
-          const u32x4_t o = *(const u32x4_t*)(stage + rl * RS + cg * 16);
-#ifdef VG_LAB
-          if (ro >= 0 && c < p.N && !((p.stagger & 1) && o[0] != 0x12345u)) epi_store16(C + ro * p.ldc + c, o);
-#else
-          if (ro >= 0 && c < p.N) epi_store16(C + ro * p.ldc + c, o);
-#endif
-        }
-      }
-    }
-  });
-}
-
 // Epilogue of the four-workgroups-per-CU 128x128 kernels (64-byte-step and single-stage): the wave's 64x64 tile goes out 32 rows at a
 // time through 4 x 32 x 68 floats of staging (34.8 KB with the stage buffers aliased: what keeps four workgroups on a CU).
 template <typename TO>
@@ -710,33 +580,27 @@ __device__ __forceinline__ void gemm_epilogue64x32(const GemmArgs& p, f32x16_t (
   float* ws = (float*)smem + wave * 32 * ES;
   const int cg = lane & 7, rsub = lane >> 3;
   const int n0 = n0w + cg * 8;
-#ifdef VG_LAB
-  if (p.stagger & 4) {           // no epilogue at all: one store per lane keeps the accumulators alive
-    if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) C[0] = (TO)1;
-    return;
-  }
-#endif
-  // the accumulators arrive TRANSPOSED (lane = row, see gemm_epilogue_regs64): 16-byte aligned rows and N % 8 == 0 go out of the registers;
-  // everything else (odd N, unaligned rows, fp8 scales) is staged row-major through the wave's own LDS rows and finished element-wise
-  if (p.vec_out && !p.sa && (N & 7) == 0 && ((((uintptr_t)p.bias) | ((uintptr_t)p.gamma)) & 15) == 0) {
-    gemm_epilogue_regs64<TO>(p, acc, (char*)ws, m0w, n0w, bz, lane);
-    return;
-  }
   float bv[8], gv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
     gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
   }
+  const bool fast = p.vec_out && !p.sa && n0w + 64 <= N;     // wave-uniform: whole 16-byte groups -> the straight-line form
   auto pass32 = [&](auto ic) {           // (instantiated by hand: see gemm_tile_w128x8_kernel's epilogue)
     constexpr int i = decltype(ic)::value;
-    // the staging rows are this wave's own: wave-local ordering is enough (no workgroup barrier, see vg_lds_wave_fence)
-    if (i) vg_lds_wave_fence();
+    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[l31 * ES + j * 32 + mfma32_row(r, h)] = acc[i][j][r];
-    vg_lds_wave_fence();
+      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
+    vg_lds_barrier();
+    if (fast) {
+      epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
+        epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES>(p, ws, m0w + i * 32, n0, cg, rsub, bv, gv, C, R);
+      });
+      return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int ml = pass * 8 + rsub;
@@ -830,9 +694,6 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
   auto issue = [&](int kt, int buf) {
     char* sa = smem + buf * 2 * TILEB + wave * 32 * 64;
     char* sb = sa + TILEB;
-#ifdef VG_LAB
-    if (p.stagger & 2) return;
-#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
@@ -842,9 +703,6 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
     }
   };
   auto issue_tail = [&](int kt, int buf) {
-#ifdef VG_LAB
-    if (p.stagger & 2) return;
-#endif
     char* sa = smem + buf * 2 * TILEB + wave * 32 * 64 + lane * 16;
     char* sb = sa + TILEB;
     u32x4_t va[2], vb[2];
@@ -896,130 +754,16 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_k64b_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      MmaOp<T>::run(fb0[g], fa0[g], acc[0][0]);      // D^T = W . A^T: a lane ends up with one output ROW (gemm_epilogue_regs64)
-      MmaOp<T>::run(fb1[g], fa0[g], acc[0][1]);
-      MmaOp<T>::run(fb0[g], fa1[g], acc[1][0]);
-      MmaOp<T>::run(fb1[g], fa1[g], acc[1][1]);
+      MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+      MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+      MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+      MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
   // epilogue, 32 rows of the wave's 64x64 tile at a time (4 x 32 x 68 floats = 34.8 KB of staging)
-  gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
-}
-
-// The 64-byte-step kernel on an NST-stage LDS-DMA RING (r03).  gemm_tile_k64b_kernel serialises one global->LDS round trip per
-// K step (issue kt+1, multiply kt, wait, barrier): at K = 144 / 288 (Hiera stages 1-2: five / nine steps per tile) a tile spends
-// its life waiting — the r02 counters show those launches at 2.0 TB/s of HBM-side traffic, a quarter of the roof they are bound by
-// (arithmetic intensity 100-140 flop/B).  Here the first NST-1 steps of a tile are requested at once and every later step as soon as
-// the stage it overwrites has been read by everyone (one barrier per step, counted vmcnt waits: a step is waited for with the
-// younger ones still in flight), so a K = 144 tile pays about two round trips instead of five.  NST x 16 KB of LDS: two workgroups
-// per CU keep 96 KB of loads in flight (k64b: four workgroups x 16 KB).  A partial last step needs no register path: lanes whose
-// chunk lies beyond K fetch from a zero chunk instead (the LDS-DMA cannot zero-fill, but every lane has its own source address).
-__device__ __attribute__((aligned(256))) uint32_t g_zero_chunk[64];      // zero-initialised: 256 B of zeros for redirected DMA lanes
-
-template <int N> __device__ __forceinline__ void vg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T, typename TO, int NST>
-__global__ __launch_bounds__(256, 2) void gemm_tile_ring64_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);
-  constexpr int BK = 64 / sizeof(T);
-  constexpr int TILEB = 128 * 64;         // bytes per operand per stage
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-  const int nk = (K + BK - 1) / BK;
-
-  // wave w stages rows [32w, 32w+32) of each operand in 2 DMA instructions of 16 rows (4 lanes per 64-byte row)
-  const T* asrc[2];
-  const T* wsrc[2];
-  const T* atail[2];      // sources of the LAST step: the row's own chunk, or the zero chunk when it lies beyond K
-  const T* wtail[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 32 + i * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    int gm = bm * GBM + row, gn = bn * GBN + row;
-    gm = gm < M ? gm : M - 1;
-    gn = gn < N ? gn : N - 1;
-    if (p.wmode == 1) {
-      const int64_t r = gemm_window_row(p, gm);
-      asrc[i] = (r >= 0 ? A + r * p.lda : (const T*)p.zrow) + chunk * KPC;
-    } else {
-      asrc[i] = A + (int64_t)gm * p.lda + chunk * KPC;
-    }
-    wsrc[i] = W + (int64_t)gn * p.ldw + chunk * KPC;
-    const bool in = (nk - 1) * BK + chunk * KPC < K;
-    atail[i] = in ? asrc[i] + (int64_t)(nk - 1) * BK : (const T*)g_zero_chunk;
-    wtail[i] = in ? wsrc[i] + (int64_t)(nk - 1) * BK : (const T*)g_zero_chunk;
-  }
-  auto issue = [&](int kt) {
-    char* sa = smem + (kt % NST) * 2 * TILEB + wave * 32 * 64;
-    char* sb = sa + TILEB;
-    const bool last = kt == nk - 1;
-#ifdef VG_LAB
-    if (p.stagger & 2) return;
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const T* a = last ? atail[i] : asrc[i] + (int64_t)kt * BK;
-      const T* w = last ? wtail[i] : wsrc[i] + (int64_t)kt * BK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w, (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int ra = wm * 64 + l31, rb = wn * 64 + l31;
-  const int swa = (ra >> 2) & 3, swb = (rb >> 2) & 3;
-  for (int s = 0; s < NST - 1 && s < nk; ++s) issue(s);
-  for (int kt = 0; kt < nk; ++kt) {
-    // step kt has landed when at most `rem` younger steps (4 DMA instructions each) are still in flight
-    const int rem = min(nk - 1 - kt, NST - 2);
-    if (rem >= 2) vg_wait_vmcnt<8>();          // (NST <= 4: at most two younger steps)
-    else if (rem == 1) vg_wait_vmcnt<4>();
-    else vg_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();              // everyone's part of step kt is in LDS; everyone has read stage (kt - 1) % NST
-    asm volatile("" ::: "memory");
-    if (kt + NST - 1 < nk) issue(kt + NST - 1);
-    const char* sa = smem + (kt % NST) * 2 * TILEB + ra * 64;
-    const char* sb = smem + (kt % NST) * 2 * TILEB + TILEB + rb * 64;
-    u32x4_t fa0[2], fa1[2], fb0[2], fb1[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int c = 2 * g + h;
-      fa0[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
-      fb0[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
-      fa1[g] = *(const u32x4_t*)(sa + 32 * 64 + ((c ^ swa) << 4));
-      fb1[g] = *(const u32x4_t*)(sb + 32 * 64 + ((c ^ swb) << 4));
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      MmaOp<T>::run(fb0[g], fa0[g], acc[0][0]);      // D^T = W . A^T: a lane ends up with one output ROW (gemm_epilogue_regs64)
-      MmaOp<T>::run(fb1[g], fa0[g], acc[0][1]);
-      MmaOp<T>::run(fb0[g], fa1[g], acc[1][0]);
-      MmaOp<T>::run(fb1[g], fa1[g], acc[1][1]);
-    }
-  }
-  __syncthreads();       // the epilogue staging aliases the stages
-
   gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
@@ -1123,10 +867,10 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      MmaOp<T>::run(fb0[g], fa0[g], acc[0][0]);      // D^T = W . A^T: a lane ends up with one output ROW (gemm_epilogue_regs64)
-      MmaOp<T>::run(fb1[g], fa0[g], acc[0][1]);
-      MmaOp<T>::run(fb0[g], fa1[g], acc[1][0]);
-      MmaOp<T>::run(fb1[g], fa1[g], acc[1][1]);
+      MmaOp<T>::run(fa0[g], fb0[g], acc[0][0]);
+      MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
+      MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
+      MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
     }
     __syncthreads();           // everyone has its fragments in registers: the stage may be overwritten
   }
@@ -1489,14 +1233,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
     // honoured, and a run-time acc[i] sends the accumulators to scratch)
     auto pass32 = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      // SwiGLU reads the partner wave's staging rows: workgroup barriers (LDS-only: __syncthreads would also wait for the previous pass's
-      // global stores); every other epilogue reads back the wave's own rows: wave-local ordering (vg_lds_wave_fence)
-      if (i) { if (p.a_op == 1) vg_lds_barrier(); else vg_lds_wave_fence(); }
+      if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-      if (p.a_op == 1) vg_lds_barrier(); else vg_lds_wave_fence();
+      vg_lds_barrier();
       const int mrow = bm * 256 + wm * 128 + i * 32;
       if (p.a_op == 1) {
         // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows:
@@ -1534,7 +1276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
               u32x4_t o;
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-              epi_store16(cp, o);
+              epi_store16(cp, o, p.nt);
             } else {
               f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
               *(f32x4_t*)cp = o0;
@@ -1572,7 +1314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
             u32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            epi_store16(cp, o);
+            epi_store16(cp, o, p.nt);
           } else {
             if (rp) {
               const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
@@ -1967,6 +1709,11 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     };
     GemmArgs q = p;
     q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + GBN - 1) / GBN);
+    // streaming stores for big outputs with sector-aligned rows (epi_store16): VG_GEMM_NT = 0 never, 1 (default) by this rule, 2 always
+    static const int nt_mode = env_knob("VG_GEMM_NT", 1);
+    static const int nt_mb = env_knob("VG_GEMM_NT_MB", 128);
+    q.nt = nt_mode == 2 || (nt_mode == 1 && p.vec_out && (p.ldc * (int64_t)sizeof(TO)) % 64 == 0 &&
+                            (int64_t)p.M * p.N * (int64_t)sizeof(TO) * batch >= (int64_t)nt_mb << 20);
     // VG_GEMM_VARIANT = 644: the 64-byte-step kernel for every shape (A/B knob); default: the 128x128 LDS-DMA kernel with all 16 fragment
     // reads of a K step requested up front.  (The register-staged kernels 1281 / 1282 / 641 / 642, the group-by-group fragment reads 1283
     // and the 256x128 three-stage ring, r01's A/B twins, were removed at the end of r02: -10 % / 0 / +-3 %)
@@ -2019,19 +1766,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
       gemm_tile_s128_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (small_k) {
-      // r03: the same tile on a 4-stage DMA ring, two workgroups per CU (VG_GEMM_RING64=0: the double-buffered kernel, four per CU)
-      static const int ring = env_knob("VG_GEMM_RING64", 1);
-      static bool ring_attr = false;
-      if (!ring_attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tile_ring64_kernel<T, TO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 128 * 64);
-        ring_attr = true;
-      }
-#ifdef VG_LAB
-      static const int ablate = env_knob("VG_GEMM_ABLATE", 0);
-      q.stagger = ablate;
-#endif
-      if (ring) gemm_tile_ring64_kernel<T, TO, 4><<<grid, 256, 4 * 2 * 128 * 64, st>>>(q);
-      else gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
+      gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (p.a_op == 1) {       // SwiGLU in the epilogue: a tile = 128 rows x 64 outputs (gate | up halves)
       dim3 gridg((p.N + 63) / 64, (p.M + GBM - 1) / GBM, batch);
       q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + 63) / 64);
