@@ -669,6 +669,13 @@ def main():
         md = roof(None, "every ops.linear launch inside SAM2.mask_decoder (two-way transformer q/k/v/out projections on [frames x objects, 4096, 256], "
                         "ConvTranspose-as-GEMM upscaling, token MLPs)", scope="mask_decoder")
         if md["launches"]:
+            # these GEMMs are [frames x objects x 4096, 256] x [256, 128 | 256] projections: 86-170 flop per algorithmic byte against the
+            # 312 flop/B ridge of the part — bound by HBM, not by the MFMA pipe: both fractions are reported, and the
+            # MFMA fraction these shapes could reach if they streamed at the full 8 TB/s
+            gbs = md["algorithmic_bytes_per_launch"] / (md["avg_launch_us"] * 1e-6) / 1e9 if md["avg_launch_us"] else 0.0
+            ai = md["algorithmic_tflop_per_launch"] * 1e12 / max(md["algorithmic_bytes_per_launch"], 1)
+            md.update({"bound": "hbm", "achieved_gbs": round(gbs, 1), "peak_gbs": 8000.0, "frac_hbm": round(gbs / 8000.0, 4), "frac_mfma": md["frac"],
+                       "flop_per_algorithmic_byte": round(ai, 1), "mfma_frac_ceiling_at_hbm_peak": round(min(1.0, ai * 8e12 / 2.5e15), 3)})
             res["roofline_mask_decoder_gemm"] = md
         if dec_n and not args.tiny:
             c = cfg["llm"]

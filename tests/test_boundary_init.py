@@ -99,6 +99,14 @@ def test_config_ids_are_live_and_refusals(tmp_path, cpu_ops, monkeypatch):
             VideoGLaMMForCausalLM.from_pretrained(model_dir, sam2_checkpoint=sam2, seg_token_idx=cfg["seg_token_idx"], device="cpu", **kw)
     with pytest.raises(ValueError):
         initialize_model_videogptplus(model_dir, "fp32", base_llm_type="vicuna", tokenizer=tok, sam2_checkpoint=sam2, device="cpu")
+    # --precision fp16 (the reference's default) is never a silent bf16 swap: a UserWarning, or a refusal under VG_FP16_STRICT=1
+    with pytest.warns(UserWarning, match="runs in bfloat16"):
+        m16, _ = initialize_model_videogptplus(model_dir, "fp16", base_llm_type="llama3_1", tokenizer=tok, sam2_checkpoint=sam2, device="cpu")
+    assert m16.dtype == torch.bfloat16
+    monkeypatch.setenv("VG_FP16_STRICT", "1")
+    with pytest.raises(NotImplementedError):
+        initialize_model_videogptplus(model_dir, "fp16", base_llm_type="llama3_1", tokenizer=tok, sam2_checkpoint=sam2, device="cpu")
+    monkeypatch.delenv("VG_FP16_STRICT")
     bad = ToyTokenizer(cfg["llm"]["vocab"], seg_id=None)
     bad.added["[SEG]"] = 10 ** 6                          # an id outside the (resized) table must not pass silently
     with pytest.raises(ValueError):

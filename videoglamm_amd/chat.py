@@ -47,7 +47,16 @@ def initialize_model_videogptplus(model_base, precision="fp16", local_rank=0, lo
     if precision == "bf16":
         torch_dtype = torch.bfloat16
     elif precision == "fp16":
-        print("precision fp16: running the bf16 kernels (no fp16 compute path on this build)")
+        # the one flag where the drop-in changes numerics without being asked (fp16 is the reference's DEFAULT, R/chat.py:105,153): never
+        # silent — a UserWarning on every load, and a refusal under VG_FP16_STRICT=1 for callers that must not run another number format
+        import os
+        import warnings
+        msg = ("--precision fp16 (the reference's default) runs in bfloat16 on this build: the MI355X kernels compute in bf16 or fp32 "
+               "(same 16-bit storage, 8-bit instead of 11-bit significand, fp32 exponent range); pass --precision bf16 to silence this, "
+               "--precision fp32 for the parity mode")
+        if os.environ.get("VG_FP16_STRICT", "0") == "1":
+            raise NotImplementedError(msg + " [VG_FP16_STRICT=1]")
+        warnings.warn(msg, UserWarning, stacklevel=2)
         torch_dtype = torch.bfloat16
     model_args = {"torch_dtype": torch_dtype}
     if load_in_4bit or load_in_8bit:
