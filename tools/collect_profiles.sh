@@ -7,7 +7,7 @@
 #          VG_HIERA_START=serial VG_TOWERS_OVERLAP=0 (the instrumented pass's config)    -> TAG_kt_serial.txt / .json
 #   mfma:  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass in both configurations    -> mfma_busy_frac inside TAG_kt_*.json
 #   pmc:   two PMC passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only)                    -> TAG_pmc_fetch.txt / TAG_pmc_write.txt / TAG_pmc_<kernel>.json
-#   all:   everything above + bench lines of the video branch, C1 and Phi-3-mini         -> TAG_bench_video.json / _c1.json / _phi3.json
+#   all:   everything above + bench lines of the video branch, C1, Phi-3-mini and C4's clip on one GPU -> TAG_bench_{video,c1,phi3,c4clip,c4clip_fp8,c4clip_video}.json
 set -u
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -61,4 +61,8 @@ fi
 python $R/bench.py --branch video --no-cpu-baseline > $O/${TAG}_bench_video.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --frames 8 --te 8 --src 512 --no-cpu-baseline > $O/${TAG}_bench_c1.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --llm phi3-mini --no-cpu-baseline > $O/${TAG}_bench_phi3.json 2>> $O/${TAG}_bench.err
-cut -c1-140 $O/${TAG}_bench_video.json $O/${TAG}_bench_c1.json $O/${TAG}_bench_phi3.json
+# BASELINE config C4's clip on ONE GPU (64 frames, 8 [SEG] objects = 512 mask-decoder instances), bf16 and the fp8 LLM path, framewise and video branch
+python $R/bench.py --frames 64 --objects 8 --no-cpu-baseline --no-quality > $O/${TAG}_bench_c4clip.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 64 --objects 8 --prefill fp8 --decode-weights fp8 --no-cpu-baseline --no-quality > $O/${TAG}_bench_c4clip_fp8.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 64 --objects 8 --branch video --no-cpu-baseline --no-quality --steps 2 > $O/${TAG}_bench_c4clip_video.json 2>> $O/${TAG}_bench.err
+cut -c1-140 $O/${TAG}_bench_video.json $O/${TAG}_bench_c1.json $O/${TAG}_bench_phi3.json $O/${TAG}_bench_c4clip.json $O/${TAG}_bench_c4clip_fp8.json $O/${TAG}_bench_c4clip_video.json
