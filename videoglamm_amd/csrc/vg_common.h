@@ -58,15 +58,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // instead of libm erff's ~40 — the exact-GELU epilogue of the Hiera / InternVideo2 fc1 GEMMs applies it to 4.4e9
 // elements per C1 clip.  For z < 0 the complement poly(t)*exp(-z^2) is used directly, so the tail keeps relative accuracy.
 __device__ __forceinline__ float vg_half_erfc_neg(float z) {
+  // r03: v_rcp_f32 / v_exp_f32 directly (1 ulp each, far inside the 1.5e-7 of the formula).  __frcp_rn is the CORRECTLY ROUNDED reciprocal:
+  // hipcc expands it into the full division sequence (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup + the denormal selects) —
+  // 10 of the ~22 instructions per GELU in the ISA of the fc1 epilogues, on kernels that are bound by instruction issue
   const float a = fabsf(z);
-  const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float q = 0.5f * p * t * __expf(-a * a);   // 0.5 * erfc(|z|)
+  const float q = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);   // 0.5 * erfc(|z|)
   return z < 0.f ? q : 1.0f - q;
 }
+
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): ONE definition for every SwiGLU site (GEMM
+// epilogues, vg_swiglu, the decode GEMV) — the fused and unfused paths are compared bit for bit by the tests
+__device__ __forceinline__ float vg_silu(float g) { return g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
 
 // activation codes (vg_kernels.h): 0 none, 1 gelu(erf), 2 quick_gelu, 3 relu, 4 silu, 5 sigmoid
 __device__ __forceinline__ float vg_act(float x, int act) {
@@ -76,10 +83,10 @@ __device__ __forceinline__ float vg_act(float x, int act) {
 #else
     case VG_ACT_GELU: return x * vg_half_erfc_neg(x * 0.70710678118654752440f);
 #endif
-    case VG_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+    case VG_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case VG_ACT_RELU: return x > 0.f ? x : 0.f;
-    case VG_ACT_SILU: return x / (1.0f + __expf(-x));
-    case VG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+    case VG_ACT_SILU: return vg_silu(x);
+    case VG_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     default: return x;
   }
 }

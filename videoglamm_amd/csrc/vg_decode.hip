@@ -86,7 +86,7 @@ __device__ __forceinline__ void dec_gemv_store(const DecGemvArgs& p, int pi, flo
   if constexpr (GLU) {
     float g = a0, u = a1;
     if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
-    g = g / (1.0f + __expf(-g));
+    g = vg_silu(g);
     if (sizeof(T) == 2) g = bf2f(f2bf(g));
     float v = g * u;
     if (R) v += vg_elt<TO>::ld(R + n0);

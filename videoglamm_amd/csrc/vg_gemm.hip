@@ -30,6 +30,7 @@ struct GemmArgs {
   // (window_partition fused into the load), 2 = C and R rows are scattered to / read from image order (window_unpartition
   // + residual add fused into the epilogue).  GEMM row m is always the window-order index.
   int wmode, wH, wW, wws, wnH, wnW;
+  int wsh;      // >= 0: ws, wnW, wnH are powers of two, their log2 packed as ws | nW << 8 | nH << 16 (gemm_window_row's shift path); -1: divide
   const void* zrow;   // K zeros: source of the padded window rows (the LDS-DMA cannot zero-fill)
   // fp8 operands (vg_gemm_f8): C = (A8 . W8^T) * sa[m] * sw[n] — one fp32 scale per A row (token) and per W row (output)
   const float* sa; const float* sw;
@@ -41,8 +42,21 @@ struct GemmArgs {
   int nt;       // output tiles leave with non-temporal (streaming) stores: large outputs whose rows are whole 64-byte sectors (launch_gemm)
 };
 
-// window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition)
+// window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition).
+// r03: when the window side and the window counts are powers of two (every Hiera stage of a 1024^2 input: 8 / 4 / 16 / 8-token windows on
+// 256 / 128 / 64 / 32-token grids) the five integer divisions — ~25 instructions each on this ISA, per ROW: two to four rows per lane in the
+// gathering prologue, eight per lane and tile in the scattering epilogue, on kernels that are bound by instruction issue — are shifts and
+// masks (p.wsh: log2 of ws | nW << 8 | nH << 16, or -1).
 __device__ __forceinline__ int64_t gemm_window_row(const GemmArgs& p, int m) {
+  if (p.wsh >= 0) {
+    const int ws_sh = p.wsh & 0xff, nw_sh = (p.wsh >> 8) & 0xff, nh_sh = (p.wsh >> 16) & 0xff;
+    const int win = m >> (2 * ws_sh), tok = m & ((1 << (2 * ws_sh)) - 1);
+    const int rr = tok >> ws_sh, cc = tok & ((1 << ws_sh) - 1);
+    const int wx = win & ((1 << nw_sh) - 1), t = win >> nw_sh;
+    const int wy = t & ((1 << nh_sh) - 1), b = t >> nh_sh;
+    const int y = (wy << ws_sh) + rr, x = (wx << ws_sh) + cc;
+    return (y < p.wH && x < p.wW) ? ((int64_t)b * p.wH + y) * p.wW + x : -1;
+  }
   const int per = p.wws * p.wws;
   const int win = m / per, tok = m - win * per;
   const int rr = tok / p.wws, cc = tok - rr * p.wws;
@@ -258,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
           g += bg[e];
           u += bu[e];
           if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-          g = g / (1.0f + __expf(-g));
+          g = vg_silu(g);
           if (sizeof(TO) == 2) g = bf2f(f2bf(g));
           v[e] = g * u;
         }
@@ -1038,7 +1052,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_w128_kernel(GemmArgs p) {
           float g = wg[ml * ES + cg * 8 + e] + bv[e];
           float u = wu[ml * ES + cg * 8 + e] + ((p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f);
           if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-          g = g / (1.0f + __expf(-g));
+          g = vg_silu(g);
           if (sizeof(TO) == 2) g = bf2f(f2bf(g));
           v[e] = g * u;
         }
@@ -1266,7 +1280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
             float g = gx[e] + bv[e];
             float u = ux[e] + bu[e];
             if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-            g = g / (1.0f + __expf(-g));
+            g = vg_silu(g);
             if (sizeof(TO) == 2) g = bf2f(f2bf(g));
             v[e] = g * u;
           }
@@ -1572,7 +1586,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         if constexpr (GLU) {
           float g = acc[m] + bv, u = accu[m] + (p.bias ? p.bias[p.N + n] : 0.f);
           if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
-          g = g / (1.0f + __expf(-g));
+          g = vg_silu(g);
           if (sizeof(T) == 2) g = bf2f(f2bf(g));
           v = g * u * gv;
         } else {
@@ -1847,6 +1861,7 @@ extern "C" int vg_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t
   VG_CHECK((ldc * oes) % 16 == 0 && ((uintptr_t)C & 15) == 0, VG_ERR_ARG, "vg_gemm_splitk: C rows must be 16-byte aligned");
   VG_CHECK(ws_floats >= (int64_t)ksplit * M * N, VG_ERR_ARG, "vg_gemm_splitk: workspace %lld < %lld floats", (long long)ws_floats, (long long)ksplit * M * N);
   GemmArgs p{};
+  p.wsh = -1;
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.gamma = gamma; p.R = R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.act = act; p.vec_out = 1; p.gn = 4;
@@ -1923,6 +1938,7 @@ extern "C" int vg_gemm_f8(const uint8_t* A8, int64_t lda, const float* a_scale, 
   VG_CHECK(N % 8 == 0 && (ldc * oes) % 16 == 0 && ((uintptr_t)C & 15) == 0 && (!R || ((ldr * oes) % 16 == 0 && ((uintptr_t)R & 15) == 0)),
            VG_ERR_UNSUPPORTED, "vg_gemm_f8: C / R rows must be 16-byte aligned and N a multiple of 8");
   GemmArgs p{};
+  p.wsh = -1;
   p.A = A8; p.W = W8; p.C = C; p.bias = bias; p.gamma = nullptr; p.R = R;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = VG_ACT_NONE; p.vec_out = 1; p.a_op = a_op; p.gn = 4;
@@ -1959,13 +1975,16 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
                       (!R || ((ldr % ovec == 0) && (sR % ovec == 0) && (((uintptr_t)R & 15) == 0)));
   VG_CHECK(a_op == 0 || M <= 16 || (vec_out && !R && !gamma && batch == 1 && act == VG_ACT_NONE), VG_ERR_UNSUPPORTED,
            "vg_gemm: a_op=1 with M > 16 needs 16-byte aligned C rows and no residual / LayerScale / activation / batch");
-  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1, 0, 0, 0, 0, 0, 0, nullptr};
+  GemmArgs p{A, W, C, bias, gamma, R, lda, ldw, ldc, ldr, sA, sW, sC, sR, M, N, K, act, vec_out, a_op, 1, 0, 0, 0, 0, 0, 0, -1, nullptr};
   if (g_window.mode) {
     VG_CHECK(g_window.mode != 2 || vec_out, VG_ERR_UNSUPPORTED, "vg_gemm_window: scattered C/R rows must be 16-byte aligned (ldc=%lld ldr=%lld)",
              (long long)ldc, (long long)ldr);
     p.wmode = g_window.mode; p.wH = g_window.H; p.wW = g_window.W; p.wws = g_window.ws;
     p.wnH = (g_window.H + g_window.ws - 1) / g_window.ws; p.wnW = (g_window.W + g_window.ws - 1) / g_window.ws;
     p.zrow = g_window.zrow;
+    auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    const int a = lg2(p.wws), b = lg2(p.wnW), c = lg2(p.wnH);
+    p.wsh = (a >= 0 && b >= 0 && c >= 0) ? (a | (b << 8) | (c << 16)) : -1;
   }
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);

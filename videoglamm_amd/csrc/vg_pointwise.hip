@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const void* gu, void* y, in
     const int f = (int)(i - m * F);
     float g = ld_any(gu, m * 2 * F + f, dt);
     const float u = ld_any(gu, m * 2 * F + F + f, dt);
-    g = g / (1.0f + __expf(-g));
+    g = vg_silu(g);
     if (dt == VG_BF16) g = bf2f(f2bf(g));  // HF: act(gate) materialised in bf16 before the product
     st_any(y, i, dt, g * u);
   }
