@@ -54,21 +54,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// 0.5 * (1 + erf(z)) by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7, i.e. fp32 rounding level): ~14 VALU ops
-// instead of libm erff's ~40 — the exact-GELU epilogue of the Hiera / InternVideo2 fc1 GEMMs applies it to 4.4e9
-// elements per C1 clip.  For z < 0 the complement poly(t)*exp(-z^2) is used directly, so the tail keeps relative accuracy.
-__device__ __forceinline__ float vg_half_erfc_neg(float z) {
-  // r03: v_rcp_f32 / v_exp_f32 directly (1 ulp each, far inside the 1.5e-7 of the formula).  __frcp_rn is the CORRECTLY ROUNDED reciprocal:
-  // hipcc expands it into the full division sequence (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup + the denormal selects) —
-  // 10 of the ~22 instructions per GELU in the ISA of the fc1 epilogues, on kernels that are bound by instruction issue
-  const float a = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float q = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);   // 0.5 * erfc(|z|)
-  return z < 0.f ? q : 1.0f - q;
+// Exact (erf) GELU: x * Phi(x), Phi(x) = 0.5 * (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7, i.e. fp32 rounding
+// level) instead of libm erff's ~40 instructions — the fc1 epilogues of Hiera / InternVideo2 apply it to 22e9 elements per C2 clip, in kernels that
+// are bound by instruction issue.  r03, in two steps measured on the fc1 GEMMs:
+//   (1) v_rcp_f32 / v_exp_f32 directly (1 ulp each): the correctly rounded __frcp_rn expands to the IEEE division sequence, 10 of ~22 instructions;
+//   (2) everything in terms of x (the 1/sqrt 2 folded into the constants, 0.5 folded into the polynomial), exp2 argument c * x * x, and the branch
+//       "x < 0 ? q : 1 - q" as 0.5 + copysign(0.5 - q, x): one v_bfi instead of compare + select, and straight-line code the compiler packs into
+//       v_pk_fma_f32 / v_pk_mul_f32 pairs.  (0.5 - q loses the RELATIVE accuracy of Phi deep in the negative tail — absolute error of x * Phi(x)
+//       <= |x| * 6e-8 there, the rounding level of every other term; libm's erff: -DVG_LIBM_ERF.)
+__device__ __forceinline__ float vg_gelu_erf(float x) {
+  const float a = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, a, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float q = p * t * __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * x * x);   // 0.5 * erfc(|x| / sqrt 2)
+  const float phi = 0.5f + __builtin_copysignf(0.5f - q, x);
+  return x * phi;
 }
 
 // x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): ONE definition for every SwiGLU site (GEMM
@@ -81,7 +84,7 @@ __device__ __forceinline__ float vg_act(float x, int act) {
 #ifdef VG_LIBM_ERF
     case VG_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 #else
-    case VG_ACT_GELU: return x * vg_half_erfc_neg(x * 0.70710678118654752440f);
+    case VG_ACT_GELU: return vg_gelu_erf(x);
 #endif
     case VG_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case VG_ACT_RELU: return x > 0.f ? x : 0.f;
