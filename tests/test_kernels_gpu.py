@@ -45,9 +45,14 @@ def test_gemm(cuda, dtype, M, N, K):
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2)
     bias, gamma = rnd(N, seed=3), rnd(N, seed=4)
     res = rnd(M, N, dtype=dtype, seed=5)
-    for act in (ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU, ops.ACT_QUICK_GELU):
+    # every activation with LayerScale + residual (only "none" has a straight-line epilogue variant there: the others take the general path) ...
+    for act in (ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU, ops.ACT_QUICK_GELU, ops.ACT_SILU, ops.ACT_SIGMOID):
         y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act, gamma.to(cuda), res.to(cuda))
         close(y, ref.linear(x, w, bias, act, gamma, res), **tol(dtype, K))
+    # ... and bias + activation alone (the epilogues the model runs: GELU / quick-GELU / ReLU variants, SiLU / sigmoid through the general path)
+    for act in (ops.ACT_GELU, ops.ACT_RELU, ops.ACT_QUICK_GELU, ops.ACT_SILU, ops.ACT_SIGMOID):
+        y = ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), act)
+        close(y, ref.linear(x, w, bias, act), **tol(dtype, K))
     y = ops.linear(x.to(cuda), w.to(cuda))
     close(y, ref.linear(x, w), **tol(dtype, K))
     if dtype == torch.bfloat16:
