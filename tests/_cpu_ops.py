@@ -294,9 +294,13 @@ def bilinear(x, Ho, Wo):
     return F.interpolate(x[:, None].float(), size=(Ho, Wo), mode="bilinear", align_corners=False)[:, 0]
 
 
-def upsample2_add(lateral, top):
+def upsample2_add(lateral, top, out=None):
     up = top.float().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
-    return (lateral.float() + up).to(lateral.dtype)
+    y = (lateral.float() + up).to(lateral.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 # ---- mask post-processing / evaluation counts: the numpy restatement (oracle/postproc.py) behind the same signatures

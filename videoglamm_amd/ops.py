@@ -672,12 +672,14 @@ def bilinear_mask(x, Ho, Wo):
     return out
 
 
-def upsample2_add(lateral, top):
+def upsample2_add(lateral, top, out=None):
     lib = _lib.load()
     lateral = lateral.contiguous()
     top = top.contiguous()
     B, H, W, C = top.shape
-    out = torch.empty_like(lateral)
+    if out is None:
+        out = torch.empty_like(lateral)
+    assert out.is_contiguous() and out.shape == lateral.shape and out.dtype == lateral.dtype
     _lib.check(lib.vg_upsample2_add(_p(lateral), _p(top), _p(out), B, H, W, C, _dt(top), _stream()), "vg_upsample2_add")
     return out
 

@@ -86,9 +86,16 @@ class SAM2:
         """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
         frames = list(range(images.shape[0])) if frames is None else frames
         out = {}
-        for c0 in range(0, len(frames), self.frame_chunk):
+        # ONE buffer per level for all requested frames: the chunks' last kernels write straight into their rows, so consecutive frames stay
+        # consecutive views across chunk borders and the consumers' batches (_stack_views) never copy (r03: a 32-pair mask-decoder batch over two
+        # 16-frame chunks cat 268 MB of FPN levels per C2 clip)
+        S, n = self.S, len(frames)
+        bufs = [torch.empty(n, S // 4, S // 4, 32, dtype=self.dtype, device=self.device), torch.empty(n, S // 8, S // 8, 64, dtype=self.dtype, device=self.device),
+                torch.empty(n, S // 16, S // 16, 256, dtype=self.dtype, device=self.device)]
+        for c0 in range(0, n, self.frame_chunk):
             fr = frames[c0:c0 + self.frame_chunk]
-            fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr])
+            fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr],
+                                     out=[b[c0:c0 + len(fr)] for b in bufs])
             for j, t in enumerate(fr):
                 out[t] = [f[j:j + 1] for f in fpn]
         return out
@@ -161,7 +168,7 @@ class SAM2:
         hmid = self.lin(p + "mlp.layers.0", self.ln(p + "norm2", x, 1e-6), act=ops.ACT_GELU)
         return self.lin(p + "mlp.layers.1", hmid, residual=x)
 
-    def forward_image(self, img):
+    def forward_image(self, img, out=None):
         """SAM2Base.forward_image (Hiera + FpnNeck scalp=1 + conv_s0/s1) — R/modeling/sam2_base.py:465-477,
         backbones/image_encoder.py:29-42,101-133.  img: [B,3,S,S] (any float dtype, NCHW like the reference's
         preprocessing emits) -> fpn = [[B,S/4,S/4,32], [B,S/8,S/8,64], [B,S/16,S/16,256]] channels-last."""
@@ -180,14 +187,18 @@ class SAM2:
             if i in self.stage_ends:
                 feats.append(x)
         n = len(feats) - 1
+        dst = out                                   # optional [B, ...] destination per returned level (hiera_frames' clip-wide buffers)
         out, prev = [None] * len(feats), None
         for i in range(n, -1, -1):
-            lat = self.lin(f"image_encoder.neck.convs.{n - i}.conv", feats[i])
-            prev = ops.upsample2_add(lat, prev) if (i in (2, 3) and prev is not None) else lat
+            top_dst = dst[2] if (dst is not None and i == 2) else None      # level 2 is returned as the neck makes it
+            if i in (2, 3) and prev is not None:
+                prev = ops.upsample2_add(self.lin(f"image_encoder.neck.convs.{n - i}.conv", feats[i]), prev, out=top_dst)
+            else:
+                prev = self.lin(f"image_encoder.neck.convs.{n - i}.conv", feats[i], out=top_dst)
             out[i] = prev
         out = out[:-1]
-        out[0] = self.lin("sam_mask_decoder.conv_s0", out[0])
-        out[1] = self.lin("sam_mask_decoder.conv_s1", out[1])
+        out[0] = self.lin("sam_mask_decoder.conv_s0", out[0], out=None if dst is None else dst[0])
+        out[1] = self.lin("sam_mask_decoder.conv_s1", out[1], out=None if dst is None else dst[1])
         return out
 
     def vision_pos(self):
