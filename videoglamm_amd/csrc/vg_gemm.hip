@@ -136,7 +136,7 @@ __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v, int nt 
 // pass wait for the previous pass's stores — loads and stores share vmcnt on gfx9) cost 90 of the GEMM's 287 us.  Here: every
 // residual load of the block is requested before its first store, the staged tile is read with two ds_read_b128 per row, the
 // activation and the presence of a residual are compile-time constants (one switch per block, epi_dispatch).
-template <typename TO, int ACT, bool RES, int NP, int ES, int RPP = 8>
+template <typename TO, int ACT, bool RES, int NP, int ES, int RPP = 8, bool GAM = true>
 __device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws, int m0, int n0, int cg, int rsub,
                                               const float (&bv)[8], const float (&gv)[8], TO* C, const TO* R) {
   int64_t mo[NP];
@@ -169,8 +169,9 @@ __device__ __forceinline__ void epi_rows_fast(const GemmArgs& p, const float* ws
     float v[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[e] = vg_act(x0[e] + bv[e], ACT) * gv[e];
-      v[4 + e] = vg_act(x1[e] + bv[4 + e], ACT) * gv[4 + e];
+      v[e] = vg_act(x0[e] + bv[e], ACT);
+      v[4 + e] = vg_act(x1[e] + bv[4 + e], ACT);
+      if constexpr (GAM) { v[e] *= gv[e]; v[4 + e] *= gv[4 + e]; }        // LayerScale: only the (none, residual) variant carries it
     }
     TO* cp = C + mo[ps] * p.ldc + n0;
     if constexpr (sizeof(TO) == 2) {
@@ -202,18 +203,25 @@ template <int V> struct epi_ic { static constexpr int value = V; };
 // without residual (SiLU / sigmoid / activation + residual epilogues: the mask decoder's IoU head on > 16 rows, nothing else) — 5 variants per
 // kernel instead of 12.  Speed-neutral on C2 (Hiera 110.2 / 109.7 -> 109.9 / 110.1 ms same-box), vg_gemm.hip compiles in 1 min instead of 2.5.
 template <typename F>
-__device__ __forceinline__ bool epi_dispatch(int act, bool res, F&& f) {
+__device__ __forceinline__ bool epi_dispatch(int act, bool res, bool gam, F&& f) {
+  // LayerScale (gamma) comes with "no activation + residual" only (InternVideo2's ls1 / ls2, the memory encoder's fuser): that variant alone
+  // multiplies by it; the others do not carry the 8 multiplies per 8 outputs
+  if (gam) {
+    if (act != VG_ACT_NONE || !res) return false;
+    f(epi_ic<0>{}, epi_ic<1>{}, epi_ic<1>{});
+    return true;
+  }
 #define VG_EPI_CASE(A) \
   case A:              \
     if (res) return false; \
-    f(epi_ic<A>{}, epi_ic<0>{}); \
+    f(epi_ic<A>{}, epi_ic<0>{}, epi_ic<0>{}); \
     return true;
   switch (act) {
     VG_EPI_CASE(VG_ACT_GELU)
     VG_EPI_CASE(VG_ACT_QUICK_GELU)
     VG_EPI_CASE(VG_ACT_RELU)
     case VG_ACT_NONE:
-      if (res) f(epi_ic<0>{}, epi_ic<1>{}); else f(epi_ic<0>{}, epi_ic<0>{});
+      if (res) f(epi_ic<0>{}, epi_ic<1>{}, epi_ic<0>{}); else f(epi_ic<0>{}, epi_ic<0>{}, epi_ic<0>{});
       return true;
     default:
       return false;
@@ -305,8 +313,8 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
       gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
     }
     if (!p.sa && n0w + 64 <= N &&     // (wave-uniform) whole 16-byte groups, no fp8 scales: the straight-line form
-        epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
-          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 8, ES>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
+        epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
+          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 8, ES, 8, decltype(gam)::value != 0>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
         }))
       return;
 #pragma unroll
@@ -612,8 +620,8 @@ __device__ __forceinline__ void gemm_epilogue64x32(const GemmArgs& p, f32x16_t (
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
     vg_lds_barrier();
-    if (fast && epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
-          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES>(p, ws, m0w + i * 32, n0, cg, rsub, bv, gv, C, R);
+    if (fast && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
+          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES, 8, decltype(gam)::value != 0>(p, ws, m0w + i * 32, n0, cg, rsub, bv, gv, C, R);
         }))
       return;
 #pragma unroll
@@ -1303,8 +1311,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
         }
         return;
       }
-      if (fast && epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
-            epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES>(p, ws, mrow, n0, cg, rsub, bv, gv, C, R);
+      if (fast && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
+            epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES, 8, decltype(gam)::value != 0>(p, ws, mrow, n0, cg, rsub, bv, gv, C, R);
           }))
         return;
 #pragma unroll 1
@@ -1498,8 +1506,8 @@ __global__ __launch_bounds__(256) void gemm_small64_kernel(GemmArgs p) {
     bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
     gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
   }
-  if (n0w + 32 <= N && epi_dispatch(p.act, R != nullptr, [&](auto act, auto res) {
-        epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
+  if (n0w + 32 <= N && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
+        epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16, decltype(gam)::value != 0>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
       }))
     return;
   for (int ps = 0; ps < 2; ++ps) {                     // the last N tile of a ragged N (N % 8 == 0 still holds: vec_out)

@@ -38,6 +38,28 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def graph_capture(g):
+    """torch.cuda.graph(g) with Python's cyclic garbage collector held off for the duration of the capture.  A capture of the decode step or of
+    the SAM2 propagation creates tens of thousands of Python objects, so a generation-2 collection WILL run inside it in a long-lived process —
+    and if that collection finalises device objects of an earlier clip that sit in reference cycles (an evicted CUDAGraph, events), the runtime
+    calls their destructors make are illegal while a stream is capturing and abort the process (seen r03: tests/test_kernels_gpu.py's graph
+    tests followed by an end-to-end capture in one process)."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def _f32(t):
     if t is None:
         return None

@@ -465,7 +465,7 @@ class SAM2:
             st_emb.copy_(text_embeds)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with ops.graph_capture(g):      # (thread-local capture mode, cyclic GC held off: ops.graph_capture)
                 out = self.video_branch(images, st_emb, video_hw, frame_feats=st_feats, as_masks=as_masks)
             ent = (g, st_feats, st_emb, out)
         graphs[key] = ent                       # (re-inserted last: most recently used)

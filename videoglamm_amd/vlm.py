@@ -365,7 +365,7 @@ class LlamaDecoder:
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: in multi-GPU runs the RCCL watchdog thread of torch.distributed polls events of
                 # finished collectives; under the default (global) mode such a call from another thread can invalidate the capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with ops.graph_capture(g):      # (thread-local capture mode, cyclic GC held off: ops.graph_capture)
                     self._decode_step()
                 self.graph = g
                 self.tok_dev.copy_(snap_tok)
