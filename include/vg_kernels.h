@@ -145,6 +145,24 @@ int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const flo
                         void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
                         float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream);
 
+/* vg_decode_layer (r03): everything of a decoder layer behind the q|k|v projection as ONE launch — vg_decode_attention, then
+ *   y_o = attn_out . Wo^T + resid (vg_decode_gemv), and when Wgu != NULL also act = SwiGLU(RMSNorm(y_o; norm_w, eps) . Wgu^T) and
+ *   y = act . Wdown^T + y_o.  The GEMV workgroups request their weight rows before the row they multiply exists and wait for it on
+ *   device-side arrival counters (csrc/vg_decode.hip: decode_layer_kernel), so the weight stream no longer idles behind the
+ *   latency-bound attention and between the GEMVs.  Results are bit-identical to the separate calls.  The same zero-filled
+ *   workspace as vg_decode_attention; flags: vg_decode_layer_flag_ints() ints, 128-byte aligned, zero-filled by the caller before
+ *   EVERY launch (one memset per token over the regions of all layers); word [1] != 0 afterwards = a device-side wait gave up.
+ *   vg_decode_layer_roles: 0 = shape not covered (use the separate calls), 1 = attention + o_proj
+ *   (pass Wgu = NULL), 3 = the MLP as well.  HF LlamaDecoderLayer.forward at q_len = 1 (R/model/VideoGLaMM.py:616-628 via generate). */
+int vg_decode_layer_roles(int H, int Hkv, int D, int hidden, int inter, int dtype);
+int64_t vg_decode_layer_flag_ints(void);
+int vg_decode_layer(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin, void* attn_out,
+                    int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
+                    float* workspace, int64_t ws_floats, int32_t* flags,
+                    const void* Wo, int64_t ldo, const void* resid, void* y_o,
+                    const float* norm_w, float eps, const void* Wgu, int64_t ldgu, void* act,
+                    const void* Wdown, int64_t lddown, void* y, int hidden, int inter, int dtype, vg_stream_t stream);
+
 /* ---- row normalisation -------------------------------------------------------------------------
  * LayerNorm over the last dim (biased variance, two-pass fp32): nn.LayerNorm and LayerNorm2d
  * (R/model/segment_anything_2/sam2/modeling/sam2_utils.py:137-149 — channels-last makes them identical).

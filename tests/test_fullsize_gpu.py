@@ -70,6 +70,34 @@ def test_llama3_8b_width_prefill_decode_bf16(cuda):
     assert clear.sum() >= 10 and bool(agree[clear].all()), (int(clear.sum()), float(agree.float().mean()))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_decode_chain_launch_equals_separate(cuda, dt, monkeypatch):
+    """the opt-in chained layer launch (VG_DECODE_CHAIN=3: attention, o_proj and the MLP as roles of one grid that hand rows over through
+    device-side flags, vg_decode_layer) inside the decoder: 5 teacher-forced rows after a 300-row prefill, hidden states bit-identical to the
+    separate launches, through the graph-replayed step as well."""
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    S, G = 300, 5
+    c, sd, x = _llama2(cuda, S + G)
+    P = Params({k: v.float() if dt == torch.float32 else v for k, v in sd.items()}, cuda, dt)
+    got = {}
+    for chain in ("0", "3"):
+        monkeypatch.setenv("VG_DECODE_CHAIN", chain)
+        dec = LlamaDecoder(P, c, 1024, use_graph=False)
+        assert dec.chain_roles == (0 if chain == "0" else (3 if dt == torch.bfloat16 else 1))
+        dec.forward(x[:S].to(cuda, dt))
+        rows = []
+        for i in range(G):
+            rows.append(dec._layers_decode(x[S + i:S + i + 1].to(cuda, dt)))
+            dec.pos += 1
+            dec.pos_dev.fill_(dec.pos)
+        got[chain] = torch.cat(rows)
+        if chain != "0":
+            assert int(dec.chain_flags[:, 1].sum()) == 0          # no device-side wait gave up
+        del dec
+    assert torch.isfinite(got["0"]).all() and torch.equal(got["0"], got["3"])
+
+
 def test_sam2_large_frame_bf16_vs_oracle(cuda):
     """ONE full-size frame through Hiera-L + FPN + the mask decoder (framewise branch, 2 objects, 1024^2 input, masks at
     480x640): fp32 parity mode vs the CPU oracle on logits, bf16 mode vs the oracle on masks (mIoU as

@@ -156,6 +156,43 @@ def test_decode_attention(cuda, dtype, H, Hkv, D, max_len):
     assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0   # arrival counters reset themselves
 
 
+@pytest.mark.parametrize("dtype,H,Hkv,D,inter", [(torch.bfloat16, 32, 8, 128, 14336), (torch.bfloat16, 32, 8, 128, 11008), (torch.float32, 32, 8, 128, 14336),
+                                                   (torch.bfloat16, 32, 32, 96, 8192)])
+def test_decode_layer_chain(cuda, dtype, H, Hkv, D, inter):
+    """vg_decode_layer (attention, o_proj and the MLP as roles of one launch that wait on device-side arrival counters) moves no bit against
+    the separate launches, at split boundaries and long caches, replayed on ONE workspace; its counters end at zero, no wait gave up."""
+    from videoglamm_amd import ops
+    hidden, max_len = H * D, 4096
+    roles = ops.decode_layer_roles(H, Hkv, D, hidden, inter, dtype)
+    assert roles == (3 if (dtype == torch.bfloat16 and D == 128 and inter == 14336) else 1)
+    assert ops.decode_layer_roles(8, 2, 64, 512, 1024, dtype) == 0
+    kc, vc = rnd(max_len, Hkv, D, dtype=dtype, seed=2), rnd(max_len, Hkv, D, dtype=dtype, seed=3)
+    ang = torch.arange(max_len)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, D, 2).float() / D)))[None]
+    g_cos, g_sin = ang.cos().to(cuda), ang.sin().to(cuda)
+    w_o = rnd(hidden, hidden, dtype=dtype, seed=4, scale=hidden ** -0.5).to(cuda)
+    w_gu = rnd(2 * inter, hidden, dtype=dtype, seed=5, scale=hidden ** -0.5).to(cuda)
+    w_d = rnd(hidden, inter, dtype=dtype, seed=6, scale=inter ** -0.5).to(cuda)
+    nw = (1.0 + 0.1 * rnd(hidden, seed=7)).to(cuda)
+    ws_a = ops.decode_attention_workspace(H, Hkv, D, max_len, cuda)
+    ws_b = ops.decode_attention_workspace(H, Hkv, D, max_len, cuda)
+    flags = ops.decode_layer_flags(2, cuda)
+    for pos in (0, 63, 64, 1700, 3400, max_len - 1):
+        qkv = rnd(1, (H + 2 * Hkv) * D, dtype=dtype, seed=10 + pos).to(cuda)
+        x = rnd(1, hidden, dtype=dtype, seed=20 + pos).to(cuda)
+        pos_dev = torch.tensor([pos], dtype=torch.int32, device=cuda)
+        a_kc, a_vc, b_kc, b_vc = kc.to(cuda), vc.to(cuda), kc.to(cuda), vc.to(cuda)
+        o = ops.decode_attention(qkv, a_kc, a_vc, g_cos, g_sin, H, Hkv, D, pos_dev, D ** -0.5, ws_a)
+        y_o = ops.decode_gemv(o, w_o, residual=x)
+        flags.zero_()
+        got = ops.decode_layer(qkv, b_kc, b_vc, g_cos, g_sin, H, Hkv, D, pos_dev, D ** -0.5, ws_b, flags[0], w_o, x)
+        assert torch.equal(got, y_o) and torch.equal(a_kc, b_kc) and torch.equal(a_vc, b_vc)
+        if roles == 3:
+            y = ops.decode_gemv(ops.decode_gemv(y_o, w_gu, norm_w=nw, eps=1e-5, glu=True), w_d, residual=y_o)
+            got = ops.decode_layer(qkv, b_kc, b_vc, g_cos, g_sin, H, Hkv, D, pos_dev, D ** -0.5, ws_b, flags[1], w_o, x, mlp=(nw, 1e-5, w_gu, w_d))
+            assert torch.equal(got, y)
+        assert int(ws_b[-Hkv:].view(torch.int32).abs().sum()) == 0 and int(flags[:, 1].sum()) == 0   # per-head tickets reset; no wait gave up
+
+
 def test_gemm_small64_routing_and_batch(cuda):
     """the small-problem kernel is what runs the memory-attention projections (vg_gemm_route == 5), batched launches included."""
     from videoglamm_amd import _lib, ops

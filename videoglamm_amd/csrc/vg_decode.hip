@@ -425,6 +425,10 @@ extern "C" int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y
 // trip), RoPE of q and of the new k runs while they are in flight, the workgroup that owns position `pos` appends the
 // new k/v rows to the cache, and the last workgroup of a KV head to finish merges the per-split (max, sum, acc)
 // partials — ordering by an agent-scope arrival counter that resets itself, so the launch is graph-replayable.
+// vg_decode_layer's flag region (ints; 32-int = 128-byte lines so that no two hot words share one): line 0 = [0] KV heads merged, [1] a wait gave up;
+// lines 4 + 16 r + s = arrival stripe s of GEMV role r; lines 36 + r = the stripes of role r completed; lines 40 + 64 b + i = go flag i of boundary b
+constexpr int DEC_LINE = 32, DEC_STRIPES = 16, DEC_GO = 64;
+constexpr int DEC_CHAIN_INTS = (40 + 3 * DEC_GO) * DEC_LINE;
 struct DecAttnArgs {
   const void* qkv; void* kc; void* vc; const float* cs; const float* sn; void* o;
   float* ws; int* cnt; const int* pos_dev;
@@ -439,16 +443,26 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_store_dword sc1 (write-through)
 }
 
+template <typename TO> __device__ __forceinline__ float ld_agent_elt(const TO* p);
+template <> __device__ __forceinline__ float ld_agent_elt<float>(const float* p) { return ld_agent(p); }
+template <> __device__ __forceinline__ float ld_agent_elt<bf16_t>(const bf16_t* p) {
+  return bf2f(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));       // global_load_ushort sc1
+}
+template <typename TO> __device__ __forceinline__ void st_agent_elt(TO* p, float v);
+template <> __device__ __forceinline__ void st_agent_elt<float>(float* p, float v) { st_agent(p, v); }
+template <> __device__ __forceinline__ void st_agent_elt<bf16_t>(bf16_t* p, float v) {
+  __hip_atomic_store(p, f2bf(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_store_short sc1
+}
+
 // DT = compile-time head_dim (0 = run-time p.D): with it every load loop below has a constant trip count, so the
 // kernel is straight-line up to the first wait and the compiler's vmcnt bookkeeping stays exact.
-template <typename T, int G, int DT>
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
+// AG (decode_layer_kernel): the merged output row leaves write-through (sc1) and *done is bumped once per KV head after it — the
+// o_proj workgroups of the same launch wait on that counter and read the row with sc1 loads.
+template <typename T, int G, int DT, bool AG>
+__device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s, const int kvh, char* dec_smem, int& ticket, int* done) {
   constexpr int KPC = 16 / sizeof(T);
   constexpr int L = 64;
-  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
-  __shared__ int ticket;
   const int pos = *p.pos_dev;
-  const int s = blockIdx.x, kvh = blockIdx.y;
   const int active = pos / L + 1;
   const int lo = p.window > 0 ? max(0, pos + 1 - p.window) : 0;     // first visible position
   const int first = lo / L;                                         // first split with a visible key
@@ -689,9 +703,27 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      if (oo[k] < G * D) vg_elt<T>::st(out + (int64_t)(kvh * G + og[k]) * D + od[k], num[k] * ms[og[k]]);
+      if (oo[k] < G * D) {
+        if constexpr (AG) st_agent_elt<T>(out + (int64_t)(kvh * G + og[k]) * D + od[k], num[k] * ms[og[k]]);
+        else vg_elt<T>::st(out + (int64_t)(kvh * G + og[k]) * D + od[k], num[k] * ms[og[k]]);
+      }
   }
   if (tid == 0) __hip_atomic_store(&p.cnt[kvh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (AG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ticket = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket == p.Hkv - 1 && tid < DEC_GO)        // every head's row is in memory: release the o_proj workgroups (64 flags, 8 pollers each)
+      __hip_atomic_store(done + (40 + tid) * DEC_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename T, int G, int DT>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+  __shared__ int ticket;
+  dec_attn_body<T, G, DT, false>(p, blockIdx.x, blockIdx.y, dec_smem, ticket, nullptr);
 }
 
 template <typename T, int G, int DT>
@@ -754,4 +786,329 @@ extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache
   DecAttnArgs p{qkv, k_cache, v_cache, cos, sin, out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale, window};
   if (dtype == VG_BF16) return launch_decode_attn<bf16_t>(p, H / Hkv, (hipStream_t)stream);
   return launch_decode_attn<float>(p, H / Hkv, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launch per decoder layer behind the q|k|v projection (r03): attention, o_proj (+ residual), and — bf16 Llama
+// widths — RMSNorm + gate|up + SwiGLU and down_proj (+ residual) as ROLES of one grid.  A workgroup's role follows
+// from its index, roles are laid out in dependency order, and the dispatcher hands out workgroups in index order, so
+// every workgroup a waiting one depends on is already running: a GEMV workgroup requests its first two batches of
+// weight rows (16 x 16 bytes per lane — all of its rows for o_proj / down_proj), THEN waits for the producer role,
+// then reads the input row with sc1 loads.  What the separate launches serialised — the weight stream's ramp behind
+// the latency-bound attention, and each GEMV's ramp behind the previous one's tail — now overlaps.  Arithmetic
+// (order of every sum) is the separate kernels': results are bit-identical.
+// Hand-off: a producer workgroup stores sc1 (write-through) -> s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope
+// add on one of 16 arrival stripes (own 128-byte lines: 512 simultaneous arrivals on ONE word serialise at the
+// memory side); who completes a stripe adds to the role's counter, who completes that raises 64 go flags (own lines);
+// a consumer workgroup polls go flag (index % 64) with one lane, s_sleep between polls (first version: every waiting
+// workgroup polled the word next to the attention tickets — the pollers starved the tickets, +17 us per layer), then
+// barrier -> sc1 loads (MI355X_MICROARCH.md, valid hand-off forms: the one the split merge above uses).  The wait is
+// bounded: after ~0.5 s a workgroup sets the gave-up word and carries on (wrong numbers the host reports, not a hung
+// queue).  The caller zero-fills the flag region before every launch (one memset per token for all layers).
+struct DecRoleArgs {
+  DecGemvArgs g;
+  int nblocks;
+};
+struct DecLayerArgs {
+  DecAttnArgs a;
+  DecRoleArgs r[3];     // o_proj, gate|up, down
+  int nroles;           // 1: attention + o_proj; 3: + the MLP
+  int* flags;
+};
+
+__device__ __forceinline__ void dec_chain_wait(int* flags, const int boundary, const int wg) {
+  if (threadIdx.x == 0) {
+    const int* go = flags + (40 + boundary * DEC_GO + (wg & (DEC_GO - 1))) * DEC_LINE;
+    int spins = 0;
+    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1 << 20)) {
+        __hip_atomic_store(flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  asm volatile("" ::: "memory");
+}
+
+// thread 0 of a finished workgroup of role r (n workgroups): true for the one arrival that completes the role
+__device__ __forceinline__ bool dec_chain_arrive(int* flags, const int r, const int wg, const int n) {
+  const int st = wg & (DEC_STRIPES - 1);
+  const int in_stripe = (n - st + DEC_STRIPES - 1) / DEC_STRIPES;
+  if (__hip_atomic_fetch_add(flags + (4 + DEC_STRIPES * r + st) * DEC_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_stripe - 1) return false;
+  const int nst = min(n, DEC_STRIPES);
+  return __hip_atomic_fetch_add(flags + (36 + r) * DEC_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nst - 1;
+}
+
+// dec_gemv_store for a role: the residual row was written by another role of this launch (sc1 loads: this XCD's L2 may hold the line from an earlier
+// launch); AGST: somebody in this launch reads y (sc1 stores)
+template <typename T, typename TO, bool GLU, bool AGST>
+__device__ __forceinline__ void dec_gemv_store_ag(const DecGemvArgs& p, int pi, float a0, float a1) {
+  const int n0 = GLU ? pi : 2 * pi, n1 = GLU ? p.N + pi : 2 * pi + 1;
+  TO* y = (TO*)p.y;
+  const TO* R = (const TO*)p.R;
+  auto put = [&](int n, float v) {
+    if (R) v += ld_agent_elt<TO>(R + n);
+    if constexpr (AGST) st_agent_elt<TO>(y + n, v);
+    else vg_elt<TO>::st(y + n, v);
+  };
+  if constexpr (GLU) {
+    float g = a0, u = a1;
+    if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
+    g = vg_silu(g);
+    if (sizeof(T) == 2) g = bf2f(f2bf(g));
+    put(n0, g * u);
+  } else {
+    put(n0, a0);
+    if (n1 < p.N) put(n1, a1);
+  }
+}
+
+// decode_gemv_fast_kernel's body as role `role` (0..2): weights first, wait on boundary `role`, x by sc1 loads; `release`: raise boundary role + 1
+template <typename T, typename TO, bool GLU, bool NORM, int NB, int CPB>
+__device__ __forceinline__ void dec_gemv_role(const DecGemvArgs& p, const int wg, const int nwg, char* dec_smem, float* red, float (*res)[DEC_MAX_PPW][2],
+                                               int* flags, const int role, const bool release, int& bcast) {
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int NWV = KPC / 4;
+  constexpr int NCH = NB * CPB * 64;
+  constexpr int XN = (NCH + 255) / 256;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t* xs = (u32x4_t*)dec_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npair = GLU ? p.N : (p.N + 1) / 2;
+  const int gw = wg * 4 + wave;
+  const T* W = (const T*)p.W;
+  const int p0 = gw * p.ppw;
+  const int np = max(min(p0 + p.ppw, npair) - p0, 0);
+  const int total = np * NB;
+
+  // ---- 1. the weights (and the norm weights: constants of the layer) before the input row exists
+  int ipi = p0, icb = 0;
+  u32x4_t va0[CPB], va1[CPB], vb0[CPB], vb1[CPB];
+  auto issue = [&](u32x4_t (&v0)[CPB], u32x4_t (&v1)[CPB]) {
+    const int pc = min(ipi, npair - 1);
+    const int n0 = GLU ? pc : 2 * pc;
+    const int n1 = GLU ? p.N + pc : min(2 * pc + 1, p.N - 1);
+    const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw) + icb * (64 * CPB) + lane;
+    const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw) + icb * (64 * CPB) + lane;
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+      v0[u] = __builtin_nontemporal_load(w0 + u * 64);
+      v1[u] = __builtin_nontemporal_load(w1 + u * 64);
+    }
+    if (++icb == NB) { icb = 0; ++ipi; }
+  };
+  issue(va0, va1);
+  issue(vb0, vb1);
+  f32x4_t nwr[NORM ? XN : 1][NWV];
+  if constexpr (NORM) {
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+#pragma unroll
+      for (int j = 0; j < NWV; ++j) nwr[i][j] = ((const f32x4_t*)p.nw)[min(tid + 256 * i, NCH - 1) * NWV + j];
+  }
+
+  // ---- 2. the producer role's row
+  dec_chain_wait(flags, role, wg);
+  u32x4_t xr[XN];
+#pragma unroll
+  for (int i = 0; i < XN; ++i) {
+    const uint32_t* src = (const uint32_t*)p.x + (int64_t)min(tid + 256 * i, NCH - 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    float rstd = 1.f;
+    if constexpr (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        float f[KPC];
+        dec_unpack<T>(xr[i], f);
+        if (tid + 256 * i < NCH) {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) ss += f[e] * f[e];
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        float f[KPC];
+        dec_unpack<T>(xr[i], f);
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) f[e] = dec_round<T>(f[e] * rstd) * nwr[i][e / 4][e % 4];
+        xr[i] = dec_pack<T>(f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+      if (tid + 256 * i < NCH) xs[tid + 256 * i] = xr[i];
+    __syncthreads();
+  }
+
+  // ---- 3. the stream (decode_gemv_fast_kernel's)
+  float a0 = 0.f, a1 = 0.f;
+  int cpl = 0, ccb = 0;
+  auto consume = [&](const u32x4_t (&v0)[CPB], const u32x4_t (&v1)[CPB]) {
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+      const u32x4_t xv = xs[ccb * (64 * CPB) + u * 64 + lane];
+      a0 += dec_dot<T>(v0[u], xv);
+      a1 += dec_dot<T>(v1[u], xv);
+    }
+    if (++ccb == NB) {
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (lane == 0) { res[wave][cpl][0] = a0; res[wave][cpl][1] = a1; }
+      a0 = 0.f;
+      a1 = 0.f;
+      ccb = 0;
+      ++cpl;
+    }
+  };
+  int b = 0;
+  for (; b + 4 <= total; b += 2) {
+    consume(va0, va1);
+    issue(va0, va1);
+    consume(vb0, vb1);
+    issue(vb0, vb1);
+  }
+  const int rem = total - b;
+  if (rem == 3) {
+    consume(va0, va1);
+    issue(va0, va1);
+    consume(vb0, vb1);
+    consume(va0, va1);
+  } else if (rem == 2) {
+    consume(va0, va1);
+    consume(vb0, vb1);
+  } else if (rem == 1) {
+    consume(va0, va1);
+  }
+  // ---- 4. epilogue; a role somebody waits for leaves write-through and arrives
+  if (!release) {
+    for (int i = lane; i < np; i += 64) dec_gemv_store_ag<T, TO, GLU, false>(p, p0 + i, res[wave][i][0], res[wave][i][1]);
+    return;
+  }
+  for (int i = lane; i < np; i += 64) dec_gemv_store_ag<T, TO, GLU, true>(p, p0 + i, res[wave][i][0], res[wave][i][1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) bcast = dec_chain_arrive(flags, role, wg, nwg) ? 1 : 0;
+  __syncthreads();
+  if (bcast && tid < DEC_GO) __hip_atomic_store(flags + (40 + (role + 1) * DEC_GO + tid) * DEC_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// NBH / CPBH: batches x chunks of a hidden-size row (o_proj, gate|up); NBI: batches of an intermediate-size row (down_proj), 0 = no MLP roles
+template <typename T, int G, int DT, int NBH, int CPBH, int NBI>
+__global__ __launch_bounds__(256, 2) void decode_layer_kernel(DecLayerArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+  __shared__ int ticket;
+  __shared__ float red[4];
+  __shared__ float res[4][DEC_MAX_PPW][2];
+  int w = blockIdx.x;
+  const int nattn = q.a.nsplit * q.a.Hkv;
+  if (w < nattn) {
+    dec_attn_body<T, G, DT, true>(q.a, w % q.a.nsplit, w / q.a.nsplit, dec_smem, ticket, q.flags);
+    return;
+  }
+  w -= nattn;
+  if (w < q.r[0].nblocks) {
+    dec_gemv_role<T, T, false, false, NBH, CPBH>(q.r[0].g, w, q.r[0].nblocks, dec_smem, red, res, q.flags, 0, q.nroles > 1, ticket);
+    return;
+  }
+  if constexpr (NBI > 0) {
+    w -= q.r[0].nblocks;
+    if (w < q.r[1].nblocks) {
+      dec_gemv_role<T, T, true, true, NBH, CPBH>(q.r[1].g, w, q.r[1].nblocks, dec_smem, red, res, q.flags, 1, true, ticket);
+      return;
+    }
+    w -= q.r[1].nblocks;
+    dec_gemv_role<T, T, false, false, NBI, 4>(q.r[2].g, w, q.r[2].nblocks, dec_smem, red, res, q.flags, 2, false, ticket);
+  }
+}
+
+static int dec_role_blocks(int npair, int* ppw_out) {     // launch_decode_gemv's split
+  static const int bpc = [] { const char* e = getenv("VG_DEC_BPC"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+  const int maxw = 256 * bpc * 4;
+  int ppw = (npair + maxw - 1) / maxw;
+  for (int c = ppw; c <= 2 * ppw; ++c)
+    if (((npair + 4 * c - 1) / (4 * c)) % 256 == 0 && npair % (4 * c) == 0) { ppw = c; break; }
+  if (ppw > DEC_MAX_PPW) ppw = DEC_MAX_PPW;
+  *ppw_out = ppw;
+  return (npair + 4 * ppw - 1) / (4 * ppw);
+}
+
+// 0: not available for this shape; 1: attention + o_proj; 3: + the MLP roles
+extern "C" int vg_decode_layer_roles(int H, int Hkv, int D, int hidden, int inter, int dtype) {
+  if (H <= 0 || Hkv <= 0 || H % Hkv || (int64_t)H * D != hidden) return 0;
+  if (dtype == VG_BF16 && H / Hkv == 4 && D == 128 && hidden == 4096) return inter == 14336 ? 3 : 1;   // Llama-3-8B widths
+  if (dtype == VG_F32 && H / Hkv == 4 && D == 128 && hidden == 4096) return 1;                          // fp32 mode of the same
+  if (dtype == VG_BF16 && H == Hkv && D == 96 && hidden == 3072) return 1;                              // Phi-3-mini
+  return 0;
+}
+extern "C" int64_t vg_decode_layer_flag_ints(void) { return DEC_CHAIN_INTS; }
+
+template <typename T, int G, int DT, int NBH, int CPBH, int NBI>
+static int launch_decode_layer(const DecLayerArgs& q, int blocks, size_t lds, hipStream_t st) {
+  static size_t lds_cap = 64 * 1024;
+  if (lds > lds_cap) {
+    (void)hipFuncSetAttribute((const void*)decode_layer_kernel<T, G, DT, NBH, CPBH, NBI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_cap = lds;
+  }
+  decode_layer_kernel<T, G, DT, NBH, CPBH, NBI><<<blocks, 256, lds, st>>>(q);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_decode_layer(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin, void* attn_out,
+                               int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
+                               float* workspace, int64_t ws_floats, int32_t* flags,
+                               const void* Wo, int64_t ldo, const void* resid, void* y_o,
+                               const float* norm_w, float eps, const void* Wgu, int64_t ldgu, void* act,
+                               const void* Wdown, int64_t lddown, void* y, int hidden, int inter, int dtype, vg_stream_t stream) {
+  VG_CHECK(qkv && k_cache && v_cache && cos && sin && attn_out && pos_dev && workspace && flags && Wo && resid && y_o, VG_ERR_ARG, "vg_decode_layer: null pointer");
+  const int roles = vg_decode_layer_roles(H, Hkv, D, hidden, inter, dtype);
+  const int want = Wgu ? 3 : 1;
+  VG_CHECK(roles >= want, VG_ERR_UNSUPPORTED, "vg_decode_layer: H=%d Hkv=%d D=%d hidden=%d inter=%d dtype=%d: %d role(s) available, %d asked for",
+           H, Hkv, D, hidden, inter, dtype, roles, want);
+  VG_CHECK(want == 1 || (norm_w && Wdown && act && y), VG_ERR_ARG, "vg_decode_layer: the MLP roles need norm_w, Wgu, Wdown, act, y");
+  VG_CHECK(window >= 0 && max_len > 0, VG_ERR_ARG, "vg_decode_layer: bad window / max_len");
+  const int es = dtype == VG_BF16 ? 2 : 4, kpc = 16 / es;
+  VG_CHECK(ldo % kpc == 0 && (!Wgu || (ldgu % kpc == 0 && lddown % kpc == 0)), VG_ERR_ARG, "vg_decode_layer: weight row strides must be multiples of %d", kpc);
+  VG_CHECK((((uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)Wo | (uintptr_t)Wgu | (uintptr_t)Wdown | (uintptr_t)norm_w | (uintptr_t)attn_out |
+             (uintptr_t)y_o | (uintptr_t)act) & 15) == 0 && ((uintptr_t)flags & 127) == 0, VG_ERR_ARG, "vg_decode_layer: alignment (16 bytes; flags 128)");
+  const int64_t need = vg_decode_attention_ws_floats(H, Hkv, D, max_len);
+  VG_CHECK(ws_floats >= need, VG_ERR_ARG, "vg_decode_layer: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
+  const int nsplit = (max_len + 63) / 64;
+  VG_CHECK(nsplit <= 128, VG_ERR_UNSUPPORTED, "vg_decode_layer: max_len %d > 8192", max_len);
+  DecLayerArgs q{};
+  q.a = DecAttnArgs{qkv, k_cache, v_cache, cos, sin, attn_out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale, window};
+  q.flags = flags;
+  q.nroles = want;
+  int ppw = 1;
+  q.r[0].nblocks = dec_role_blocks((hidden + 1) / 2, &ppw);
+  q.r[0].g = DecGemvArgs{attn_out, Wo, y_o, nullptr, resid, hidden, hidden, ldo, 0.f, ppw, nullptr};
+  int blocks = nsplit * Hkv + q.r[0].nblocks;
+  if (want == 3) {
+    q.r[1].nblocks = dec_role_blocks(inter, &ppw);
+    q.r[1].g = DecGemvArgs{y_o, Wgu, act, norm_w, nullptr, inter, hidden, ldgu, eps, ppw, nullptr};
+    q.r[2].nblocks = dec_role_blocks((hidden + 1) / 2, &ppw);
+    q.r[2].g = DecGemvArgs{act, Wdown, y, nullptr, y_o, hidden, inter, lddown, 0.f, ppw, nullptr};
+    blocks += q.r[1].nblocks + q.r[2].nblocks;
+  }
+  const int G = H / Hkv, KP = 256 / (D / kpc);
+  size_t lds = sizeof(float) * ((size_t)G * D + 2 * D + 4 * G * 64 + G * 64 + 2 * G + 4 + (size_t)KP * G * D);
+  const size_t xbytes = (size_t)(want == 3 ? inter : hidden) * es;
+  if (xbytes > lds) lds = xbytes;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VG_BF16 && D == 128) {
+    if (want == 3) return launch_decode_layer<bf16_t, 4, 128, 2, 4, 7>(q, blocks, lds, st);
+    return launch_decode_layer<bf16_t, 4, 128, 2, 4, 0>(q, blocks, lds, st);
+  }
+  if (dtype == VG_BF16) return launch_decode_layer<bf16_t, 1, 96, 3, 2, 0>(q, blocks, lds, st);
+  return launch_decode_layer<float, 4, 128, 4, 4, 0>(q, blocks, lds, st);
 }

@@ -424,6 +424,43 @@ def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale,
     return out
 
 
+def decode_layer_roles(H, Hkv, D, hidden, inter, dtype):
+    """0 / 1 / 3: which roles vg_decode_layer covers for this shape (0: use decode_attention + decode_gemv)."""
+    return int(_lib.load().vg_decode_layer_roles(H, Hkv, D, hidden, inter, F32 if dtype == torch.float32 else BF16))
+
+
+def decode_layer_flags(n_layers, device):
+    """[n_layers, vg_decode_layer_flag_ints()] int32 zeros: one flag region per layer; the caller zero-fills ALL of it once per token."""
+    return torch.zeros(n_layers, int(_lib.load().vg_decode_layer_flag_ints()), dtype=torch.int32, device=device)
+
+
+def decode_layer(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, flags, w_o, resid, window=0, mlp=None):
+    """vg_decode_layer: attention + o_proj (+ residual) and, with mlp = (norm_w fp32, eps, W gate|up [2I,hidden], W down [hidden,I]), the
+    whole MLP as roles of one launch.  flags: one row of decode_layer_flags(), zeroed since its last use.  -> the layer's output row [1, hidden] (mlp) or the post-attention row (mlp=None)."""
+    lib = _lib.load()
+    assert qkv.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and pos_dev.dtype == torch.int32
+    assert w_o.stride(1) == 1 and resid.is_contiguous() and flags.dtype == torch.int32 and flags.is_contiguous()
+    hidden = w_o.shape[0]
+    o = torch.empty(1, H * D, dtype=qkv.dtype, device=qkv.device)
+    y_o = torch.empty(1, hidden, dtype=qkv.dtype, device=qkv.device)
+    if mlp is None:
+        nw, eps, wgu, wd, act, y, inter = None, 0.0, None, None, None, None, 0
+    else:
+        nw, eps, wgu, wd = mlp
+        inter = wd.shape[1]
+        assert wgu.shape == (2 * inter, hidden) and wgu.stride(1) == 1 and wd.stride(1) == 1 and nw.dtype == torch.float32
+        act = torch.empty(1, inter, dtype=qkv.dtype, device=qkv.device)
+        y = torch.empty(1, hidden, dtype=qkv.dtype, device=qkv.device)
+    rc = lib.vg_decode_layer(_p(qkv), _p(k_cache), _p(v_cache), _p(_f32(cos)), _p(_f32(sin)), _p(o), H, Hkv, D, k_cache.shape[0],
+                             int(window), float(scale), _p(pos_dev), _p(ws), ws.numel(), _p(flags),
+                             _p(w_o), w_o.stride(0), _p(resid), _p(y_o),
+                             _p(nw), float(eps), _p(wgu), wgu.stride(0) if wgu is not None else 0, _p(act),
+                             _p(wd), wd.stride(0) if wd is not None else 0, _p(y),
+                             hidden, inter, _dt(qkv), _stream())
+    _lib.check(rc, "vg_decode_layer")
+    return y_o if mlp is None else y
+
+
 def store_row_(src, dst, idx_dev, idx_off=0):
     """dst[*idx_dev + idx_off] = src (one row), index read on the device."""
     lib = _lib.load()

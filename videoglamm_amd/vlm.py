@@ -212,6 +212,14 @@ class LlamaDecoder:
                              and self.hd % (16 // es) == 0 and self.hd * es <= 512 and max_len <= 8192
                              and max(self.D, ffn) * es <= 65536 and self.D % (16 // es) == 0 and ffn % (16 // es) == 0)
         assert self.fused_decode or not self.w8, "fp8 decode weights need the fused decode kernels"
+        # vg_decode_layer: which roles of a layer run as one chained launch.  VG_DECODE_CHAIN=1 (attention + o_proj) / 3 (+ the MLP); default 0 =
+        # separate launches: measured on C2 the chained launch only ties (27.4 us vs 20.1 + 8.0; 85.4 vs 84.7 for the whole layer — every
+        # device-side hand-off is a fabric round trip, as the launch boundary it replaces is)
+        self.chain_roles, self.chain_flags = 0, None
+        if self.fused_decode and dev.type == "cuda":
+            self.chain_roles = min(ops.decode_layer_roles(self.H, self.Hkv, self.hd, self.D, ffn, dt), int(os.environ.get("VG_DECODE_CHAIN", "0")))
+            if self.chain_roles == 2:
+                self.chain_roles = 1
 
     def reset(self):
         self.pos = 0
@@ -263,15 +271,32 @@ class LlamaDecoder:
         P, c = self.P, self.c
         if self.attn_ws is None:
             self.attn_ws = ops.decode_attention_workspace(self.H, self.Hkv, self.hd, self.max_len, x.device)
+        if self.chain_roles:
+            if self.chain_flags is None:
+                self.chain_flags = ops.decode_layer_flags(c["num_layers"], x.device)
+            self.chain_flags.zero_()          # one memset per token: every layer's arrival stripes and go flags
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
             qkv_names = [l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"]
             gu_names = [l + "mlp.gate_proj", l + "mlp.up_proj"]
             wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
             qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
-            o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
-                                     self.pos_dev, self.hd ** -0.5, self.attn_ws, window=self.window)
-            x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
+            if self.chain_roles:
+                # r03: attention, o_proj and (bf16 Llama widths) the MLP as roles of ONE launch whose GEMV workgroups fetch their weight
+                # rows while the producer role still runs (vg_decode_layer) — bit-identical to the separate launches below
+                w_o = P.w(l + "self_attn.o_proj")
+                if self.chain_roles == 3 and not self.w8:
+                    wgu, _ = P.fused(gu_names, stored=l + "mlp.gate_up_proj")
+                    x = ops.decode_layer(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, self.pos_dev, self.hd ** -0.5,
+                                         self.attn_ws, self.chain_flags[i], w_o, x, window=self.window,
+                                         mlp=(P.f32(l + "post_attention_layernorm.weight"), c["rms_eps"], wgu, P.w(l + "mlp.down_proj")))
+                    continue
+                x = ops.decode_layer(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd, self.pos_dev, self.hd ** -0.5,
+                                     self.attn_ws, self.chain_flags[i], w_o, x, window=self.window)
+            else:
+                o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
+                                         self.pos_dev, self.hd ** -0.5, self.attn_ws, window=self.window)
+                x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
             if self.w8:
                 # fp8 weights + row scales for the MLP (81 % of a layer's bytes) — the attention projections stay bf16: at K = 4096
                 # an fp8 row is a single batch of loads per lane and the per-row reduction eats the gain (10.4 vs 9.1 us measured)
