@@ -77,6 +77,9 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #ifndef VG_ATTN_PREFETCH
 #define VG_ATTN_PREFETCH 1
 #endif
+#ifndef VG_ATTN_QREG
+#define VG_ATTN_QREG 1
+#endif
 #ifndef VG_ATTN_MINW
 #define VG_ATTN_MINW 2
 #endif
@@ -249,6 +252,15 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   };
   constexpr bool PF = VG_ATTN_PREFETCH;
   if (PF && kv_begin < kv_end) fetch(kv_begin);
+  // QREG (bf16, head dim <= 128): the wave's Q fragments stay in registers for the whole KV walk — one of every five LDS reads of a tile
+  // (NG of 5 NG per 64 keys) was the same Q bytes again, and the loop is LDS-read-bound at eight waves per CU
+  constexpr bool QREG = VG_ATTN_QREG && sizeof(T) == 2 && DP <= 128;
+  u32x4_t qreg[QREG ? NG : 1];
+  if constexpr (QREG) {
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qreg[g] = *(const u32x4_t*)(qrow + g * 32);
+  }
   for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
     if (!PF) fetch(kv0);
     __syncthreads();
@@ -270,18 +282,18 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       u32x4_t kf[2][NKT], qf[2];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) kf[0][kt] = *(const u32x4_t*)(krow0 + kt * 32 * RS);
-      qf[0] = *(const u32x4_t*)qrow;
+      if constexpr (!QREG) qf[0] = *(const u32x4_t*)qrow;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int cur = g & 1, nxt = cur ^ 1;
         if (g + 1 < NG) {
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt) kf[nxt][kt] = *(const u32x4_t*)(krow0 + kt * 32 * RS + (g + 1) * 32);
-          qf[nxt] = *(const u32x4_t*)(qrow + (g + 1) * 32);
+          if constexpr (!QREG) qf[nxt] = *(const u32x4_t*)(qrow + (g + 1) * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) AMma<T>::qk(kf[cur][kt], qf[cur], s[kt]);
+        for (int kt = 0; kt < NKT; ++kt) AMma<T>::qk(kf[cur][kt], QREG ? qreg[g] : qf[cur], s[kt]);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
