@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON the GPU box (gpurun -- 'bash tools/collect_profiles.sh TAG [all|kt|pmc|mfma|bench]'): the bench lines and rocprofv3 passes that
 # profiles/ is made from.  Outputs under gpurun_out/TAG_*.
-#   bench: bench.py defaults (C2 framewise, quality + cpu_baseline included)            -> TAG_bench.json
+#   bench: bench.py defaults (C2 framewise, quality + cpu_baseline included), run AFTER the traces -> TAG_bench.json
 #   kt:    TWO kernel traces of `bench.py --steps 3 --warmup 1 --no-roofline ...` (4 passes each, nothing else in the process):
 #          the timed stream configuration (Hiera on its side stream)                     -> TAG_kt_overlapped.txt / .json
 #          VG_HIERA_START=serial VG_TOWERS_OVERLAP=0 (the instrumented pass's config)    -> TAG_kt_serial.txt / .json
@@ -18,10 +18,6 @@ db() { find "$1" -name '*.db' | head -1; }
 has() { [ $ONLY = all ] || [ $ONLY = $1 ]; }
 
 ONLY=${2:-all}
-if has bench; then
-python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-tail -c 900 $O/${TAG}_bench.json
-fi
 BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality --no-roofline"
 PASSES=4
 if has kt || has mfma; then
@@ -42,6 +38,13 @@ for MODE in overlapped serial; do
   rm -rf $O/${TAG}_kt_$MODE $O/${TAG}_mfma_$MODE
 done
 unset VG_HIERA_START VG_TOWERS_OVERLAP
+fi
+if has bench; then
+# after the traces: the line quotes profiles/${TAG}_kt_*.json (frac_trace_*, mfma_busy_frac_*), so the traces of THIS call (same box, same build) go
+# into the box's copy of profiles/ first
+for MODE in overlapped serial; do [ -f $O/${TAG}_kt_$MODE.json ] && cp $O/${TAG}_kt_$MODE.json $R/profiles/; done
+python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+tail -c 900 $O/${TAG}_bench.json
 fi
 if has pmc; then
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality"
