@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoglamm_amd import ops
 def t(fn, n=10):
     fn(); torch.cuda.synchronize()

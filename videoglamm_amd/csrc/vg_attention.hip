@@ -80,6 +80,9 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #ifndef VG_ATTN_QREG
 #define VG_ATTN_QREG 1
 #endif
+#ifndef VG_ATTN_VTR
+#define VG_ATTN_VTR 1
+#endif
 #ifndef VG_ATTN_MINW
 #define VG_ATTN_MINW 2
 #endif
@@ -105,6 +108,11 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   constexpr int NDT = DP / 32;
   constexpr int NKT = BKV / 32 / KS;   // 32-key sub-tiles of a KV tile this wave multiplies
   static_assert(KS == 1 || (KS == 2 && BKV == 64 && sizeof(T) == 2), "key split: two waves per 64-key bf16 tile");
+  // VTR (bf16, head dim <= 128 = the PIPE path): V goes to LDS as it comes (padded rows, like K) and the PV step's V^T fragments are read with
+  // ds_read_b64_tr_b16 — the transposing staging pass (≈ 80 bit-shuffle VALU instructions per thread and tile in a VALU-bound loop) is gone.
+  // Row stride: the 16 lanes of a transpose read touch 4 rows x 4 column quads of 8 bytes; rows must land 8 banks apart
+  constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
+  constexpr int RSV = DP * ES + (DP == 128 ? 32 : 16);
   char* Qs = smem;
   char* Ks = Qs + BQ * RS;
   char* Vs = Ks + BKV * RS;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   }
   // K/V staging: a tile is fetched into registers one iteration ahead (the loads of tile t+1 are in flight while
   // tile t is multiplied), then written to LDS — K as padded rows, V (bf16) transposed for pv_step_bf16t
-  constexpr bool VT = sizeof(T) == 2;
+  constexpr bool VT = sizeof(T) == 2 && !VTR;
   static_assert(!VT || BKV == 64, "the transposed V image assumes 64-key tiles");
   constexpr int NKI = (BKV * CPR + NT - 1) / NT;                 // K chunks per thread per tile
   constexpr int NVI = VT ? (16 * CPR + NT - 1) / NT : NKI;       // V items per thread: (key quad, chunk) | chunks
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       const int idx = tid + i * NT, row = idx / CPR, c = idx - row * CPR;
       if (idx < BKV * CPR) {
         *(u32x4_t*)(Ks + row * RS + c * 16) = kreg[i];
-        if constexpr (!VT) *(u32x4_t*)(Vs + row * RS + c * 16) = vreg[i];
+        if constexpr (!VT) *(u32x4_t*)(Vs + row * (VTR ? RSV : RS) + c * 16) = vreg[i];
       }
     }
     if constexpr (VT) {
@@ -329,28 +337,39 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
           mx = fmaxf(mx, v);
         }
     } else {
+      // no mask: the scale is positive, so the maximum is taken over the raw scores (v_max3) and scale and shift ride in ONE fma per score in front of
+      // the exponential below — 16 + 32 VALU instructions per 32 scores instead of 32 + 32 + 32 (multiply, maximum, subtract)
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = s[kt][r] * sl2;
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx *= sl2;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_i, mx);                       // log2 units
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = exp2f(m_i - m_safe);
     float rs = 0.f;
+    if (need_mask) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_safe);
-        s[kt][r] = pv;
-        rs += pv;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_safe);
+          s[kt][r] = pv;
+          rs += pv;
+        }
+    } else {
+      const float nm = -m_safe;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, nm));
+          s[kt][r] = pv;
+          rs += pv;
+        }
+    }
     rs += __shfl_xor(rs, 32, 64);
     l_i = l_i * alpha + rs;
     m_i = m_new;
@@ -370,9 +389,24 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) pb[t][jj] = f2bf2(s[t >> 1][(t & 1) * 8 + jj * 2], s[t >> 1][(t & 1) * 8 + jj * 2 + 1]);
       u32x4_t vf[2][NDT];
+      // VTR: lane i of a 16-lane group hands ds_read_b64_tr_b16 the 8-byte piece (key row i >> 2, column quad i & 3) of a 4-key x 16-column
+      // block and receives column i of it = 4 keys of ONE head-dim column (tools/lab/tr_probe.hip); the MFMA A operand of 16-key step t wants
+      // the keys whose P values this lane's accumulator registers hold: 16 t + 4 h + {0..3} and 16 t + 8 + 4 h + {0..3} -> two reads
+      const char* vtr = Vs + (4 * h + ((lane & 15) >> 2)) * RSV + ((((lane >> 4) & 1) * 16 + 4 * (lane & 3)) << 1);
       auto vread = [&](int t, int dt) -> u32x4_t {
-        const int d = dt * 32 + l31;
-        return *(const u32x4_t*)(Vs + d * 128 + ((((kh * NKT + (t >> 1)) * 4 + (t & 1) * 2 + h) ^ ((d >> 1) & 7)) << 4));
+        if constexpr (VTR) {
+          typedef short s16x4_t __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+          const char* a = vtr + ((kh * NKT + (t >> 1)) * 32 + (t & 1) * 16) * RSV + dt * 64;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)a);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + 8 * RSV));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          const u32x4_t v = {l2.x, l2.y, h2.x, h2.y};
+          return v;
+        } else {
+          const int d = dt * 32 + l31;
+          return *(const u32x4_t*)(Vs + d * 128 + ((((kh * NKT + (t >> 1)) * 4 + (t & 1) * 2 + h) ^ ((d >> 1) & 7)) << 4));
+        }
       };
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) vf[0][dt] = vread(0, dt);
@@ -484,7 +518,9 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 template <typename T, int DP, int BKV, int NW, int KS = 1>
 static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RS = DP * sizeof(T) + 16;
-  constexpr int vbytes = sizeof(T) == 2 ? DP * 128 : BKV * RS;   // bf16: transposed V image, DP rows of 64 keys
+  constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
+  constexpr int RSV = DP * (int)sizeof(T) + (DP == 128 ? 32 : 16);
+  constexpr int vbytes = VTR ? BKV * RSV : (sizeof(T) == 2 ? DP * 128 : BKV * RS);   // bf16, head dim 256: transposed V image, DP rows of 64 keys
   constexpr int BQ = NW / KS * 32;
   constexpr int lds = (BQ + BKV) * RS + vbytes;
   static_assert(KS == 1 || lds >= (NW / KS) * (DP / 32 * 16 + 2) * 64 * 4, "the key-half merge reuses the tile buffers");
