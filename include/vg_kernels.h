@@ -137,13 +137,16 @@ int vg_add_int(int* p, int v, vg_stream_t stream);
  *   rotate-half RoPE (cos/sin tables [max_len, D/2]) to q and k, appends k/v to the caches ([max_len,Hkv,D]) and writes
  *   softmax(q.K[lo..p]^T * scale).V[lo..p] to out [H*D], lo = window > 0 ? max(0, p + 1 - window) : 0 (window = number of
  *   visible positions, the new one included; 0 = the whole cache).  workspace: fp32, vg_decode_attention_ws_floats() floats, must be
- *   zero-filled ONCE by the caller before the first launch (it ends with self-resetting per-head counters). */
+ *   zero-filled ONCE by the caller before the first launch (it ends with self-resetting per-head counters).  keys_per_wg: 0 / 64 =
+ *   one workgroup per 64 cache positions and KV head; 128 = a hint for long caches (>= ~2048 positions): two 64-key blocks per
+ *   workgroup, so half as many partial results are published and merged (same result up to fp32 summation order; honoured for the
+ *   bf16 Llama-3 / Phi-3 head shapes, ignored elsewhere). */
 int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y, const float* norm_w, float eps,
                    const void* R, int N, int K, int glu, int in_dtype, int out_dtype, vg_stream_t stream);
 int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_len);
 int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
                         void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
-                        float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream);
+                        float* workspace, int64_t ws_floats, int keys_per_wg, int dtype, vg_stream_t stream);
 
 /* vg_decode_layer (r03): everything of a decoder layer behind the q|k|v projection as ONE launch — vg_decode_attention, then
  *   y_o = attn_out . Wo^T + resid (vg_decode_gemv), and when Wgu != NULL also act = SwiGLU(RMSNorm(y_o; norm_w, eps) . Wgu^T) and

@@ -154,6 +154,20 @@ def test_decode_attention(cuda, dtype, H, Hkv, D, max_len):
         else:
             close(g_kc, u_kc, rtol=1e-6, atol=1e-6)
     assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0   # arrival counters reset themselves
+    # keys_per_wg = 128 (two 64-key blocks per workgroup; honoured for the bf16 Llama-3 / Phi-3 head shapes, the default kernel elsewhere): same
+    # answers at the block boundaries of both granularities, same appended rows, on its own replayed workspace
+    ws2 = ops.decode_attention_workspace(H, Hkv, D, max_len, cuda)
+    for pos in (0, 63, 64, 127, 128, 129, 191, 192, max_len // 2 + 5, max_len - 1):
+        if pos >= max_len:
+            continue
+        qkv = rnd(1, (H + 2 * Hkv) * D, dtype=dtype, seed=10 + pos).to(cuda)
+        pos_dev = torch.tensor([pos], dtype=torch.int32, device=cuda)
+        a_kc, a_vc, b_kc, b_vc = kc.to(cuda), vc.to(cuda), kc.to(cuda), vc.to(cuda)
+        o1 = ops.decode_attention(qkv, a_kc, a_vc, g_cos, g_sin, H, Hkv, D, pos_dev, D ** -0.5, ws)
+        o2 = ops.decode_attention(qkv, b_kc, b_vc, g_cos, g_sin, H, Hkv, D, pos_dev, D ** -0.5, ws2, keys_per_wg=128)
+        close(o2, o1, **(dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-3)))   # fp32 merge order; one bf16 ulp
+        assert torch.equal(a_kc, b_kc) and torch.equal(a_vc, b_vc)
+    assert int(ws2[-Hkv:].view(torch.int32).abs().sum()) == 0
 
 
 @pytest.mark.parametrize("dtype,H,Hkv,D,inter", [(torch.bfloat16, 32, 8, 128, 14336), (torch.bfloat16, 32, 8, 128, 11008), (torch.float32, 32, 8, 128, 14336),

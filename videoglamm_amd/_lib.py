@@ -38,7 +38,7 @@ def _sig(lib):
         "vg_decode_gemv": ([P, P, L, P, P, F, P, I, I, I, I, I, P], c_int),
         "vg_decode_gemv_w8": ([P, P, L, P, P, P, F, P, I, I, I, I, P], c_int),
         "vg_decode_attention_ws_floats": ([I, I, I, I], c_int64),
-        "vg_decode_attention": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, I, P], c_int),
+        "vg_decode_attention": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, I, I, P], c_int),
         "vg_decode_layer_roles": ([I, I, I, I, I, I], c_int),
         "vg_decode_layer_flag_ints": ([], c_int64),
         "vg_decode_layer": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, P, P, L, P, P, P, F, P, L, P, P, L, P, I, I, I, P], c_int),

@@ -458,10 +458,11 @@ template <> __device__ __forceinline__ void st_agent_elt<bf16_t>(bf16_t* p, floa
 // kernel is straight-line up to the first wait and the compiler's vmcnt bookkeeping stays exact.
 // AG (decode_layer_kernel): the merged output row leaves write-through (sc1) and *done is bumped once per KV head after it — the
 // o_proj workgroups of the same launch wait on that counter and read the row with sc1 loads.
-template <typename T, int G, int DT, bool AG>
+// LB = 64-key blocks per workgroup (2 at long caches: half as many partials to publish, arrive and merge — the merge then takes ONE pass of <= 32)
+template <typename T, int G, int DT, bool AG, int LB = 1>
 __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s, const int kvh, char* dec_smem, int& ticket, int* done) {
   constexpr int KPC = 16 / sizeof(T);
-  constexpr int L = 64;
+  constexpr int L = 64 * LB;
   const int pos = *p.pos_dev;
   const int active = pos / L + 1;
   const int lo = p.window > 0 ? max(0, pos + 1 - p.window) : 0;     // first visible position
@@ -482,8 +483,8 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
   float* knew = qs + G * D;           // [D] roped new k
   float* vnew = knew + D;             // [D]
   float* sp = vnew + D;               // [4 waves][G][64] partial scores
-  float* sc = sp + 4 * G * 64;        // [G][64] exp(score - max)
-  float* ms = sc + G * 64;            // [G] max | [G] sum
+  float* sc = sp + LB * 4 * G * 64;   // [G][LB][64] exp(score - max)      (sp: [LB][4 waves][G][64])
+  float* ms = sc + LB * G * 64;       // [G] max | [G] sum
   float* po = ms + 2 * G + ((4 - ((2 * G) & 3)) & 3);   // [KP][G][D] partial outputs
 
   // ---- 1. every global load up front, the early-needed (L2-resident) ones first: vmcnt retires in order
@@ -507,15 +508,19 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
   const int64_t rs = (int64_t)p.Hkv * D;
   const T* kb = (const T*)p.kc + ((int64_t)j0 * p.Hkv + kvh) * D;
   const T* vb = (const T*)p.vc + ((int64_t)j0 * p.Hkv + kvh) * D;
-  u32x4_t kreg[8], vreg[8];
-  {
-    const int jl = min(lane, nk - 1);
+  u32x4_t kreg[LB][8], vreg[LB][8];
+#pragma unroll
+  for (int sub = 0; sub < LB; ++sub) {
+    const int jl = min(sub * 64 + lane, nk - 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < NKI) kreg[i] = *(const u32x4_t*)(kb + jl * rs + min(wave + 4 * i, CH - 1) * KPC);
+      if (i < NKI) kreg[sub][i] = *(const u32x4_t*)(kb + jl * rs + min(wave + 4 * i, CH - 1) * KPC);
+  }
+#pragma unroll
+  for (int sub = 0; sub < LB; ++sub) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < NVI) vreg[i] = *(const u32x4_t*)(vb + min(kslot + KP * i, nk - 1) * rs + cidx * KPC);
+      if (i < NVI) vreg[sub][i] = *(const u32x4_t*)(vb + min(sub * 64 + kslot + KP * i, nk - 1) * rs + cidx * KPC);
   }
   // ---- 2. RoPE of the G query heads and of the new key; the new value row (vg_rope_kv_append arithmetic)
 #pragma unroll
@@ -553,8 +558,9 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
     }
   }
   // ---- 3. q.k: lane = key, wave w covers 16-byte chunks w, w+4, ... of the head dimension
-  {
-    const bool isnew = (j0 + lane == pos);
+#pragma unroll
+  for (int sub = 0; sub < LB; ++sub) {
+    const bool isnew = (j0 + sub * 64 + lane == pos);
     float part[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) part[g] = 0.f;
@@ -563,7 +569,7 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
       const int c = wave + 4 * i;
       if (i < NKI && c < CH) {
         float kf[KPC];
-        dec_unpack<T>(kreg[i], kf);
+        dec_unpack<T>(kreg[sub][i], kf);
         if (isnew) {
 #pragma unroll
           for (int e = 0; e < KPC; ++e) kf[e] = knew[c * KPC + e];
@@ -575,17 +581,30 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
       }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) sp[(wave * G + g) * 64 + lane] = part[g];
+    for (int g = 0; g < G; ++g) sp[((sub * 4 + wave) * G + g) * 64 + lane] = part[g];
   }
   __syncthreads();
   for (int g = wave; g < G; g += 4) {
-    float v = (sp[(0 * G + g) * 64 + lane] + sp[(1 * G + g) * 64 + lane] + sp[(2 * G + g) * 64 + lane] + sp[(3 * G + g) * 64 + lane]) * p.scale;
-    const bool seen = lane < nk && j0 + lane >= lo;
-    if (!seen) v = -INFINITY;
-    const float m = wave_max(v);
-    const float e = seen ? __expf(v - m) : 0.f;
-    const float l = wave_sum(e);
-    sc[g * 64 + lane] = e;
+    float v[LB];
+    bool seen[LB];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < LB; ++sub) {
+      const float* q4 = sp + (sub * 4 * G + g) * 64 + lane;
+      v[sub] = (q4[0] + q4[G * 64] + q4[2 * G * 64] + q4[3 * G * 64]) * p.scale;
+      seen[sub] = sub * 64 + lane < nk && j0 + sub * 64 + lane >= lo;
+      if (!seen[sub]) v[sub] = -INFINITY;
+      mx = fmaxf(mx, v[sub]);
+    }
+    const float m = wave_max(mx);
+    float es = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < LB; ++sub) {
+      const float e = seen[sub] ? __expf(v[sub] - m) : 0.f;
+      sc[(g * LB + sub) * 64 + lane] = e;
+      es += e;
+    }
+    const float l = wave_sum(es);
     if (lane == 0) { ms[g] = m; ms[G + g] = l; }
   }
   __syncthreads();
@@ -597,18 +616,20 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
 #pragma unroll
       for (int e = 0; e < KPC; ++e) acc[g][e] = 0.f;
 #pragma unroll
+    for (int sub = 0; sub < LB; ++sub)
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int j = kslot + KP * i;
-      if (i < NVI && vlive && j < nk) {
+      const int j = sub * 64 + kslot + KP * i;
+      if (i < NVI && vlive && kslot + KP * i < 64 && j < nk) {      // (KP does not divide 64 at head dim 96: the last row round overshoots the block)
         float vf[KPC];
-        dec_unpack<T>(vreg[i], vf);
+        dec_unpack<T>(vreg[sub][i], vf);
         if (j0 + j == pos) {
 #pragma unroll
           for (int e = 0; e < KPC; ++e) vf[e] = vnew[cidx * KPC + e];
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const float pj = sc[g * 64 + j];
+          const float pj = sc[g * LB * 64 + j];
 #pragma unroll
           for (int e = 0; e < KPC; ++e) acc[g][e] = fmaf(pj, vf[e], acc[g][e]);
         }
@@ -719,21 +740,21 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnArgs& p, const int s,
   }
 }
 
-template <typename T, int G, int DT>
+template <typename T, int G, int DT, int LB = 1>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dec_smem[];
   __shared__ int ticket;
-  dec_attn_body<T, G, DT, false>(p, blockIdx.x, blockIdx.y, dec_smem, ticket, nullptr);
+  dec_attn_body<T, G, DT, false, LB>(p, blockIdx.x, blockIdx.y, dec_smem, ticket, nullptr);
 }
 
-template <typename T, int G, int DT>
+template <typename T, int G, int DT, int LB = 1>
 static void launch_decode_attn_gd(const DecAttnArgs& p, dim3 grid, size_t lds, hipStream_t st) {
   static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap only when a shape needs it (never inside a replay)
   if (lds > lds_cap) {
-    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<T, G, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<T, G, DT, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_cap = lds;
   }
-  decode_attn_kernel<T, G, DT><<<grid, 256, lds, st>>>(p);
+  decode_attn_kernel<T, G, DT, LB><<<grid, 256, lds, st>>>(p);
 }
 
 template <typename T, int G>
@@ -744,11 +765,21 @@ static void launch_decode_attn_g(const DecAttnArgs& p, dim3 grid, size_t lds, hi
 }
 
 template <typename T>
-static int launch_decode_attn(const DecAttnArgs& p, int G, hipStream_t st) {
+static int launch_decode_attn(const DecAttnArgs& p, int G, int keys_per_wg, hipStream_t st) {
   constexpr int KPC = 16 / sizeof(T);
   const int KP = 256 / (p.D / KPC);
-  const size_t lds = sizeof(float) * ((size_t)G * p.D + 2 * p.D + 4 * G * 64 + G * 64 + 2 * G + 4 + (size_t)KP * G * p.D);
+  size_t lds = sizeof(float) * ((size_t)G * p.D + 2 * p.D + 4 * G * 64 + G * 64 + 2 * G + 4 + (size_t)KP * G * p.D);
   dim3 grid(p.nsplit, p.Hkv);
+  if constexpr (sizeof(T) == 2) {
+    // 128 keys per workgroup (the caller's hint for long caches): the two shapes the pipeline decodes with — Llama-3 (G = 4, d = 128), Phi-3 (MHA, d = 96)
+    if (keys_per_wg == 128 && ((G == 4 && p.D == 128) || (G == 1 && p.D == 96))) {
+      lds += sizeof(float) * (4 * G * 64 + G * 64);
+      if (G == 4) launch_decode_attn_gd<T, 4, 128, 2>(p, grid, lds, st);
+      else launch_decode_attn_gd<T, 1, 96, 2>(p, grid, lds, st);
+      VG_LAUNCH_CHECK();
+      return VG_OK;
+    }
+  }
   switch (G) {
     case 1: launch_decode_attn_g<T, 1>(p, grid, lds, st); break;
     case 2: launch_decode_attn_g<T, 2>(p, grid, lds, st); break;
@@ -770,8 +801,9 @@ extern "C" int64_t vg_decode_attention_ws_floats(int H, int Hkv, int D, int max_
 
 extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const float* cos, const float* sin,
                                    void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
-                                   float* workspace, int64_t ws_floats, int dtype, vg_stream_t stream) {
+                                   float* workspace, int64_t ws_floats, int keys_per_wg, int dtype, vg_stream_t stream) {
   VG_CHECK(qkv && k_cache && v_cache && cos && sin && out && pos_dev && workspace, VG_ERR_ARG, "vg_decode_attention: null pointer");
+  VG_CHECK(keys_per_wg == 0 || keys_per_wg == 64 || keys_per_wg == 128, VG_ERR_ARG, "vg_decode_attention: keys_per_wg %d not in {0, 64, 128}", keys_per_wg);
   VG_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && D > 0 && D % 2 == 0 && max_len > 0, VG_ERR_ARG,
            "vg_decode_attention: bad shape H=%d Hkv=%d D=%d max_len=%d", H, Hkv, D, max_len);
   VG_CHECK(dtype == VG_BF16 || dtype == VG_F32, VG_ERR_ARG, "vg_decode_attention: bad dtype %d", dtype);
@@ -784,8 +816,8 @@ extern "C" int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache
   const int nsplit = (max_len + 63) / 64;
   VG_CHECK(nsplit <= 128, VG_ERR_UNSUPPORTED, "vg_decode_attention: max_len %d > 8192", max_len);
   DecAttnArgs p{qkv, k_cache, v_cache, cos, sin, out, workspace, (int*)(workspace + (need - Hkv)), pos_dev, H, Hkv, D, nsplit, scale, window};
-  if (dtype == VG_BF16) return launch_decode_attn<bf16_t>(p, H / Hkv, (hipStream_t)stream);
-  return launch_decode_attn<float>(p, H / Hkv, (hipStream_t)stream);
+  if (dtype == VG_BF16) return launch_decode_attn<bf16_t>(p, H / Hkv, keys_per_wg, (hipStream_t)stream);
+  return launch_decode_attn<float>(p, H / Hkv, keys_per_wg, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

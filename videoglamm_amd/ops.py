@@ -412,14 +412,15 @@ def decode_attention_workspace(H, Hkv, D, max_len, device):
     return torch.zeros(n, dtype=torch.float32, device=device)
 
 
-def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0):
-    """Fused RoPE + KV append + attention of the one new token (vg_decode_attention): qkv [1,(H+2Hkv)*D] -> [1,H*D]."""
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0, keys_per_wg=0):
+    """Fused RoPE + KV append + attention of the one new token (vg_decode_attention): qkv [1,(H+2Hkv)*D] -> [1,H*D].
+    keys_per_wg=128: two 64-key blocks per workgroup (long caches: half the partials to merge)."""
     lib = _lib.load()
     assert qkv.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and pos_dev.dtype == torch.int32
     max_len = k_cache.shape[0]
     out = torch.empty(1, H * D, dtype=qkv.dtype, device=qkv.device)
     rc = lib.vg_decode_attention(_p(qkv), _p(k_cache), _p(v_cache), _p(_f32(cos)), _p(_f32(sin)), _p(out), H, Hkv, D, max_len,
-                                 int(window), float(scale), _p(pos_dev), _p(ws), ws.numel(), _dt(qkv), _stream())
+                                 int(window), float(scale), _p(pos_dev), _p(ws), ws.numel(), int(keys_per_wg), _dt(qkv), _stream())
     _lib.check(rc, "vg_decode_attention")
     return out
 

@@ -195,7 +195,8 @@ class LlamaDecoder:
         self.tok_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.hid_all = torch.empty(max_len, self.D, dtype=dt, device=dev)   # final-norm state of every position
         self.use_graph = (dev.type == "cuda") if use_graph is None else use_graph
-        self.graph = None
+        self.graph, self.graphs = None, {}
+        self.kpw, self.kpw_min = 0, int(os.environ.get("VG_DEC_KPW_MIN", "2048"))
         self.attn_ws = None
         es = 2 if dt == torch.bfloat16 else 4
         ffn = c.get("ffn") or params.t("model.layers.0.mlp.down_proj.weight").shape[1]
@@ -295,7 +296,7 @@ class LlamaDecoder:
                                      self.attn_ws, self.chain_flags[i], w_o, x, window=self.window)
             else:
                 o = ops.decode_attention(qkv, self.kc[i], self.vc[i], self.cos, self.sin, self.H, self.Hkv, self.hd,
-                                         self.pos_dev, self.hd ** -0.5, self.attn_ws, window=self.window)
+                                         self.pos_dev, self.hd ** -0.5, self.attn_ws, window=self.window, keys_per_wg=self.kpw)
                 x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
             if self.w8:
                 # fp8 weights + row scales for the MLP (81 % of a layer's bytes) — the attention projections stay bf16: at K = 4096
@@ -377,6 +378,10 @@ class LlamaDecoder:
 
     def decode_step(self):
         assert self.pos + 1 <= self.max_len
+        # long caches: two 64-key blocks per decode-attention workgroup (half the partials to publish, arrive and merge: the merge of a C2 prompt's
+        # 54 splits took two passes); a launch parameter, so each setting has its own captured graph.  VG_DEC_KPW_MIN = first position that uses it
+        self.kpw = 128 if self.pos >= self.kpw_min else 0
+        self.graph = self.graphs.get(self.kpw)
         if not self.use_graph:
             self._decode_step()
         else:
@@ -392,7 +397,7 @@ class LlamaDecoder:
                 # finished collectives; under the default (global) mode such a call from another thread can invalidate the capture
                 with ops.graph_capture(g):      # (thread-local capture mode, cyclic GC held off: ops.graph_capture)
                     self._decode_step()
-                self.graph = g
+                self.graph = self.graphs[self.kpw] = g
                 self.tok_dev.copy_(snap_tok)
                 self.pos_dev.copy_(snap_pos)
             self.graph.replay()
