@@ -206,7 +206,7 @@ def decode_attention_workspace(H, Hkv, D, max_len, device):
     return torch.zeros(1)
 
 
-def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0):
+def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale, ws, window=0, keys_per_wg=0):   # (keys_per_wg: a work split of the HIP kernel, no arithmetic meaning)
     qkv = qkv.clone()
     rope_kv_append_(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, 0, pos_dev)
     q = qkv[:, : H * D].view(1, 1, H, D)
