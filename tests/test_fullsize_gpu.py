@@ -98,6 +98,39 @@ def test_decode_chain_launch_equals_separate(cuda, dt, monkeypatch):
     assert torch.isfinite(got["0"]).all() and torch.equal(got["0"], got["3"])
 
 
+def test_decode_step_graphs_per_key_block_setting(cuda, monkeypatch):
+    """the graph-replayed decode step across the position where the attention switches to 128 keys per workgroup (VG_DEC_KPW_MIN): a 2-layer
+    Llama-3-8B-width decoder, 2040-row prompt, 16 teacher-forced tokens through decode_step() — positions 2040..2055, so both settings run, each from
+    its own captured graph — against the same steps with the switch disabled: hidden rows within bf16 summation noise, same greedy tokens."""
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.vlm import LlamaDecoder
+    S, G = 2040, 16
+    c, sd, x = _llama2(cuda, S)
+    P = Params(sd, cuda, torch.bfloat16)
+    toks = torch.randint(0, c["vocab"], (G,), generator=torch.Generator().manual_seed(11))
+    got = {}
+    for kmin in ("2048", "1000000"):
+        monkeypatch.setenv("VG_DEC_KPW_MIN", kmin)
+        dec = LlamaDecoder(P, c, 4096, use_graph=True)
+        dec.forward(x[:S].to(cuda))
+        rows, picks, used = [], [], set()
+        for i in range(G):
+            dec.tok_dev.fill_(int(toks[i]))
+            dec.decode_step()
+            used.add(dec.kpw)
+            rows.append(dec.hid_all[dec.pos - 1].clone())
+            picks.append(int(dec.tok_dev[0]))
+        assert used == ({0, 128} if kmin == "2048" else {0}) and len(dec.graphs) == len(used)
+        got[kmin] = (torch.stack(rows).float(), picks)
+        del dec
+    a, b = got["2048"][0], got["1000000"][0]
+    assert torch.isfinite(a).all()
+    assert torch.equal(a[:8], b[:8])                                   # positions below the switch: the same kernel, the same bits
+    rel = (a - b).norm(dim=1) / b.norm(dim=1)
+    assert rel.max() < 2e-2, float(rel.max())                          # above it: another fp32 merge order under bf16 activations
+    assert sum(p == q for p, q in zip(got["2048"][1], got["1000000"][1])) >= G - 1
+
+
 def test_sam2_large_frame_bf16_vs_oracle(cuda):
     """ONE full-size frame through Hiera-L + FPN + the mask decoder (framewise branch, 2 objects, 1024^2 input, masks at
     480x640): fp32 parity mode vs the CPU oracle on logits, bf16 mode vs the oracle on masks (mIoU as
