@@ -216,7 +216,7 @@ class LlamaDecoder:
         # vg_decode_layer: which roles of a layer run as one chained launch.  VG_DECODE_CHAIN=1 (attention + o_proj) / 3 (+ the MLP); default 0 =
         # separate launches: measured on C2 the chained launch only ties (27.4 us vs 20.1 + 8.0; 85.4 vs 84.7 for the whole layer — every
         # device-side hand-off is a fabric round trip, as the launch boundary it replaces is)
-        self.chain_roles, self.chain_flags = 0, None
+        self.chain_roles, self.chain_flags, self.chain_err = 0, None, None
         if self.fused_decode and dev.type == "cuda":
             self.chain_roles = min(ops.decode_layer_roles(self.H, self.Hkv, self.hd, self.D, ffn, dt), int(os.environ.get("VG_DECODE_CHAIN", "0")))
             if self.chain_roles == 2:
@@ -275,6 +275,8 @@ class LlamaDecoder:
         if self.chain_roles:
             if self.chain_flags is None:
                 self.chain_flags = ops.decode_layer_flags(c["num_layers"], x.device)
+                self.chain_err = torch.zeros((), dtype=torch.int32, device=x.device)
+            self.chain_err.add_(self.chain_flags[:, 1].sum())      # the previous token's gave-up words survive the memset below (generate() checks)
             self.chain_flags.zero_()          # one memset per token: every layer's arrival stripes and go flags
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
@@ -476,6 +478,9 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
         if nxt in eos or step == max_new_tokens - 1:
             break
         dec.decode_step()
+    if dec.chain_roles and dec.chain_flags is not None and int(dec.chain_err) + int(dec.chain_flags[:, 1].sum()):
+        # VG_DECODE_CHAIN: a workgroup of a chained layer launch stopped waiting for its producer role (bounded wait) — the ids above are not to be trusted
+        raise ops._lib.VGKernelError("vg_decode_layer: a device-side wait gave up (flags[1] set); rerun with VG_DECODE_CHAIN=0")
     out_ids = torch.tensor(ids, dtype=torch.int64)
     # seg_token_mask = (output_ids[:,1:] == seg) left-padded by `added` (VideoGLaMM.py:630-633,803-806):
     # the row picked for a [SEG] at output position j is j-1+added, i.e. the state that emitted it
