@@ -80,7 +80,7 @@ class SAM2:
         # batches fill the tails of the 128-tile grids) and per framewise mask-decoder launch group (its GEMMs are M = 4096 rows
         # per (frame, object): the more pairs per launch the better)
         self.frame_chunk = int(os.environ.get("VG_FRAME_CHUNK", "16"))
-        self.decode_chunk = int(os.environ.get("VG_DECODE_CHUNK", "32"))
+        self.decode_chunk = int(os.environ.get("VG_DECODE_CHUNK", "128"))
 
     def hiera_frames(self, images, frames=None):
         """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
