@@ -706,4 +706,8 @@ def test_decode_attention_sliding_window(cuda, dtype, H, Hkv, D, max_len, window
         ops.rope_kv_append_(u_qkv, kc.to(cuda), vc.to(cuda), cos.to(cuda), sin.to(cuda), H, Hkv, D, 0, pos_dev.to(cuda))
         o2 = ops.attention_decode(u_qkv[:, : H * D].view(1, 1, H, D), g_kc, g_vc, pos_dev.to(cuda), D ** -0.5, window=window)
         close(o2.view(1, H * D), o, **t)
+        # the window under 128 keys per workgroup (first visible block, partially visible blocks at both granularities)
+        o3 = ops.decode_attention(qkv.to(cuda), kc.to(cuda), vc.to(cuda), cos.to(cuda), sin.to(cuda), H, Hkv, D, pos_dev.to(cuda), D ** -0.5, ws,
+                                  window=window, keys_per_wg=128)
+        close(o3, o, **(dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-3)))
     assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0
