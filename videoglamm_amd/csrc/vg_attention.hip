@@ -965,6 +965,7 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
            "vg_attention: bad shape B=%d Hq=%d Hkv=%d Sq=%d Skv=%d", B, Hq, Hkv, Sq, Skv);
   VG_CHECK(D > 0 && D <= 256 && D % 8 == 0, VG_ERR_ARG, "vg_attention: head dim %d unsupported (multiple of 8, <= 256)", D);
   VG_CHECK(dtype == VG_F32 || dtype == VG_BF16, VG_ERR_ARG, "vg_attention: bad dtype %d", dtype);
+  VG_CHECK(scale > 0.f, VG_ERR_ARG, "vg_attention: scale %g must be positive (the running maximum is taken over the raw scores)", (double)scale);
   const int kpc = dtype == VG_BF16 ? 8 : 4;
   VG_CHECK(q_ss % kpc == 0 && q_sh % kpc == 0 && q_sb % kpc == 0 && k_ss % kpc == 0 && k_sh % kpc == 0 &&
                k_sb % kpc == 0 && v_ss % kpc == 0 && v_sh % kpc == 0 && v_sb % kpc == 0,
