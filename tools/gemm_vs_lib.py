@@ -19,11 +19,16 @@ shapes = [("c2 llm qkv", 3361, 6144, 4096), ("c2 llm o", 3361, 4096, 4096), ("c2
           ("hiera s3 qkv", 65536, 1728, 576), ("hiera s3 proj", 65536, 576, 576), ("hiera s3 fc1", 65536, 2304, 576), ("hiera s3 fc2", 65536, 576, 2304),
           ("hiera s4 qkv", 16384, 3456, 1152), ("hiera s4 fc1", 16384, 4608, 1152), ("hiera s4 fc2", 16384, 1152, 4608),
           ("square 8k", 8192, 8192, 8192)]
+if os.environ.get("VG_BENCH_SHAPES"):
+    shapes = [s for s in shapes if any(t in s[0] for t in os.environ["VG_BENCH_SHAPES"].split(","))]
 for name, M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    ms = t(lambda: ops.linear(a, w, out=out))
-    ml = t(lambda: F.linear(a, w))
+    # interleaved rounds, best of each (box drift between two single runs is larger than most kernel effects)
+    ms, ml = 1e9, 1e9
+    for _ in range(int(os.environ.get("VG_BENCH_ROUNDS", "3"))):
+        ms = min(ms, t(lambda: ops.linear(a, w, out=out)))
+        ml = min(ml, t(lambda: F.linear(a, w)))
     fl = 2 * M * N * K
     print(f"{name:14s} M={M:8d} N={N:6d} K={K:6d}  ours {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s | lib {ml*1e3:8.1f} us {fl/ml/1e9:7.1f} TF/s  ratio {ml/ms:.2f}", flush=True)
