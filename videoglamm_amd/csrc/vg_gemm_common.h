@@ -91,6 +91,10 @@ __device__ __forceinline__ i32x8_t f8_operand(const u32x4_t& lo, const u32x4_t& 
 #define VG_EPI_ST 0
 #endif
 __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v, int nt = 0) {
+#if defined(P8_ABL) && P8_ABL == 3
+  asm volatile("" ::"v"(v), "v"(ptr));
+  return;      // ablation build: no output stores
+#endif
 #if VG_EPI_ST == 1
   __builtin_nontemporal_store(v, (u32x4_t*)ptr);
 #elif VG_EPI_ST == 2

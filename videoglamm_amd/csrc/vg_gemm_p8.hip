@@ -28,135 +28,280 @@ constexpr int P8_HALF = 16 * 1024;
 
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// Epilogue: wave-private LDS transposes, no workgroup barrier.  The MFMAs run as D^T = W . A^T (operands swapped), so a lane owns ONE output row
+// (l31) and, per 32-column fragment, four groups g of four CONSECUTIVE columns 8 g + 4 h + {0..3}: bias / activation / LayerScale are applied in
+// that layout (the lane's 32 bias values are loaded once per tile), a group is packed to 8 bytes of bf16 (16 bytes of fp32 where a residual or an
+// fp32 output needs the unrounded value) and written with ONE ds_write_b64 / b128 into the wave's own 4 KB slab above the operand ring; the slab is
+// read back row-major — 8 lanes x 16 bytes = a whole 128-byte line of one row — and leaves as 16-byte global stores.  Nothing is shared between
+// waves, so there is no barrier, group 0 starts while group 1 still multiplies, and the next tile's first DMAs (issued before the epilogue) land
+// under it.  Measured r04 on Hiera's stage-3 fc1 (M = 65536, N = 2304, K = 576) with the previous epilogue (the lock-step kernel's: fp32 tile
+// through LDS by 128 ds_write_b32 per lane at the LDS's 64 B/clk store rate, sixteen workgroup barriers, row-major re-read): 8.7 us of a tile's
+// 23.5 us (build without the epilogue: 212 -> 134 us), the global stores themselves 2.2 us.  A store straight from the swapped accumulators
+// (v_permlane32_swap -> 16 bytes per lane, 32 bytes per row and instruction) was built and measured too: 380 us — partial-line stores are far
+// worse than the LDS round trip.
+constexpr int P8_SLAB = 8 * P8_HALF;      // + wave * 4096
+
+__device__ __forceinline__ void p8_load4(const float* src, int c0, int N, float dflt, float (&o)[4]) {
+  if (src && c0 + 4 <= N) {
+    const f32x4_t x = *(const f32x4_t*)(src + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = x[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (src && c0 + e < N) ? src[c0 + e] : dflt;
+  }
+}
 template <typename TO>
-__device__ __forceinline__ void p8_epilogue(const GemmArgs& pa, f32x16_t (&acc)[4][2], char* smem, int bm, int bn, int bz, int wave, int lane) {
-  // this kernel never runs the window scatter or the fp8 scales (vg_gemm_p8_eligible): as constants they fold out of every epilogue variant
-  GemmArgs p = pa;
-  p.wmode = 0;
-  p.sa = nullptr;
-  p.sw = nullptr;
+__device__ __forceinline__ void p8_store_tail(TO* cp, const float* v, int nvalid) {
+  for (int e = 0; e < nvalid; ++e) vg_elt<TO>::st(cp + e, v[e]);
+}
+__device__ __forceinline__ void p8_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// bf16 output without a residual: packed staging, one pass per 32-row fragment (NC = 64 columns per wave; the SwiGLU form: 32).
+// INTERIOR (wave-uniform, chosen once per tile): the wave's 128 x NC block lies inside M x N — no per-lane bounds code at all.
+template <int NC, bool INTERIOR>
+__device__ __forceinline__ void p8_flush_packed(const GemmArgs& p, const char* slab, char* cbase, int64_t rstride, int m0, int n0w, int lane) {
+  // slab: 32 rows x NC bf16, 16-byte chunk c of row r at slot c ^ key(r); cbase: this lane's (row lane / CPR, chunk lane % CPR) of the pass's first rows
+  constexpr int RB = NC * 2, CPR = NC / 8, RPI = 64 / CPR;      // row bytes, 16-byte chunks per row, rows per read instruction
+  p8_wave_lds_fence();
+  u32x4_t d[32 / RPI];
+#pragma unroll
+  for (int k = 0; k < 32 / RPI; ++k) {
+    const int row = k * RPI + lane / CPR, c = lane % CPR;
+    const int key = NC == 64 ? (row >> 1) & 7 : (row >> 1) & 3;
+    d[k] = *(const u32x4_t*)(slab + row * RB + ((c ^ key) << 4));
+  }
+#pragma unroll
+  for (int k = 0; k < 32 / RPI; ++k) {
+    char* cp = cbase + k * RPI * rstride;
+    if constexpr (INTERIOR) {
+      epi_store16(cp, d[k], p.nt);
+    } else {
+      const int m = m0 + k * RPI + lane / CPR, col = n0w + (lane % CPR) * 8;
+      if (m < p.M) {
+        if (col + 8 <= p.N) epi_store16(cp, d[k], p.nt);
+        else
+          for (int e = 0; e < 8 && col + e < p.N; ++e) ((bf16_t*)cp)[e] = (bf16_t)(d[k][e >> 1] >> (16 * (e & 1)));
+      }
+    }
+  }
+  // (the reads have returned — their data was stored — before the next pass overwrites the slab)
+}
+
+template <typename TO, int ACT, bool RES, bool GAM, bool INTERIOR>      // ACT < 0: the activation code is read at run time (rare combinations)
+__device__ __forceinline__ void p8_epi_plain_body(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int bm, int bn, int bz, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
   TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 68;
-  float* ws = (float*)smem + wave * 32 * ES;
-  const int cg = lane & 7, rsub = lane >> 3;
-  const int n0w = p.a_op == 1 ? bn * 128 + (wn & 1) * 64 : bn * 256 + wn * 64;
-  const int n0 = n0w + cg * 8;
-  const bool fast = n0w + 64 <= N;               // wave-uniform: whole 16-byte groups -> the straight-line forms
-  float bv[8], gv[8], bu[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-    bu[e] = (p.a_op == 1 && p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f;
-  }
-  auto pass32 = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    if (i) vg_lds_barrier();
+  const TO* R = RES ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
+  const int n0w = bn * 256 + wn * 64, m0w = bm * 256 + wm * 128;
+  char* slab = smem + P8_SLAB + wave * 4096;
+  const int wkey = (l31 >> 1) & 7;
+  float bv[2][4][4], gv[4][4];       // (LayerScale: the current column fragment's only — 32 more registers beside the accumulators spill)
+  if (p.bias) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    vg_lds_barrier();
-    const int mrow = bm * 256 + wm * 128 + i * 32;
-    if (p.a_op == 1) {
-      // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows:
-      // y = round(silu(round(gate + b_g))) * round(up + b_u)  (HF LlamaMLP in the activation dtype; the arithmetic of vg_swiglu)
-      const float* wg = (const float*)smem + (wm * 4 + (wn & 1)) * 32 * ES;
-      const float* wu = wg + 2 * 32 * ES;
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = n0w + j * 32 + 8 * g + 4 * h;
+        if constexpr (INTERIOR) {
+          const f32x4_t x = *(const f32x4_t*)(p.bias + c0);
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int ml = (wn >> 1) * 16 + pass * 8 + rsub;
-        const int m = mrow + ml;
-        if (m >= M || n0 >= N) continue;
-        float gx[8], ux[8];
-        if (fast) {
-          const f32x4_t g0 = *(const f32x4_t*)(wg + ml * ES + cg * 8), g1 = *(const f32x4_t*)(wg + ml * ES + cg * 8 + 4);
-          const f32x4_t u0 = *(const f32x4_t*)(wu + ml * ES + cg * 8), u1 = *(const f32x4_t*)(wu + ml * ES + cg * 8 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { gx[e] = g0[e]; gx[4 + e] = g1[e]; ux[e] = u0[e]; ux[4 + e] = u1[e]; }
+          for (int e = 0; e < 4; ++e) bv[j][g][e] = x[e];
         } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { gx[e] = wg[ml * ES + cg * 8 + e]; ux[e] = wu[ml * ES + cg * 8 + e]; }
-        }
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float g = gx[e] + bv[e];
-          float u = ux[e] + bu[e];
-          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-          g = vg_silu(g);
-          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
-          v[e] = g * u;
-        }
-        TO* cp = C + (int64_t)m * p.ldc + n0;
-        if (n0 + 8 <= N) {
-          if constexpr (sizeof(TO) == 2) {
-            u32x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            epi_store16(cp, o, p.nt);
-          } else {
-            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-            *(f32x4_t*)cp = o0;
-            *(f32x4_t*)(cp + 4) = o1;
-          }
-        } else {
-          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
+          p8_load4(p.bias, c0, N, 0.f, bv[j][g]);
         }
       }
-      return;
-    }
-    if (fast && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
-          epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES, 8, decltype(gam)::value != 0>(p, ws, mrow, n0, cg, rsub, bv, gv, C, R);
-        }))
-      return;
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {     // edge tiles (N not a whole 16-byte group here) and the rarely used epilogue combinations
-      const int ml = pass * 8 + rsub;
-      const int m = mrow + ml;
-      if (m >= M || n0 >= N) continue;
-      float v[8];
+  } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-      TO* cp = C + (int64_t)m * p.ldc + n0;
-      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
-      if (n0 + 8 <= N) {
-        if constexpr (sizeof(TO) == 2) {
-          if (rp) {
-            const u32x4_t rv = *(const u32x4_t*)rp;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-          }
-          u32x4_t o;
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-          epi_store16(cp, o, p.nt);
-        } else {
-          if (rp) {
-            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          }
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *(f32x4_t*)cp = o0;
-          *(f32x4_t*)(cp + 4) = o1;
-        }
-      } else {
-        for (int e = 0; e < 8 && n0 + e < N; ++e) {
-          float o = v[e];
-          if (rp) o += vg_elt<TO>::ld(rp + e);
-          vg_elt<TO>::st(cp + e, o);
-        }
-      }
-    }
+        for (int e = 0; e < 4; ++e) bv[j][g][e] = 0.f;
+  }
+  auto value = [&](int i, int j, int g, int jj) {
+    float v = vg_act(acc[i][j][4 * g + jj] + bv[j][g][jj], ACT < 0 ? p.act : ACT);
+    if constexpr (GAM) v *= gv[g][jj];
+    return v;
   };
-  pass32(epi_ic<0>{});
-  pass32(epi_ic<1>{});
-  pass32(epi_ic<2>{});
-  pass32(epi_ic<3>{});
+  if constexpr (!RES && !GAM && sizeof(TO) == 2) {
+    char* wbase = slab + l31 * 128;
+    char* cbase = (char*)(C + (int64_t)(m0w + (lane >> 3)) * p.ldc + n0w + (lane & 7) * 8);
+    const int64_t rstride = (int64_t)p.ldc * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int unit = j * 8 + 2 * g + h;                                   // 8-byte unit of the row; the key keeps 16-byte chunks whole
+          uint2 d;
+          d.x = f2bf2(value(i, j, g, 0), value(i, j, g, 1));
+          d.y = f2bf2(value(i, j, g, 2), value(i, j, g, 3));
+          *(uint2*)(wbase + ((unit ^ (2 * wkey)) << 3)) = d;
+        }
+      p8_flush_packed<64, INTERIOR>(p, slab, cbase + i * 32 * rstride, rstride, m0w + i * 32, n0w, lane);
+    }
+  } else {
+    // fp32 staging, one pass per (row fragment, column fragment): 32 rows x 32 fp32 columns; a lane then finishes 8 columns of one row
+    const int64_t rs = RES ? p.ldr : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m0 = m0w + i * 32, c0w = n0w + j * 32;
+        if constexpr (GAM) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) p8_load4(p.gamma, c0w + 8 * g + 4 * h, N, 1.f, gv[g]);
+        }
+        // residual pieces first (row-major side: rows k * 16 + lane / 4, columns (lane & 3) * 8)
+        u32x4_t rv[2][sizeof(TO) == 2 ? 1 : 2];
+        if constexpr (RES) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int m = m0 + k * 16 + (lane >> 2), col = c0w + (lane & 3) * 8;
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            const bool ok = INTERIOR || (m < M && col + 8 <= N);
+#pragma unroll
+            for (int w = 0; w < (sizeof(TO) == 2 ? 1 : 2); ++w) rv[k][w] = ok ? *(const u32x4_t*)((const char*)(R + (int64_t)m * rs + col) + 16 * w) : z;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t x = {value(i, j, g, 0), value(i, j, g, 1), value(i, j, g, 2), value(i, j, g, 3)};
+          *(f32x4_t*)(slab + l31 * 128 + (((2 * g + h) ^ wkey) << 4)) = x;
+        }
+        p8_wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = k * 16 + (lane >> 2), c8 = lane & 3, rkey = (row >> 1) & 7;
+          const f32x4_t x0 = *(const f32x4_t*)(slab + row * 128 + (((2 * c8) ^ rkey) << 4));
+          const f32x4_t x1 = *(const f32x4_t*)(slab + row * 128 + (((2 * c8 + 1) ^ rkey) << 4));
+          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          const int m = m0 + row, col = c0w + c8 * 8, nvalid = INTERIOR ? 8 : N - col;
+          if (!INTERIOR && (m >= M || nvalid <= 0)) continue;
+          TO* cp = C + (int64_t)m * p.ldc + col;
+          if (nvalid >= 8) {
+            if constexpr (sizeof(TO) == 2) {
+              if constexpr (RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[k][0][e] << 16); v[2 * e + 1] += __uint_as_float(rv[k][0][e] & 0xffff0000u); }
+              }
+              u32x4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+              epi_store16(cp, o, p.nt);
+            } else {
+              if constexpr (RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(rv[k][0][e]); v[4 + e] += __uint_as_float(rv[k][1][e]); }
+              }
+              const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+              *(f32x4_t*)cp = o0;
+              *(f32x4_t*)(cp + 4) = o1;
+            }
+          } else {
+            if constexpr (RES)
+              for (int e = 0; e < nvalid; ++e) v[e] += vg_elt<TO>::ld(R + (int64_t)m * rs + col + e);
+            p8_store_tail<TO>(cp, v, nvalid);
+          }
+        }
+        p8_wave_lds_fence();
+      }
+  }
+}
+template <typename TO, int ACT, bool RES, bool GAM>
+__device__ __forceinline__ void p8_epi_plain(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int bm, int bn, int bz, int wave, int lane) {
+  const bool interior = bm * 256 + (wave >> 2) * 128 + 128 <= p.M && bn * 256 + (wave & 3) * 64 + 64 <= p.N;      // wave-uniform
+  if (interior) p8_epi_plain_body<TO, ACT, RES, GAM, true>(p, acc, smem, bm, bn, bz, wave, lane);
+  else p8_epi_plain_body<TO, ACT, RES, GAM, false>(p, acc, smem, bm, bn, bz, wave, lane);
+}
+
+// SwiGLU: fragment column 0 of a wave holds the gate rows, column 1 the up rows of the SAME 32 outputs (setup's W-row map), so
+// y = round(silu(round(gate + b_g))) * round(up + b_u)  (HF LlamaMLP in the activation dtype; the arithmetic of vg_swiglu) is lane-local
+template <typename TO>
+__device__ __forceinline__ void p8_epi_glu(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int bm, int bn, int bz, int wave, int lane) {
+  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const int n0w = bn * 128 + wn * 32;
+  char* slab = smem + P8_SLAB + wave * 4096;
+  const bool interior = bm * 256 + wm * 128 + 128 <= M && n0w + 32 <= N;      // wave-uniform
+  float bg[4][4], bu[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = n0w + 8 * g + 4 * h;
+    p8_load4(p.bias, c0, N, 0.f, bg[g]);
+    p8_load4(p.bias ? p.bias + N : nullptr, c0, N, 0.f, bu[g]);
+  }
+  auto value = [&](int i, int g, int jj) {
+    float gg = acc[i][0][4 * g + jj] + bg[g][jj], uu = acc[i][1][4 * g + jj] + bu[g][jj];
+    if (sizeof(TO) == 2) { gg = bf2f(f2bf(gg)); uu = bf2f(f2bf(uu)); }
+    gg = vg_silu(gg);
+    if (sizeof(TO) == 2) gg = bf2f(f2bf(gg));
+    return gg * uu;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m0 = bm * 256 + wm * 128 + i * 32;
+    if constexpr (sizeof(TO) == 2) {
+      const int wkey = (l31 >> 1) & 3;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 d;
+        d.x = f2bf2(value(i, g, 0), value(i, g, 1));
+        d.y = f2bf2(value(i, g, 2), value(i, g, 3));
+        *(uint2*)(slab + l31 * 64 + (((2 * g + h) ^ (2 * wkey)) << 3)) = d;
+      }
+      {
+        char* cbase = (char*)((bf16_t*)C + (int64_t)(m0 + (lane >> 2)) * p.ldc + n0w + (lane & 3) * 8);
+        if (interior) p8_flush_packed<32, true>(p, slab, cbase, (int64_t)p.ldc * 2, m0, n0w, lane);
+        else p8_flush_packed<32, false>(p, slab, cbase, (int64_t)p.ldc * 2, m0, n0w, lane);
+      }
+    } else {
+      // fp32 output (tests / diagnostics): 32 rows x 32 fp32 columns, as the plain form's fp32 pass
+      const int wkey = (l31 >> 1) & 7;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t x = {value(i, g, 0), value(i, g, 1), value(i, g, 2), value(i, g, 3)};
+        *(f32x4_t*)(slab + l31 * 128 + (((2 * g + h) ^ wkey) << 4)) = x;
+      }
+      p8_wave_lds_fence();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = k * 16 + (lane >> 2), c8 = lane & 3, rkey = (row >> 1) & 7;
+        const f32x4_t x0 = *(const f32x4_t*)(slab + row * 128 + (((2 * c8) ^ rkey) << 4));
+        const f32x4_t x1 = *(const f32x4_t*)(slab + row * 128 + (((2 * c8 + 1) ^ rkey) << 4));
+        const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        const int m = m0 + row, col = n0w + c8 * 8, nvalid = N - col;
+        if (m >= M || nvalid <= 0) continue;
+        TO* cp = C + (int64_t)m * p.ldc + col;
+        if (nvalid >= 8) {
+          *(f32x4_t*)cp = x0;
+          *(f32x4_t*)(cp + 4) = x1;
+        } else {
+          p8_store_tail<TO>(cp, v, nvalid);
+        }
+      }
+      p8_wave_lds_fence();
+    }
+  }
+}
+
+template <typename TO>
+__device__ __forceinline__ void p8_epilogue(const GemmArgs& p, f32x16_t (&acc)[4][2], char* smem, int bm, int bn, int bz, int wave, int lane) {
+  if (p.a_op == 1) {
+    p8_epi_glu<TO>(p, acc, smem, bm, bn, bz, wave, lane);
+    return;
+  }
+  if (epi_dispatch(p.act, p.R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
+        p8_epi_plain<TO, decltype(act)::value, decltype(res)::value != 0, decltype(gam)::value != 0>(p, acc, smem, bm, bn, bz, wave, lane);
+      }))
+    return;
+  // the combinations without a straight-line variant (SiLU / sigmoid, activation + residual, LayerScale elsewhere): run-time activation code
+  if (p.R) p8_epi_plain<TO, -1, true, true>(p, acc, smem, bm, bn, bz, wave, lane);
+  else p8_epi_plain<TO, -1, false, true>(p, acc, smem, bm, bn, bz, wave, lane);
 }
 
 enum { P8_FULL = 0, P8_PRELAST = 1, P8_LAST = 2 };
@@ -210,9 +355,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
         soff[q][i] = (uint32_t)gm * (uint32_t)(p.lda * 2) + chunk * 16;
         const int tc = (lr >> 5) * 64 + q * 32 + (lr & 31);
         int gn;
-        if (p.a_op == 1) {       // fused SwiGLU: tile columns 0..127 = gate rows, 128..255 = up rows of the SAME 128 outputs
-          const int o = bn * 128 + (tc & 127);
-          gn = (o < N ? o : N - 1) + (tc < 128 ? 0 : N);
+        if (p.a_op == 1) {       // fused SwiGLU: a wave's 64 tile columns = 32 gate rows then the 32 up rows of the SAME 32 outputs
+          const int o = bn * 128 + (tc >> 6) * 32 + (tc & 31);
+          gn = (o < N ? o : N - 1) + ((tc & 32) ? N : 0);
         } else {
           gn = bn * 256 + tc;
           gn = gn < N ? gn : N - 1;
@@ -227,6 +372,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
   // statement that reads it; s_nop 4 covers "SALU wrote the base / M0 -> VMEM reads it" (cdna_hip_programming.md section 5.7 item 2)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto stage = [&](int kind, int buf, int kt) {
+#if defined(P8_ABL) && P8_ABL == 2
+    return;      // ablation build: no LDS-DMA (garbage results; timing only)
+#endif
     const char* base = (kind < 2 ? Ab : Wb) + (int64_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -237,23 +385,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
 
   f32x16_t acc[4][2];
   u32x4_t fa[2][4], fb[2][4];
+#ifdef P8_ABL
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa[i >> 2][i & 3] = u32x4_t{(uint32_t)lane, 1u, 2u, 3u}; fb[i >> 2][i & 3] = u32x4_t{(uint32_t)lane, 5u, 6u, 7u}; }
+#endif
   auto readA = [&](int buf, int q) {
+#if defined(P8_ABL) && P8_ABL == 1
+    return;      // ablation build: no fragment reads
+#endif
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
       for (int s = 0; s < 4; ++s) fa[i2][s] = *(const u32x4_t*)(smem + aoff[s] + region(q, buf) + i2 * 4096);
-  };
-  auto readB = [&](int buf, int q) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) fb[q][s] = *(const u32x4_t*)(smem + boff[s] + (region(2 + q, buf) - 4 * P8_HALF));
-  };
-  auto mma = [&](int qa, int qb) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) MmaOp<T>::run(fa[i2][s], fb[qb][s], acc[qa * 2 + i2][qb]);
-    __builtin_amdgcn_s_setprio(0);
   };
   // end of a phase's read / stage section: the barrier the partner group's MFMA section ends at, then this wave's fragments
   auto enter_mma = [&]() {
@@ -268,71 +411,120 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // one K step in buffer `buf` (tile kinds: FULL stages steps kt + 1 and kt + 2, PRELAST only kt + 1, LAST nothing; the counted waits are
-  // the number of DMA instructions issued AFTER the half-tile the NEXT phase reads — see the schedule in the header)
-  auto kstep = [&](auto kind_c, auto buf_c, int kt) {
-    constexpr int KIND = decltype(kind_c)::value, buf = decltype(buf_c)::value;
-    // phase 1: quadrant (0, 0)
+  // One K step in buffer `buf` (static: even steps live in buffer 0, odd steps in buffer 1).  `kind` (wave-uniform, run time): FULL stages steps
+  // kt + 1 and kt + 2, PRELAST (kt == nk - 2) only kt + 1, LAST nothing; a counted wait = the number of DMA instructions issued AFTER the
+  // half-tile the NEXT phase reads.
+  // Balanced reads (8 / 4 / 8 / 4 ds_read_b128 per phase): the B0 fragments of K step t + 1 are read in phase 4 of step t, into the register set
+  // B1 left free after phase 3 — the two B sets swap roles every K step (static, like the buffer).
+  //   phase 1: read A0(t)            stage B1(t+1) -> other buffer      MFMA (A0, B0)
+  //   phase 2: read B1(t)            stage A1(t+1) -> other buffer      MFMA (A0, B1)
+  //   phase 3: read A1(t)            stage B0(t+2) -> this buffer       MFMA (A1, B1)
+  //   phase 4: read B0(t+1)          stage A0(t+2) -> this buffer       MFMA (A1, B0)
+  // Steady state: every wait is vmcnt(8) (four half-tiles issued after the one needed next).
+  auto readBinto = [&](int set, int buf, int q) {
+#if defined(P8_ABL) && P8_ABL == 1
+    return;
+#endif
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb[set][s] = *(const u32x4_t*)(smem + boff[s] + (region(2 + q, buf) - 4 * P8_HALF));
+  };
+  auto mma2 = [&](int qa, int qb, int set) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) MmaOp<T>::run(fb[set][s], fa[i2][s], acc[qa * 2 + i2][qb]);      // D^T = W . A^T: a lane owns one output row
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto kstep = [&](auto buf_c, int kind_in, int kt) {
+    constexpr int buf = decltype(buf_c)::value;
+    constexpr int P = buf, Q = buf ^ 1;        // register set holding B0(t) on entry / the free one
+    const int kind = __builtin_amdgcn_readfirstlane(kind_in);      // an SGPR integer: s_cmp + s_cbranch_scc, not lane-mask booleans
     readA(buf, 0);
-    readB(buf, 0);
-    if constexpr (KIND != P8_LAST) { stage(3, buf ^ 1, kt + 1); P8_VMCNT(8); } else { P8_VMCNT(2); }
+    if (kind != P8_LAST) { stage(3, buf ^ 1, kt + 1); P8_VMCNT(8); } else { P8_VMCNT(2); }
     enter_mma();
-    mma(0, 0);
+    mma2(0, 0, P);
     leave_mma();
-    // phase 2: quadrant (0, 1)
-    readB(buf, 1);
-    if constexpr (KIND != P8_LAST) { stage(1, buf ^ 1, kt + 1); P8_VMCNT(8); } else { P8_VMCNT(0); }
+    readBinto(Q, buf, 1);
+    if (kind != P8_LAST) { stage(1, buf ^ 1, kt + 1); P8_VMCNT(8); } else { P8_VMCNT(0); }
     enter_mma();
-    mma(0, 1);
+    mma2(0, 1, Q);
     leave_mma();
-    // phase 3: quadrant (1, 1)
     readA(buf, 1);
-    if constexpr (KIND == P8_FULL) stage(0, buf, kt + 2);
+    if (kind == P8_FULL) { stage(2, buf, kt + 2); P8_VMCNT(8); } else if (kind == P8_PRELAST) { P8_VMCNT(6); }
     enter_mma();
-    mma(1, 1);
+    mma2(1, 1, Q);
     leave_mma();
-    // phase 4: quadrant (1, 0): B0 is still in registers
-    if constexpr (KIND == P8_FULL) { stage(2, buf, kt + 2); P8_VMCNT(8); } else if constexpr (KIND == P8_PRELAST) { P8_VMCNT(4); }
+    if (kind == P8_FULL) { readBinto(Q, buf ^ 1, 0); stage(0, buf, kt + 2); P8_VMCNT(8); }
+    else if (kind == P8_PRELAST) { readBinto(Q, buf ^ 1, 0); P8_VMCNT(4); }
     enter_mma();
-    mma(1, 0);
+    mma2(1, 0, P);
     leave_mma();
   };
 
-  for (int t = blockIdx.x; t < total; t += gridDim.x) {
-    int lane_t = lane;
-    asm volatile("" : "+v"(lane_t));          // tile-invariant address terms stay inside the tile (hoisted, they are live across the K loop: spills)
-    setup(t, lane_t);
-    stage(0, 0, 0);
+  auto prologue = [&]() {     // the steady-state issue order: B0, A0, B1, A1 of step 0, then B0, A0 of step 1
     stage(2, 0, 0);
+    stage(0, 0, 0);
     stage(3, 0, 0);
     stage(1, 0, 0);
-    stage(0, 1, 1);
     stage(2, 1, 1);
-    P8_VMCNT(8);
+    stage(0, 1, 1);
+  };
+  int t = blockIdx.x;
+  if (t >= total) return;
+  if (p.stagger > 0) {       // VG_W128_STAGGER (lab knob): de-phase the workgroups' epilogue store bursts — workgroup w starts ((w >> 3) % 8) * stagger * ~0.25 us late
+    const int n = ((blockIdx.x >> 3) & 7) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+  int lane_t = lane;
+  asm volatile("" : "+v"(lane_t));            // tile-invariant address terms stay inside the tile (hoisted, they are live across the K loop: spills)
+  setup(t, lane_t);
+  prologue();
+  while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // B0(0), A0(0) landed: at most the eight youngest operations may be pending — the previous tile's output stores (younger than this tile's
+    // prologue DMAs: they only make the counted waits more conservative) or the last four half-tiles of the prologue
+    P8_VMCNT(8);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-    // nk is even (vg_gemm_p8_eligible: K % 128 == 0): pairs of K steps in buffers 0 / 1, the last pair peeled with its shorter waits — a straight
-    // loop + tail keeps the accumulators in one register web (a three-way tail made hipcc copy 16-register tuples between paths: 500 spills)
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 2) {
-      kstep(epi_ic<P8_FULL>{}, epi_ic<0>{}, kt);
-      kstep(epi_ic<P8_FULL>{}, epi_ic<1>{}, kt + 1);
+    readBinto(0, 0, 0);                             // "phase 4 of step -1": B0(0)
+    // any nk >= 2: even steps in buffer 0, odd steps in buffer 1; the kind of a step is a run-time (wave-uniform) value so that the loop is
+    // two bodies and one conditional — a three-way tail of templated bodies made hipcc copy 16-register accumulator tuples between paths (500 spills)
+    for (int kt = 0; kt < nk; kt += 2) {
+      kstep(epi_ic<0>{}, kt + 2 < nk ? P8_FULL : (kt + 1 < nk ? P8_PRELAST : P8_LAST), kt);
+      if (kt + 1 < nk) kstep(epi_ic<1>{}, kt + 3 < nk ? P8_FULL : (kt + 2 < nk ? P8_PRELAST : P8_LAST), kt + 1);
     }
-    kstep(epi_ic<P8_PRELAST>{}, epi_ic<0>{}, kt);
-    kstep(epi_ic<P8_LAST>{}, epi_ic<1>{}, kt + 1);
-    if (wr == 0) __builtin_amdgcn_s_barrier();      // group 0 waits for group 1's last MFMA section: the staging below overwrites the operands
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // group 0 waits for group 1's last MFMA section: every fragment read of the tile is done
     __builtin_amdgcn_sched_barrier(0);
+    // the next tile's first six half-tiles go out BEFORE this tile's epilogue: they land under it
+    const int cbm = bm, cbn = bn, cbz = bz;
+    const int tn = t + gridDim.x;
+    const bool more = tn < total;
     asm volatile("" : "+v"(lane_t));
-    p8_epilogue<TO>(p, acc, smem, bm, bn, bz, wave, lane_t);
-    vg_lds_barrier();                               // staging reads done before the next tile's DMAs land
+    if (more) {
+      setup(tn, lane_t);
+      prologue();
+    }
+    asm volatile("" : "+v"(lane_t));
+#if defined(P8_ABL) && P8_ABL == 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1])); }      // ablation build: no epilogue
+#else
+    p8_epilogue<TO>(p, acc, smem, cbm, cbn, cbz, wave, lane_t);
+#endif
+    if (!more) break;
+    t = tn;
+    // the source offsets are recomputed here instead of living across the epilogue (whose bias / LayerScale registers next to the 128 accumulator
+    // registers made hipcc spill them — and reload them inside the K loop behind a vmcnt(0))
+    asm volatile("" : "+v"(lane_t));
+    setup(t, lane_t);
   }
 }
 
@@ -341,17 +533,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
 // Launcher (vg_gemm.hip's route_w128 decides; this only checks what the 32-bit source offsets need)
 bool vg_gemm_p8_eligible(const GemmArgs& p, int batch) {
   const int64_t arows = p.M, wrows = p.a_op == 1 ? 2 * (int64_t)p.N : p.N;
-  return p.K % 128 == 0 && p.K >= 128 && arows * p.lda * 2 < (int64_t)1 << 32 && wrows * p.ldw * 2 < (int64_t)1 << 32 && !p.sa && !p.wmode && p.vec_out;
+  return p.K % 64 == 0 && p.K >= 128 && arows * p.lda * 2 < (int64_t)1 << 32 && wrows * p.ldw * 2 < (int64_t)1 << 32 && !p.sa && !p.wmode && p.vec_out;
 }
 
 template <typename TO>
 static int p8_launch(const GemmArgs& q, int wgs, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_tile_p8_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * P8_HALF);
+    (void)hipFuncSetAttribute((const void*)gemm_tile_p8_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  gemm_tile_p8_kernel<TO><<<wgs, 512, 8 * P8_HALF, st>>>(q);
+  gemm_tile_p8_kernel<TO><<<wgs, 512, 160 * 1024, st>>>(q);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
