@@ -177,6 +177,20 @@ int vg_layernorm(const void* x, int64_t ldx, const float* w, const float* b, voi
 int vg_rmsnorm(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy, int64_t rows, int C,
                float eps, int in_dtype, int out_dtype, vg_stream_t stream);
 
+/* ---- SAM2 two-way transformer, image side of the image -> token cross-attention, fused (r04) --------
+ * Replaces, for the 4096 image rows of every (frame, object) instance, the chain q_proj -> Attention (8 heads x 16, keys = the nt prompt/output
+ * tokens) -> out_proj -> + residual -> LayerNorm -> + dense PE of TwoWayAttentionBlock.forward
+ * (R/model/segment_anything_2/sam2/modeling/sam/transformer.py:185-193 with Attention.forward :236-260) by one pass over the rows:
+ *   s = xpe . u2^T + c2  (columns (head h, token t) = h * TP + t),  a = softmax over t < nt inside each head,  y = a . w2t^T + bo,
+ *   x_out = LayerNorm(x + y),  xpe_out = x_out + pe.
+ * u2 [N, 8 TP, 256], c2 [N, 8 TP] (fp32), w2t [N, 256, 8 TP] carry the token side (k / v projections folded into the q / out projection weights:
+ * videoglamm_amd/sam2.py:_i2t_fused); x_out, xpe_out [N, P, 256]; xpe, x [x_instances, P, 256] — instance n reads slot n % x_instances (the first
+ * block of a frame's objects shares the frame's embedding); pe [P, 256]; bf16 only; TP = 8 or 16; nt <= TP.
+ */
+int vg_twoway_image_update(const void* xpe, const void* x, const void* u2, const float* c2, const void* w2t, const float* bo,
+                           const float* ln_w, const float* ln_b, float eps, const void* pe, void* x_out, void* xpe_out,
+                           int N, int x_instances, int P, int nt, int TP, int dtype, vg_stream_t stream);
+
 /* ---- pointwise --------------------------------------------------------------------------------- */
 /* out[i] = alpha*a[i] + beta*b[i % b_period]  (b may be NULL -> alpha*a[i] + beta) */
 int vg_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta,

@@ -82,6 +82,20 @@ def attention_windows(q, k, v, scale):
     return attention(q, k, v, scale)
 
 
+def twoway_image_update(xpe, x, u2, c2, w2t, bo, ln_w, ln_b, eps, pe, nt, TP):
+    """image -> token cross-attention of a two-way block on the image rows, in the fused form (sam2.py: _i2t_fused):
+    scores = xpe . u2^T + c2 over columns (head h, token t) = h * TP + t; softmax over t < nt inside each head; y = a . w2t^T + bo;
+    x' = LayerNorm(x + y); returns (x', x' + pe)."""
+    N, P = u2.shape[0], x.shape[1]
+    xpe, x = xpe.repeat(N // x.shape[0], 1, 1), x.repeat(N // x.shape[0], 1, 1)      # instance n reads input slot n % Nx
+    s = (xpe.float() @ u2.float().transpose(1, 2) + c2.float()[:, None, :]).view(N, P, 8, TP)
+    s[..., nt:] = float("-inf")
+    a = torch.softmax(s, dim=-1).view(N, P, 8 * TP)
+    y = (a @ w2t.float().transpose(1, 2)).to(x.dtype).float() + bo
+    xn = F.layer_norm(x.float() + y, (x.shape[-1],), ln_w, ln_b, eps).to(x.dtype)
+    return xn, (xn.float() + pe.float()).to(x.dtype)
+
+
 def layernorm(x, w, b, eps, out_dtype=None):
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(out_dtype or x.dtype)
 

@@ -144,6 +144,14 @@ def test_host_graph_cpu(cpu_ops):
     run_checks(torch.device("cpu"), dict(rtol=1e-4, atol=2e-4))
 
 
+def test_host_graph_fused_two_way_cpu(cpu_ops, monkeypatch):
+    """the fused form of the two-way transformer's image side (sam2.py: _two_way_fused — the token -> image attention as ONE head-dim-256
+    attention over 8 nt derived queries, the image -> token attention as two small GEMMs + per-head softmax + LayerNorm) against the SAME reference
+    fixtures: the algebra is exact, only the order of the fp32 roundings differs."""
+    monkeypatch.setenv("VG_TWOWAY_FUSED", "2")
+    run_checks(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
+
+
 @pytest.mark.gpu
 def test_hip_parity_fp32(cuda):
     """mask logits within 1e-3 of the reference in fp32 mode (BASELINE.md target)."""
@@ -180,6 +188,44 @@ def test_hip_bf16_mask_miou(cuda):
     print(f"bf16 mask mIoU vs reference: framewise {iou_fw:.4f} (median per-mask {med:.4f}, {flipped}/{len(per)} choices flipped), "
           f"video branch {iou_vid:.4f}")
     assert med > 0.99 and flipped <= len(per) // 3 and iou_fw > 0.90 and iou_vid > 0.95, (per, iou_vid)
+
+
+@pytest.mark.gpu
+def test_hip_bf16_fused_two_way_equals_unfused(cuda, monkeypatch):
+    """bf16: the fused image side of the mask decoder's two-way transformer (r04 default: head-dim-256 attention for token -> image,
+    vg_twoway_image_update for image -> token) against the unfused kernel chain on the same weights — mask logits of all four tokens, IoU heads
+    and output tokens within bf16 noise of each other, and both equally far from the fp32 reference fixture."""
+    from videoglamm_amd import ops
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+
+    fx = G.fixture("sam2_micro.npz")
+    T, N, H, W = [int(v) for v in fx["meta"]]
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_overrides())
+    m = SAM2(Params(sd, cuda, torch.bfloat16), "", G.sam2_cfg())
+    images, text = G.rnd((T, 3, m.S, m.S), 11).to(cuda), G.rnd((N, 256), 12, 0.5).to(cuda)
+    fpn = m.forward_image(images[T - 1:T])
+    emb = ops.add(fpn[2].view(1, 256, 256), m.P.t("no_mem_embed").view(-1))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VG_TWOWAY_FUSED", mode)
+        for with_pts in (False, True):          # 7 tokens (framewise) / 9 tokens (video branch: two not-a-point tokens)
+            masks, iou, toks, obj = m.mask_decoder(emb, m.sparse_prompt(N, text.unsqueeze(1), with_pts), (fpn[0], fpn[1]), True)
+            out[mode, with_pts] = (masks.float().cpu(), iou.float().cpu(), toks.float().cpu())
+    ref = fx["dec_masks4"]
+    for with_pts in (False, True):
+        (m0, i0, t0), (m1, i1, t1) = out["0", with_pts], out["1", with_pts]
+        scale = m0.abs().max().item()
+        d01 = (m0 - m1).abs().max().item()
+        print(f"two-way fused vs unfused (bf16, {'9' if with_pts else '7'} tokens): max |d logit| {d01:.4f} at |logit| <= {scale:.2f}; "
+              f"sign agreement {((m0 > 0) == (m1 > 0)).float().mean().item():.5f}")
+        assert d01 < 0.06 * scale + 0.05
+        assert ((m0 > 0) == (m1 > 0)).float().mean() > 0.995
+        torch.testing.assert_close(i1, i0, rtol=5e-2, atol=5e-2)
+        torch.testing.assert_close(t1, t0, rtol=5e-2, atol=8e-2)
+    e0, e1 = (out["0", False][0] - ref).abs().max().item(), (out["1", False][0] - ref).abs().max().item()
+    print(f"distance to the fp32 reference: unfused {e0:.4f}, fused {e1:.4f}")
+    assert e1 < 2.0 * e0 + 0.05
 
 
 @pytest.mark.gpu

@@ -711,3 +711,31 @@ def test_decode_attention_sliding_window(cuda, dtype, H, Hkv, D, max_len, window
                                   window=window, keys_per_wg=128)
         close(o3, o, **(dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-3)))
     assert int(ws[-Hkv:].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("N,P,nt,TP", [(3, 256, 7, 8), (2, 4096, 7, 8), (2, 4096, 9, 16), (1, 96, 1, 8), (2, 1024, 16, 16)])
+def test_twoway_image_update(cuda, N, P, nt, TP):
+    """vg_twoway_image_update (SAM2 mask decoder, image -> token pass fused): scores GEMM + per-head softmax over the tokens + output GEMM +
+    residual + LayerNorm + dense PE against the fp32 statement on the same bf16 inputs.  The probabilities are rounded to bf16 between the
+    two GEMMs (as the attention kernels round P), LayerNorm outputs are O(1): bf16-sized tolerance."""
+    from videoglamm_amd import ops
+    dt = torch.bfloat16
+    NC = 8 * TP
+    x, pe = rnd(N, P, 256, dtype=dt, seed=1), rnd(P, 256, dtype=dt, seed=2)
+    xpe = (x.float() + pe.float()).to(dt)
+    u2 = rnd(N, NC, 256, dtype=dt, seed=3, scale=0.05)
+    c2 = rnd(N, NC, seed=4)
+    w2t = rnd(N, 256, NC, dtype=dt, seed=5, scale=0.5)
+    bo, lw, lb = rnd(256, seed=6), 1.0 + 0.1 * rnd(256, seed=7), rnd(256, seed=8)
+    xo, xpo = ops.twoway_image_update(xpe.to(cuda), x.to(cuda), u2.to(cuda), c2.to(cuda), w2t.to(cuda), bo.to(cuda), lw.to(cuda), lb.to(cuda),
+                                      1e-5, pe.to(cuda), nt, TP)
+    ro, rpo = ref.twoway_image_update(xpe, x, u2, c2, w2t, bo, lw, lb, 1e-5, pe, nt, TP)
+    close(xo, ro, rtol=3e-2, atol=3e-2)
+    close(xpo, rpo, rtol=3e-2, atol=4e-2)
+    # the masked token columns (t >= nt) carry no weight: garbage in their u2 / w2t entries must not change anything
+    u2b, w2b = u2.clone().view(N, 8, TP, 256), w2t.clone().view(N, 256, 8, TP)
+    u2b[:, :, nt:] = 1e3
+    w2b[..., nt:] = 1e3
+    xo2, _ = ops.twoway_image_update(xpe.to(cuda), x.to(cuda), u2b.view(N, NC, 256).to(cuda), c2.to(cuda), w2b.view(N, 256, NC).contiguous().to(cuda),
+                                     bo.to(cuda), lw.to(cuda), lb.to(cuda), 1e-5, pe.to(cuda), nt, TP)
+    assert torch.equal(xo2, xo)

@@ -1496,7 +1496,7 @@ static bool route_w128(int64_t M, int64_t N, int64_t K, int es, int a_op, int wm
   const int w = knob_w128();
   // (r02, persistent kernel + straight-line epilogue: from K x es = 2304 B — Hiera stage 4, InternVideo2 — the 256x256 kernel beats the
   // single-stage 128x128 one by 2...9 %; K = 1024 / 576 stay there)
-  static const int smallk_min = env_knob("VG_W128_MINKB", 2304);
+  static const int smallk_min = env_knob("VG_W128_MINKB", 1152);     // r04: with the phase-split kernel also K = 576 (Hiera stage 3): C2 268.5 -> 266.7 ms same-box
   if (!w || es != 2 || (route_small_k(K, es, a_op) && K * es < smallk_min) || wmode || K % (128 / es) != 0 || !vec_out) return false;
   if (w == 2 || w == 4) return true;       // 2 / 4: force the 4-wave / 8-wave kernel on every eligible shape (3: 8-wave, shape rule)
   const int64_t t256 = (int64_t)ntw * mtw * batch;

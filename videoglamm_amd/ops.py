@@ -478,6 +478,26 @@ def add_int_(p, v):
     return p
 
 
+def twoway_image_update(xpe, x, u2, c2, w2t, bo, ln_w, ln_b, eps, pe, nt, TP):
+    """Image side of a two-way block's image -> token cross-attention, fused (vg_twoway_image_update; the algebra is in sam2.py: _i2t_fused):
+    xpe, x [Nx, P, 256] bf16 (instance n reads slot n % Nx); u2 [N, 8 TP, 256] bf16; c2 [N, 8 TP] fp32; w2t [N, 256, 8 TP] bf16; pe [P, 256]
+    -> (x', x' + pe), each [N, P, 256]."""
+    lib = _lib.load()
+    Nx, P, C = x.shape
+    N = u2.shape[0]
+    assert N % Nx == 0 and xpe.shape == x.shape
+    assert C == 256 and x.dtype == torch.bfloat16 and TP in (8, 16) and nt <= TP, "vg_twoway_image_update: bf16, 256 channels, <= 16 tokens"
+    for t_ in (xpe, x, u2, w2t, pe):
+        assert t_.is_contiguous() and t_.dtype == torch.bfloat16
+    c2 = _f32(c2).contiguous()
+    xo = torch.empty(N, P, C, dtype=x.dtype, device=x.device)
+    xpo = torch.empty_like(xo)
+    rc = lib.vg_twoway_image_update(_p(xpe), _p(x), _p(u2), _p(c2), _p(w2t), _p(_f32(bo)), _p(_f32(ln_w)), _p(_f32(ln_b)), float(eps), _p(pe),
+                                    _p(xo), _p(xpo), N, Nx, P, int(nt), int(TP), _dt(x), _stream())
+    _lib.check(rc, "vg_twoway_image_update")
+    return xo, xpo
+
+
 def layernorm(x, w, b, eps, out_dtype=None):
     lib = _lib.load()
     x2, M, ldx = _rows2d(x)

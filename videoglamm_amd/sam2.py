@@ -258,23 +258,107 @@ class SAM2:
         queries = self.ln(t + "norm_final_attn", self._attn(t + "final_attn_token_to_image", q, k, keys, 8, residual=queries))
         return queries, keys
 
+    # ---- fused two-way transformer (r04): the image side of a block in TWO passes over the 4096 x 256 keys instead of a dozen.
+    # Algebra (exact in real arithmetic; sam/transformer.py:236-260 Attention with 8 heads of 16 channels, internal dim 128):
+    #   token -> image:  scores[h,t,r] = scale * q_h[t] . ((x_r + pe_r) Wk_h^T + bk_h)  =  (x_r + pe_r) . u[h,t]  + const(h,t)   with
+    #                    u[h,t] = scale * Wk_h^T q_h[t]  in R^256 — the constant cancels in the softmax over r — and
+    #                    sum_r a[h,t,r] (x_r Wv_h^T + bv_h) = (sum_r a[h,t,r] x_r) Wv_h^T + bv_h:  ONE single-head attention of head dim 256 with the
+    #                    8 nt vectors u as queries, x + pe as keys and x as values (vg_attention's head-dim-256 kernel), then 16 channels per (h, t).
+    #   image -> token:  scores[r,h,t] = (x_r + pe_r) . u2[h,t] + c2[h,t]  (u2 = scale Wq_h^T k_h[t], c2 = scale bq_h . k_h[t]), softmax over t per head,
+    #                    out_proj(sum_t a v_h[t]) = a[r,:] . W2 with W2[(h,t)] = Wo[:, head h] v_h[t] in R^256: vg_twoway_image_update does the two small
+    #                    GEMMs, the per-head softmax, the residual, LayerNorm and the + pe of the next pass in one kernel.
+    # The k / v / q projections of the 4096 image rows (5 x 4096 x 256 x 128 MACs per block) are gone; the token side keeps the library's small GEMMs.
+    def _heads_bd(self, x, TP):
+        """[N, nt, 128] -> block-diagonal [N * 8 * TP, 128]: row (h, t) holds head h's 16 channels of token t, zeros elsewhere."""
+        N, nt = x.shape[0], x.shape[1]
+        bd = torch.zeros(N, 8, TP, 8, 16, dtype=x.dtype, device=x.device)
+        torch.diagonal(bd, dim1=1, dim2=3)[:, :nt].copy_(x.view(N, nt, 8, 16).permute(0, 1, 3, 2))
+        return bd.view(N * 8 * TP, 128)
+
+    def _tw_const(self, name, kind):
+        w = lambda n: self.P.sd[self.p + name + n + ".weight"].float()      # noqa: E731
+        b = lambda n: self.P.sd[self.p + name + n + ".bias"].float()        # noqa: E731
+        scale = 16 ** -0.5
+        if kind == "ukT":        # [256, 128]: U = Qbd . (scale Wk)  ->  linear weight[d][k] = scale Wk[k][d]
+            return self.P.const((name, kind), lambda: scale * w(".k_proj").t())
+        if kind == "uqT":        # image -> token: scale Wq^T
+            return self.P.const((name, kind), lambda: scale * w(".q_proj").t())
+        if kind == "cq":         # [8, 128]: row 0 = scale bq (c2 = Kbd . scale bq), rows 1..7 zero (a whole 16-byte fp32 output group)
+            return self.P.const((name, kind), lambda: torch.cat([scale * b(".q_proj")[None], torch.zeros(7, 128, device=b(".q_proj").device)], 0))
+        raise KeyError(kind)
+
+    def _t2i_fused(self, name, queries, query_pe, xpe, x, TP):
+        N, nt = queries.shape[0], queries.shape[1]
+        NC, P, Bi = 8 * TP, x.shape[1], x.shape[0]
+        q_tok = self.lin(name + ".q_proj", ops.add(queries, query_pe))
+        U = ops.linear(self._heads_bd(q_tok, TP), self._tw_const(name, "ukT")).view(N // Bi, Bi, NC, 1, 256)
+        # instance i attends image i % Bi: one attention call per group of Bi instances (Bi = N after the first block: a single call)
+        zn = [ops.attention(U[g], xpe.view(Bi, P, 1, 256), x.view(Bi, P, 1, 256), 1.0) for g in range(N // Bi)]     # softmax-weighted means of the image rows
+        zn = zn[0] if len(zn) == 1 else torch.cat(zn, dim=0)
+        o_full = self.lin(name + ".v_proj", zn.view(N * NC, 256)).view(N, 8, TP, 8, 16)            # (+ bv: the weights of a (h, t) sum to one)
+        o = torch.diagonal(o_full, dim1=1, dim2=3)[:, :nt].permute(0, 1, 3, 2).reshape(N, nt, 128)  # head h's channels of row (h, t)
+        return self.lin(name + ".out_proj", o, residual=queries)
+
+    def _i2t_fused(self, name, norm, queries, query_pe, xpe, x, pe, TP):
+        N, nt = queries.shape[0], queries.shape[1]
+        NC = 8 * TP
+        k_bd = self._heads_bd(self.lin(name + ".k_proj", ops.add(queries, query_pe)), TP)
+        v_bd = self._heads_bd(self.lin(name + ".v_proj", queries), TP)
+        u2 = ops.linear(k_bd, self._tw_const(name, "uqT")).view(N, NC, 256)
+        c2 = ops.linear(k_bd, self._tw_const(name, "cq"), out_dtype=torch.float32).view(N, NC, 8)[:, :, 0].contiguous()
+        w2t = ops.linear(v_bd, self.P.w(self.p + name + ".out_proj")).view(N, NC, 256).transpose(1, 2).contiguous()      # [N, 256, NC]
+        return ops.twoway_image_update(xpe, x, u2, c2, w2t, self.P.b(self.p + name + ".out_proj"), self.P.f32(self.p + norm + ".weight"),
+                                       self.P.f32(self.p + norm + ".bias"), 1e-5, pe, nt, TP)
+
+    def _two_way_fused(self, src, tokens):
+        """TwoWayTransformer (R/modeling/sam/transformer.py:69-115,160-193) with the image side fused — see the comment block above.
+        src [Bi, HW, 256] with Bi | N: instance i works on image i % Bi; the first block reads the shared embeddings, its image -> token pass
+        writes one updated copy per instance."""
+        t = "sam_mask_decoder.transformer."
+        key_pe = self.dense_pe()
+        nt = tokens.shape[1]
+        TP = 8 if nt <= 8 else 16
+        queries, keys, query_pe = tokens, src, tokens
+        kpe = ops.add(keys, key_pe)
+        for i in range(2):
+            l = f"{t}layers.{i}."
+            if i == 0:
+                queries = self._attn(l + "self_attn", queries, queries, queries, 8)
+            else:
+                q = ops.add(queries, query_pe)
+                queries = self._attn(l + "self_attn", q, q, queries, 8, residual=queries)
+            queries = self.ln(l + "norm1", queries)
+            queries = self.ln(l + "norm2", self._t2i_fused(l + "cross_attn_token_to_image", queries, query_pe, kpe, keys, TP))
+            h = self.lin(l + "mlp.layers.0", queries, act=ops.ACT_RELU)
+            queries = self.ln(l + "norm3", self.lin(l + "mlp.layers.1", h, residual=queries))
+            keys, kpe = self._i2t_fused(l + "cross_attn_image_to_token", l + "norm4", queries, query_pe, kpe, keys, key_pe, TP)
+        queries = self.ln(t + "norm_final_attn", self._t2i_fused(t + "final_attn_token_to_image", queries, query_pe, kpe, keys, TP))
+        return queries, keys
+
     def mask_decoder(self, image_embed, sparse, high_res, repeat_image):
         """MaskDecoder.predict_masks — R/modeling/sam/mask_decoder.py:168-245.
-        image_embed [Bi,HW,256] (Bi = 1 when repeat_image else N), sparse [N,ns,256],
-        high_res = (s0 [Bi,(4es)^2,32], s1 [Bi,(2es)^2,64]).
+        image_embed [Bi,HW,256], sparse [N,ns,256], high_res = (s0 [Bi,(4es)^2,32], s1 [Bi,(2es)^2,64]) with Bi | N: instance i decodes image
+        i % Bi (Bi = N: one image per instance; Bi = 1 = the reference's repeat_image; 1 < Bi < N: the framewise branch's (object, frame) pairs,
+        object-major — r04: a frame's objects share its embedding and high-resolution features instead of reading per-object copies).
         -> masks fp32 [N,4,4es,4es], iou fp32 [N,4], mask tokens [N,4,256], object score logits fp32 [N,1]."""
         d = "sam_mask_decoder."
-        N, es = sparse.shape[0], self.es
+        N, es, Bi = sparse.shape[0], self.es, image_embed.shape[0]
+        assert N % Bi == 0 and (repeat_image or Bi > 1 or N == 1)
         out_tokens = torch.cat([self.P.t(self.p + d + "obj_score_token.weight"), self.P.t(self.p + d + "iou_token.weight"),
                                 self.P.t(self.p + d + "mask_tokens.weight")], dim=0)
         tokens = torch.cat([out_tokens.unsqueeze(0).expand(N, -1, -1), sparse], dim=1).contiguous()
         no_mask = self.P.t(self.p + "sam_prompt_encoder.no_mask_embed.weight").view(-1)
-        src = ops.add(image_embed, no_mask)  # dense prompt = no_mask_embed broadcast (prompt_encoder.py:183-187)
-        if repeat_image and N > 1:
-            src = ops.permute5(src, (N, es * es, 256, 1, 1), (0, 256, 1, 0, 0)).view(N, es * es, 256)
-        hs, src = self._two_way(src.view(N, es * es, 256), tokens)
+        src = ops.add(image_embed, no_mask).view(Bi, es * es, 256)  # dense prompt = no_mask_embed broadcast (prompt_encoder.py:183-187)
+        # the fused image side needs the bf16 kernels (vg_twoway_image_update, head-dim-256 attention); fp32 parity mode keeps the reference's order
+        fused = self.dtype == torch.bfloat16 and os.environ.get("VG_TWOWAY_FUSED", "1") != "0" or os.environ.get("VG_TWOWAY_FUSED") == "2"
+        if fused:
+            hs, src = self._two_way_fused(src, tokens)
+        else:
+            if Bi < N:      # the unfused chain works on one image copy per instance
+                src = src.unsqueeze(0).expand(N // Bi, Bi, es * es, 256).reshape(N, es * es, 256)
+            hs, src = self._two_way(src, tokens)
         iou_tok, mask_toks = hs[:, 1, :], hs[:, 2:6, :]
-        s0, s1 = high_res
+        s0, s1 = high_res            # [Bi, ...]: ops.add broadcasts them over the instance groups (instance i -> image i % Bi)
         g = ops.linear(src, self.P.convT_w(self.p + d + "output_upscaling.0"))
         up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.0"), N, es, es, 64)
         up = ops.add(up, s1)
@@ -501,16 +585,14 @@ class SAM2:
             else:
                 fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr])
             emb = ops.add(fpn[2].view(Tc, hw, 256), no_mem)
-            s0, s1, sp = fpn[0], fpn[1], sparse
-            if N > 1:  # (frame, object) pairs: repeat each frame's features per object, tile the prompts per frame
-                rep = lambda x: ops.permute5(x.contiguous(), (Tc, N, x[0].numel(), 1, 1), (x[0].numel(), 0, 1, 0, 0))  # noqa: E731
-                emb = rep(emb).view(Tc * N, hw, 256)
-                s0, s1 = rep(s0).view(Tc * N, 16 * hw, 32), rep(s1).view(Tc * N, 4 * hw, 64)
-            if Tc > 1:
-                sp = ops.permute5(sparse, (Tc, N, ns * 256, 1, 1), (0, ns * 256, 1, 0, 0)).view(Tc * N, ns, 256)
-            masks, iou, toks, _ = self.mask_decoder(emb, sp, (s0, s1), repeat_image=False)
+            # (object, frame) pairs, object-major: instance o * Tc + t decodes frame t with object o's prompt.  r04: the frame's embedding and
+            # high-resolution features are SHARED by its objects (mask_decoder: instance i -> image i % Tc) — the per-object copies
+            # (3.1 GB per 64 x 8 clip, written and read back) are gone.
+            sp = sparse if Tc == 1 else sparse.unsqueeze(1).expand(N, Tc, ns, 256).reshape(N * Tc, ns, 256)
+            masks, iou, toks, _ = self.mask_decoder(emb, sp, (fpn[0].view(Tc, 16 * hw, 32), fpn[1].view(Tc, 4 * hw, 64)), repeat_image=Tc == 1)
             low, _, _, _ = ops.multimask_select(masks, iou, toks, 0)
-            lows.append(low.view(Tc, N, 1, 4 * es, 4 * es))
+            low = low.view(N, Tc, 1, 4 * es, 4 * es)
+            lows.append(low.transpose(0, 1) if N > 1 and Tc > 1 else low.view(Tc, N, 1, 4 * es, 4 * es))
         low = torch.cat(lows, dim=0)                                             # [T,N,1,4es,4es]
         up = ops.bilinear_mask if as_masks else ops.bilinear
         return up(low.view(len(frames) * N, 4 * es, 4 * es), H, W).view(len(frames), N, H, W), low
