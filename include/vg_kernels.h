@@ -191,6 +191,17 @@ int vg_twoway_image_update(const void* xpe, const void* x, const void* u2, const
                            const float* ln_w, const float* ln_b, float eps, const void* pe, void* x_out, void* xpe_out,
                            int N, int x_instances, int P, int nt, int TP, int dtype, vg_stream_t stream);
 
+/* Output upscaling + hypernetwork product of the mask decoder, fused (r04): MaskDecoder.predict_masks
+ * (R/model/segment_anything_2/sam2/modeling/sam/mask_decoder.py:225-245): ConvTranspose2d(256 -> 64, k2 s2) + feat_s1 -> LayerNorm2d -> GELU ->
+ * ConvTranspose2d(64 -> 32, k2 s2) + feat_s0 -> GELU -> masks[k] = hyper_in[k] . upscaled (k = 0..3).
+ * x [N, es*es, 256] (the two-way transformer's image output); w0 [4*64, 256], w1 [4*32, 64]: the ConvT weights as GEMM weights, row (dy*2+dx)*Cout + co
+ * (Params.convT_w); s1 [images, (2es)^2, 64], s0 [images, (4es)^2, 32] channels-last, instance n uses image n % images; hyper [N, 4, 32];
+ * masks fp32 [N, 4, 4es, 4es].  bf16 only.
+ */
+int vg_mask_upscale(const void* x, const void* w0, const float* b0, const void* s1, const float* ln_w, const float* ln_b, float eps,
+                    const void* w1, const float* b1, const void* s0, const void* hyper, float* masks, int N, int images, int es, int dtype,
+                    vg_stream_t stream);
+
 /* ---- pointwise --------------------------------------------------------------------------------- */
 /* out[i] = alpha*a[i] + beta*b[i % b_period]  (b may be NULL -> alpha*a[i] + beta) */
 int vg_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta,

@@ -82,6 +82,19 @@ def attention_windows(q, k, v, scale):
     return attention(q, k, v, scale)
 
 
+def mask_upscale(x, w0, b0, s1, ln_w, ln_b, eps, w1, b1, s0, hyper, es):
+    """mask_decoder.py:225-245 on channels-last tensors (sam2.py: mask_decoder's unfused chain, in fp32): ConvT as GEMM + pixel shuffle, + s1,
+    LayerNorm2d, GELU, ConvT, + s0, GELU, hyper . upscaled."""
+    N, Bi = x.shape[0], s1.shape[0]
+    rep = lambda t: t.float().repeat(N // Bi, 1, 1)      # noqa: E731   instance n -> image n % Bi
+    g = x.float() @ w0.float().t()
+    up = pixel_shuffle2(g, b0, N, es, es, 64).view(N, 4 * es * es, 64) + rep(s1)
+    up = F.gelu(F.layer_norm(up, (64,), ln_w, ln_b, eps))
+    g = up @ w1.float().t()
+    up = F.gelu(pixel_shuffle2(g, b1, N, 2 * es, 2 * es, 32).view(N, 16 * es * es, 32) + rep(s0))
+    return (hyper.float() @ up.transpose(1, 2)).view(N, 4, 4 * es, 4 * es)
+
+
 def twoway_image_update(xpe, x, u2, c2, w2t, bo, ln_w, ln_b, eps, pe, nt, TP):
     """image -> token cross-attention of a two-way block on the image rows, in the fused form (sam2.py: _i2t_fused):
     scores = xpe . u2^T + c2 over columns (head h, token t) = h * TP + t; softmax over t < nt inside each head; y = a . w2t^T + bo;

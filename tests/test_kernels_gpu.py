@@ -739,3 +739,22 @@ def test_twoway_image_update(cuda, N, P, nt, TP):
     xo2, _ = ops.twoway_image_update(xpe.to(cuda), x.to(cuda), u2b.view(N, NC, 256).to(cuda), c2.to(cuda), w2b.view(N, 256, NC).contiguous().to(cuda),
                                      bo.to(cuda), lw.to(cuda), lb.to(cuda), 1e-5, pe.to(cuda), nt, TP)
     assert torch.equal(xo2, xo)
+
+
+@pytest.mark.parametrize("N,Bi,es", [(2, 2, 16), (4, 2, 16), (2, 1, 64), (3, 3, 8)])
+def test_mask_upscale(cuda, N, Bi, es):
+    """vg_mask_upscale (mask decoder: ConvT + s1 -> LayerNorm2d -> GELU -> ConvT + s0 -> GELU -> hypernetwork product, one kernel) against the fp32
+    statement of the unfused chain on the same bf16 inputs; instance n uses the high-resolution features of image n % Bi."""
+    from videoglamm_amd import ops
+    dt = torch.bfloat16
+    P = es * es
+    x = rnd(N, P, 256, dtype=dt, seed=1)
+    w0, b0 = rnd(256, 256, dtype=dt, seed=2, scale=0.06), rnd(64, seed=3, scale=0.1)
+    w1, b1 = rnd(128, 64, dtype=dt, seed=4, scale=0.12), rnd(32, seed=5, scale=0.1)
+    s1, s0 = rnd(Bi, 4 * P, 64, dtype=dt, seed=6), rnd(Bi, 16 * P, 32, dtype=dt, seed=7)
+    lw, lb = 1.0 + 0.1 * rnd(64, seed=8), 0.1 * rnd(64, seed=9)
+    hyper = rnd(N, 4, 32, dtype=dt, seed=10, scale=0.3)
+    y = ops.mask_upscale(x.to(cuda), w0.to(cuda), b0.to(cuda), s1.to(cuda), lw.to(cuda), lb.to(cuda), 1e-6, w1.to(cuda), b1.to(cuda), s0.to(cuda),
+                         hyper.to(cuda), es)
+    r = ref.mask_upscale(x, w0, b0, s1, lw, lb, 1e-6, w1, b1, s0, hyper, es)
+    close(y, r, rtol=3e-2, atol=3e-2)

@@ -43,6 +43,7 @@ def _sig(lib):
         "vg_decode_layer_flag_ints": ([], c_int64),
         "vg_decode_layer": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, P, P, L, P, P, P, F, P, L, P, P, L, P, I, I, I, P], c_int),
         "vg_layernorm": ([P, L, P, P, P, L, L, I, F, I, I, P], c_int),
+        "vg_mask_upscale": ([P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P], c_int),
         "vg_twoway_image_update": ([P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P], c_int),
         "vg_rmsnorm": ([P, L, P, P, L, L, I, F, I, I, P], c_int),
         "vg_axpby": ([P, P, P, L, F, F, L, I, I, I, P], c_int),

@@ -203,6 +203,212 @@ __global__ __launch_bounds__(256) void twoway_image_update_kernel(TwoWayArgs p) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// vg_mask_upscale: the mask decoder's output upscaling + hypernetwork product (R/modeling/sam/mask_decoder.py:225-245) for 32 image rows per wave:
+//   g0 = ConvT2x2(x) (as a GEMM: 256 -> 4 taps x 64) + b0 + s1  ->  LayerNorm2d(64) -> GELU  ->  ConvT2x2 (64 -> 4 taps x 32) + b1 + s0 -> GELU
+//   masks[k] = hyper[k] . (the 32 channels of each of the 16 output pixels),  k = 0..3
+// i.e. what the unfused path runs as GEMM, pixel shuffle, add, LayerNorm, GELU, GEMM, pixel shuffle, add + GELU, batched GEMM — nine launches that
+// write and re-read [N, 16384, 64] and [N, 65536, 32] tensors (3 GB at 512 instances) — with the row's 16 output pixels never leaving registers.
+// All three products run swapped (a lane owns one image row = one input pixel; accumulator group g = four consecutive output channels), so the
+// per-pixel LayerNorm is lane-local + one half-wave exchange, and v_permlane32_swap turns accumulator groups into the next product's B operand
+// (as in vg_twoway_image_update).  The ConvT weights (128 KB + 16 KB) are staged once per workgroup (one workgroup per CU); s1 / s0 (shared by the
+// objects of a frame: image i = n % Bi) are read as 8-byte pieces of the pixel's own 128 / 64-byte line; only lanes h = 0 hold the four mask values
+// (the hypernetwork operand has 4 real rows of 32) and store them: 16 bytes = 4 consecutive output pixels, 512 contiguous bytes per half-wave.
+struct UpscaleArgs {
+  const bf16_t* x; const bf16_t* w0; const float* b0; const bf16_t* s1; const float* lnw; const float* lnb; const bf16_t* w1; const float* b1;
+  const bf16_t* s0; const bf16_t* hyper; float* out;
+  float eps;
+  int N, Bi, es, iters;
+};
+
+__device__ __forceinline__ float tw_gelu(float x) { return vg_gelu_erf(x); }
+
+__global__ __launch_bounds__(256, 1) void mask_upscale_kernel(UpscaleArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w0s = smem;                          // [256 outputs (tap * 64 + co)][256 in] bf16, 16-byte chunk c of row o at slot c ^ (o & 15)
+  char* w1s = smem + 256 * 512;              // [128 outputs (tap2 * 32 + c2)][64 in] bf16, chunk c at slot c ^ ((o >> 1) & 7)
+  char* hys = w1s + 128 * 128;               // [32][32] bf16: rows 0..3 = hyper[n], rows 4..31 zero (the A operand of the mask product)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y, es = p.es, P = es * es, img = n % p.Bi;
+  {
+    const u32x4_t* g = (const u32x4_t*)p.w0;
+    for (int i = tid; i < 256 * 32; i += 256) {
+      const int o = i >> 5, ch = i & 31;
+      *(u32x4_t*)(w0s + o * 512 + ((ch ^ (o & 15)) << 4)) = g[i];
+    }
+    const u32x4_t* g1 = (const u32x4_t*)p.w1;
+    for (int i = tid; i < 128 * 8; i += 256) {
+      const int o = i >> 3, ch = i & 7;
+      *(u32x4_t*)(w1s + o * 128 + ((ch ^ ((o >> 1) & 7)) << 4)) = g1[i];
+    }
+    for (int i = tid; i < 32 * 32 / 8; i += 256) {          // 128 chunks of 8 bf16
+      const int r = i >> 2;
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      *(u32x4_t*)(hys + i * 16) = r < 4 ? ((const u32x4_t*)(p.hyper + (int64_t)n * 128))[i] : z;
+    }
+  }
+  // per-lane channel constants in the accumulator layout: channel 32 jf + 8 g + 4 h + jj (first product, 64 channels), 8 g + 4 h + jj (second, 32)
+  float b0v[2][4][4], lwv[2][4][4], lbv[2][4][4], b1v[4][4];
+#pragma unroll
+  for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int co = 32 * jf + 8 * g + 4 * h + jj;
+        b0v[jf][g][jj] = p.b0[co];
+        lwv[jf][g][jj] = p.lnw[co];
+        lbv[jf][g][jj] = p.lnb[co];
+      }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) b1v[g][jj] = p.b1[8 * g + 4 * h + jj];
+  __syncthreads();
+  u32x4_t hyf[2];
+#pragma unroll
+  for (int gp = 0; gp < 2; ++gp) hyf[gp] = *(const u32x4_t*)(hys + l31 * 64 + (2 * gp + h) * 16);
+
+  for (int it = 0; it < p.iters; ++it) {
+    const int r0 = ((blockIdx.x * p.iters + it) * 4 + wave) * 32;
+    if (r0 >= P) break;
+    const int row = min(r0 + l31, P - 1);
+    const int y = row / es, x = row - y * es;
+    // ---- product 1 (swapped): G^T[(tap, co)][r] = w0[(tap, co)] . x[r]
+    u32x4_t xb[16];
+    {
+      const u32x4_t* xr = (const u32x4_t*)(p.x + ((int64_t)n * P + row) * 256) + h;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) xb[ks] = xr[2 * ks];
+    }
+    f32x16_t acc1[8];
+#pragma unroll
+    for (int jo = 0; jo < 8; ++jo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[jo][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int jo = 0; jo < 8; ++jo) {
+        const int o = 32 * jo + l31;
+        const u32x4_t a = *(const u32x4_t*)(w0s + o * 512 + (((2 * ks + h) ^ (o & 15)) << 4));
+        acc1[jo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, xb[ks]), acc1[jo], 0, 0, 0);
+      }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      float res[2][4][4];          // [dx][tap2][k]
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int tap = dy * 2 + dx;
+        // + b0 + s1, LayerNorm2d over the pixel's 64 channels (two-pass), GELU
+        const int64_t pix1 = (int64_t)(2 * y + dy) * (2 * es) + 2 * x + dx;
+        const uint2* s1p = (const uint2*)(p.s1 + ((int64_t)img * 4 * P + pix1) * 64) + h;       // 8-byte piece index = co / 4 = 8 jf + 2 g + h
+        float v[2][4][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint2 sv = s1p[8 * jf + 2 * g];
+            const float s4[4] = {__uint_as_float(sv.x << 16), __uint_as_float(sv.x & 0xffff0000u), __uint_as_float(sv.y << 16), __uint_as_float(sv.y & 0xffff0000u)};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[jf][g][jj] = acc1[2 * tap + jf][4 * g + jj] + b0v[jf][g][jj] + s4[jj];
+              sum += v[jf][g][jj];
+            }
+          }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 64.0f);
+        float q2 = 0.f;
+#pragma unroll
+        for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { v[jf][g][jj] -= mean; q2 = fmaf(v[jf][g][jj], v[jf][g][jj], q2); }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd = __builtin_amdgcn_rsqf(q2 * (1.0f / 64.0f) + p.eps);
+        // the 64 activations as product 2's B operand: 16-channel step q = 2 jf + gp holds channels 32 jf + 16 gp + 8 h + e in slot 8 h + e
+        u32x4_t uf[4];
+#pragma unroll
+        for (int jf = 0; jf < 2; ++jf)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float e8[8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float X = tw_gelu(v[jf][2 * gp][jj] * rstd * lwv[jf][2 * gp][jj] + lbv[jf][2 * gp][jj]);
+              const float Y = tw_gelu(v[jf][2 * gp + 1][jj] * rstd * lwv[jf][2 * gp + 1][jj] + lbv[jf][2 * gp + 1][jj]);
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(Y), false, false);
+              e8[jj] = __uint_as_float(sw[0]);
+              e8[4 + jj] = __uint_as_float(sw[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uf[2 * jf + gp][e] = f2bf2(e8[2 * e], e8[2 * e + 1]);
+          }
+        // ---- product 2 (swapped): [(tap2, c2)][r] = w1[(tap2, c2)] . u[r]   (K = 64)
+        f32x16_t acc2[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[t2][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t2 = 0; t2 < 4; ++t2) {
+            const int o = 32 * t2 + l31;
+            const u32x4_t a = *(const u32x4_t*)(w1s + o * 128 + (((2 * q + h) ^ ((o >> 1) & 7)) << 4));
+            acc2[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, uf[q]), acc2[t2], 0, 0, 0);
+          }
+        // ---- + b1 + s0, GELU, and the hypernetwork product: masks[k] = hyper[k] . u2   (K = 32, rows k >= 4 of the operand are zero)
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+          const int dy2 = t2 >> 1, dx2 = t2 & 1;
+          const int64_t pix2 = (int64_t)(4 * y + 2 * dy + dy2) * (4 * es) + 4 * x + 2 * dx + dx2;
+          const uint2* s0p = (const uint2*)(p.s0 + ((int64_t)img * 16 * P + pix2) * 32) + h;      // piece index = c2 / 4 = 2 g + h
+          u32x4_t u2f[2];
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float e8[8];
+            const uint2 sa = s0p[2 * (2 * gp)], sb = s0p[2 * (2 * gp + 1)];
+            const float a4[4] = {__uint_as_float(sa.x << 16), __uint_as_float(sa.x & 0xffff0000u), __uint_as_float(sa.y << 16), __uint_as_float(sa.y & 0xffff0000u)};
+            const float c4[4] = {__uint_as_float(sb.x << 16), __uint_as_float(sb.x & 0xffff0000u), __uint_as_float(sb.y << 16), __uint_as_float(sb.y & 0xffff0000u)};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float X = tw_gelu(acc2[t2][8 * gp + jj] + b1v[2 * gp][jj] + a4[jj]);
+              const float Y = tw_gelu(acc2[t2][8 * gp + 4 + jj] + b1v[2 * gp + 1][jj] + c4[jj]);
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(Y), false, false);
+              e8[jj] = __uint_as_float(sw[0]);
+              e8[4 + jj] = __uint_as_float(sw[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u2f[gp][e] = f2bf2(e8[2 * e], e8[2 * e + 1]);
+          }
+          f32x16_t acc3;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp)
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, hyf[gp]), __builtin_bit_cast(bf16x8_t, u2f[gp]), acc3, 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) res[dx][t2][k] = acc3[k];          // (lanes h = 0: accumulator rows 0..3 = k)
+        }
+      }
+      // ---- store: for each mask k and output row 4 y + 2 dy + dy2, the four pixels 4 x + {0..3} = (dx, dx2) in {0,1}^2: 16 bytes per lane (h = 0)
+      if (h == 0 && r0 + l31 < P) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int dy2 = 0; dy2 < 2; ++dy2) {
+            const f32x4_t o = {res[0][dy2 * 2 + 0][k], res[0][dy2 * 2 + 1][k], res[1][dy2 * 2 + 0][k], res[1][dy2 * 2 + 1][k]};
+            *(f32x4_t*)(p.out + ((int64_t)n * 4 + k) * 16 * P + (int64_t)(4 * y + 2 * dy + dy2) * (4 * es) + 4 * x) = o;
+          }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int vg_twoway_image_update(const void* xpe, const void* x, const void* u2, const float* c2, const void* w2t, const float* bo, const float* ln_w,
@@ -227,6 +433,26 @@ extern "C" int vg_twoway_image_update(const void* xpe, const void* x, const void
     if (!attr16) { (void)hipFuncSetAttribute((const void*)twoway_image_update_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr16 = true; }
     twoway_image_update_kernel<16><<<grid, NW * 64, lds, stream>>>(a);
   }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_mask_upscale(const void* x, const void* w0, const float* b0, const void* s1, const float* ln_w, const float* ln_b, float eps,
+                               const void* w1, const float* b1, const void* s0, const void* hyper, float* masks, int N, int images, int es, int dtype,
+                               vg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VG_CHECK(x && w0 && b0 && s1 && ln_w && ln_b && w1 && b1 && s0 && hyper && masks, VG_ERR_ARG, "vg_mask_upscale: null pointer");
+  VG_CHECK(dtype == VG_BF16, VG_ERR_ARG, "vg_mask_upscale: bf16 only (the fp32 parity mode keeps the unfused order)");
+  VG_CHECK(N > 0 && images > 0 && N % images == 0 && es > 0, VG_ERR_ARG, "vg_mask_upscale: bad sizes N=%d images=%d es=%d", N, images, es);
+  const int P = es * es;
+  UpscaleArgs a{(const bf16_t*)x, (const bf16_t*)w0, b0, (const bf16_t*)s1, ln_w, ln_b, (const bf16_t*)w1, b1, (const bf16_t*)s0, (const bf16_t*)hyper,
+                masks, eps, N, images, es, N >= 256 ? 8 : (N >= 64 ? 4 : 2)};
+  const int lds = 256 * 512 + 128 * 128 + 32 * 64;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)mask_upscale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int rows_wg = 128 * a.iters;
+  dim3 grid((P + rows_wg - 1) / rows_wg, N);
+  mask_upscale_kernel<<<grid, 256, lds, stream>>>(a);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -498,6 +498,23 @@ def twoway_image_update(xpe, x, u2, c2, w2t, bo, ln_w, ln_b, eps, pe, nt, TP):
     return xo, xpo
 
 
+def mask_upscale(x, w0, b0, s1, ln_w, ln_b, eps, w1, b1, s0, hyper, es):
+    """Mask decoder output upscaling + hypernetwork product, fused (vg_mask_upscale): x [N, es*es, 256], s1 [Bi, (2es)^2, 64], s0 [Bi, (4es)^2, 32]
+    (instance n -> image n % Bi), hyper [N, 4, 32] -> masks fp32 [N, 4, 4es, 4es]."""
+    lib = _lib.load()
+    N, Bi = x.shape[0], s1.shape[0]
+    assert x.dtype == torch.bfloat16 and x.shape[1:] == (es * es, 256) and s1.shape[1:] == (4 * es * es, 64) and s0.shape == (Bi, 16 * es * es, 32)
+    assert hyper.shape == (N, 4, 32) and w0.shape == (256, 256) and w1.shape == (128, 64) and N % Bi == 0
+    for t_ in (x, w0, s1, w1, s0):
+        assert t_.is_contiguous() and t_.dtype == torch.bfloat16
+    hyper = hyper.to(torch.bfloat16).contiguous()
+    out = torch.empty(N, 4, 4 * es, 4 * es, dtype=torch.float32, device=x.device)
+    rc = lib.vg_mask_upscale(_p(x), _p(w0), _p(_f32(b0)), _p(s1), _p(_f32(ln_w)), _p(_f32(ln_b)), float(eps), _p(w1), _p(_f32(b1)), _p(s0), _p(hyper),
+                             _p(out), N, Bi, int(es), _dt(x), _stream())
+    _lib.check(rc, "vg_mask_upscale")
+    return out
+
+
 def layernorm(x, w, b, eps, out_dtype=None):
     lib = _lib.load()
     x2, M, ldx = _rows2d(x)

@@ -359,15 +359,22 @@ class SAM2:
             hs, src = self._two_way(src, tokens)
         iou_tok, mask_toks = hs[:, 1, :], hs[:, 2:6, :]
         s0, s1 = high_res            # [Bi, ...]: ops.add broadcasts them over the instance groups (instance i -> image i % Bi)
-        g = ops.linear(src, self.P.convT_w(self.p + d + "output_upscaling.0"))
-        up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.0"), N, es, es, 64)
-        up = ops.add(up, s1)
-        up = ops.activation(self.ln(d + "output_upscaling.1", up, 1e-6), ops.ACT_GELU)
-        g = ops.linear(up, self.P.convT_w(self.p + d + "output_upscaling.3"))
-        up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.3"), N, 2 * es, 2 * es, 32)
-        up = ops.activation(ops.add(up, s0), ops.ACT_GELU)                       # [N,4es,4es,32]
         hyper = torch.stack([self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :].contiguous(), 3) for i in range(4)], dim=1)
-        masks = ops.bmm_nt(hyper, up.view(N, 16 * es * es, 32), out_dtype=torch.float32).view(N, 4, 4 * es, 4 * es)
+        if fused:
+            # r04: upscaling + hypernetwork product in one kernel (the two [N, 16384, 64] / [N, 65536, 32] intermediates never exist)
+            masks = ops.mask_upscale(src, self.P.convT_w(self.p + d + "output_upscaling.0"), self.P.b(self.p + d + "output_upscaling.0"), s1.view(Bi, 4 * es * es, 64),
+                                     self.P.f32(self.p + d + "output_upscaling.1.weight"), self.P.f32(self.p + d + "output_upscaling.1.bias"), 1e-6,
+                                     self.P.convT_w(self.p + d + "output_upscaling.3"), self.P.b(self.p + d + "output_upscaling.3"), s0.view(Bi, 16 * es * es, 32),
+                                     hyper, es)
+        else:
+            g = ops.linear(src, self.P.convT_w(self.p + d + "output_upscaling.0"))
+            up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.0"), N, es, es, 64)
+            up = ops.add(up, s1)
+            up = ops.activation(self.ln(d + "output_upscaling.1", up, 1e-6), ops.ACT_GELU)
+            g = ops.linear(up, self.P.convT_w(self.p + d + "output_upscaling.3"))
+            up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.3"), N, 2 * es, 2 * es, 32)
+            up = ops.activation(ops.add(up, s0), ops.ACT_GELU)                       # [N,4es,4es,32]
+            masks = ops.bmm_nt(hyper, up.view(N, 16 * es * es, 32), out_dtype=torch.float32).view(N, 4, 4 * es, 4 * es)
         iou = self.mlp(d + "iou_prediction_head", iou_tok.contiguous(), 3, sigmoid_output=True, out_dtype=torch.float32)
         obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :].contiguous(), 3, out_dtype=torch.float32)
         return masks, iou, mask_toks.contiguous(), obj
