@@ -33,13 +33,40 @@ from . import ops
 
 
 class FrameSharder:
-    def __init__(self, group=None, gather_masks=True):
+    def __init__(self, group=None, gather_masks=True, profile=False):
         assert dist.is_initialized(), "init torch.distributed first (torchrun: one process per GPU)"
         assert gather_masks in (True, False, "rank0")
         self.group = group
         self.gather_masks = gather_masks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # profile (bench.py --gpus N): every collective is bracketed by events on the stream that issues it and its payload is counted, so that a
+        # scaling record shows what was exchanged, how often and for how long — collective_report()
+        self.profile = profile
+        self._events = {}
+
+    # ---- per-collective accounting (r04)
+    def _timed(self, name, nbytes, fn):
+        if not self.profile or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._events.setdefault(name, []).append((e0, e1, int(nbytes)))
+        return out
+
+    def collective_report(self, reset=True):
+        """{name: {calls, bytes_received_per_rank, ms}} of the collectives since the last report (device time between the bracketing events on
+        the issuing stream: includes the wait for the slowest rank to arrive)."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        rep = {}
+        for name, evs in self._events.items():
+            rep[name] = dict(calls=len(evs), bytes_received_per_rank=sum(b for _, _, b in evs), ms=round(sum(a.elapsed_time(b) for a, b, _ in evs), 3))
+        if reset:
+            self._events = {}
+        return rep
 
     def my_frames(self, T):
         """this rank's contiguous block of the T frames (sizes differ by at most one; a rank beyond T gets none)."""
@@ -50,7 +77,7 @@ class FrameSharder:
         base, extra = divmod(n, self.world)
         return [base + (1 if r < extra else 0) for r in range(self.world)]
 
-    def gather_blocks(self, local, n, dim, shape, dtype, device):
+    def gather_blocks(self, local, n, dim, shape, dtype, device, name="block_all_gather"):
         """all-gather of per-rank blocks of unequal length along `dim`: `local` is this rank's block (or None when it has no
         unit), `shape` the full result's shape with n units along dim.  Blocks are padded to the largest so the collective is regular."""
         counts = self.counts(n)
@@ -60,7 +87,7 @@ class FrameSharder:
         buf = torch.zeros(pshape, dtype=dtype, device=device)
         if local is not None and local.shape[dim]:
             buf.narrow(dim, 0, local.shape[dim]).copy_(local)
-        parts = self._all_gather(buf)
+        parts = self._all_gather(buf, name)
         return torch.cat([parts[r].narrow(dim, 0, counts[r]) for r in range(self.world) if counts[r]], dim=dim)
 
     def block(self, n):
@@ -69,7 +96,7 @@ class FrameSharder:
         start = self.rank * base + min(self.rank, extra)
         return start, base + (1 if self.rank < extra else 0)
 
-    def gather_rows(self, local, n, rows_per_unit, tail_shape, dtype, device):
+    def gather_rows(self, local, n, rows_per_unit, tail_shape, dtype, device, name="tower_tokens_all_gather"):
         """all-gather of per-unit row blocks of unequal count: `local` holds this rank's units ([count*rows_per_unit, *tail] or
         None when it has none); every rank gets all n units in order.  Blocks are padded to the largest count so that the
         collective is regular."""
@@ -78,30 +105,37 @@ class FrameSharder:
         buf = torch.zeros((most * rows_per_unit,) + tuple(tail_shape), dtype=dtype, device=device)
         if local is not None and local.shape[0]:
             buf[:local.shape[0]].copy_(local)
-        parts = self._all_gather(buf)
+        parts = self._all_gather(buf, name)
         counts = [base + (1 if r < extra else 0) for r in range(self.world)]
         return torch.cat([parts[r][:counts[r] * rows_per_unit] for r in range(self.world) if counts[r]], dim=0)
 
-    def _all_gather(self, t):
+    def _all_gather(self, t, name="all_gather"):
+        nbytes = t.numel() * t.element_size() * self.world
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             # plumbing runs with several ranks on ONE GPU (VG_DIST_BACKEND=gloo; tests/test_dist_hip.py): gloo moves host memory
-            host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
-            dist.all_gather(host, t.contiguous().cpu(), group=self.group)
-            return [h.to(t.device) for h in host]
-        bufs = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(bufs, t.contiguous(), group=self.group)
-        return bufs
+            def via_host():
+                host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+                dist.all_gather(host, t.contiguous().cpu(), group=self.group)
+                return [h.to(t.device) for h in host]
+            return self._timed(name + " [gloo: host-staged]", nbytes, via_host)
 
-    def all_gather_into(self, recv, send):
+        def on_device():       # RCCL: device buffers, the collective is ordered on the current stream
+            bufs = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(bufs, t.contiguous(), group=self.group)
+            return bufs
+        return self._timed(name, nbytes, on_device)
+
+    def all_gather_into(self, recv, send, name="kv_all_gather"):
         """recv [world * m, ...] <- every rank's send [m, ...], in rank order."""
+        nbytes = recv.numel() * recv.element_size()
         if send.is_cuda and dist.get_backend(self.group) == "gloo":
-            recv.copy_(torch.cat(self._all_gather(send), dim=0))
+            recv.copy_(torch.cat(self._all_gather(send, name), dim=0))
         else:
-            dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)
+            self._timed(name, nbytes, lambda: dist.all_gather(list(recv.chunk(self.world)), send, group=self.group))
 
     def sync_seg_embeddings(self, emb):
         """all-gather of the [N,256] [SEG] embeddings; every rank adopts rank 0's copy."""
-        return self._all_gather(emb)[0]
+        return self._all_gather(emb, "seg_all_gather")[0]
 
     def framewise(self, sam2, images_for_sam, emb, hw, frame_feats=None, binarize=None):
         """frame-sharded Hiera + mask decode -> (device uint8 masks [frames, N, H, W], their global frame indices): this rank's frames,
@@ -119,7 +153,7 @@ class FrameSharder:
         mine = (local if local is not None else torch.zeros((0, N) + tuple(hw), dtype=torch.uint8, device=emb.device)), frames
         if not self.gather_masks:
             return mine
-        full = self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(T))
+        full = self.gather_blocks(local, T, 0, (T, N) + tuple(hw), torch.uint8, emb.device, name="mask_gather"), list(range(T))
         return full if (self.gather_masks is True or self.rank == 0) else mine
 
     def video_branch_objects(self, sam2, images_for_sam, emb, hw, frame_feats, binarize=None, **kw):
@@ -147,7 +181,7 @@ class FrameSharder:
         mine = (local if local is not None else torch.zeros((T, 0) + tuple(hw), dtype=torch.uint8, device=emb.device)), list(range(o0, o0 + on))
         if not self.gather_masks:
             return mine
-        full = self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device), list(range(N))
+        full = self.gather_blocks(local, N, 1, (T, N) + tuple(hw), torch.uint8, emb.device, name="mask_gather"), list(range(N))
         return full if (self.gather_masks is True or self.rank == 0) else mine
 
     def gather_frame_feats(self, local_feats, T, sam2):
@@ -161,10 +195,46 @@ class FrameSharder:
         for lv in range(3):
             stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0) if frames else None      # [frames of this rank, h, w, c]
             assert stacked is None or tuple(stacked.shape[1:]) == level_shapes[lv], (tuple(stacked.shape), level_shapes[lv])
-            levels.append(self.gather_blocks(stacked, T, 0, (T,) + level_shapes[lv], sam2.dtype, sam2.device))
+            levels.append(self.gather_blocks(stacked, T, 0, (T,) + level_shapes[lv], sam2.dtype, sam2.device, name="feature_all_gather"))
         return {t: [levels[lv][t:t + 1] for lv in range(3)] for t in range(T)}
 
     def hiera_all_frames(self, sam2, images_for_sam):
-        """frame-sharded Hiera + FPN, features all-gathered level by level -> {frame: fpn levels}."""
+        """frame-sharded Hiera + FPN with the features STREAMED to every rank (video branch: the object ranks need all frames): the rank's frames
+        go through Hiera in chunks (SAM2.frame_chunk) and a chunk's three levels are all-gathered — asynchronously under RCCL — while the next
+        chunk is being computed, instead of one exchange of the whole clip's features after the last frame (r04; 8.4 MB per frame at SAM2-L).
+        Every rank runs the same number of chunk steps (blocks differ by at most one frame; a step a rank has no frame for sends an empty,
+        padded block) -> {frame: fpn levels} for all T frames."""
         T = images_for_sam.shape[0]
-        return self.gather_frame_feats(sam2.hiera_frames(images_for_sam, self.my_frames(T)), T, sam2)
+        frames = self.my_frames(T)
+        counts = self.counts(T)
+        S, ch = sam2.S, max(1, sam2.frame_chunk)
+        level_shapes = [(S // 4, S // 4, 32), (S // 8, S // 8, 64), (S // 16, S // 16, 256)]
+        starts = [sum(counts[:r]) for r in range(self.world)]
+        steps = -(-max(counts) // ch)
+        asyn = images_for_sam.is_cuda and dist.get_backend(self.group) != "gloo"
+        pending, out = [], {}
+        for st in range(steps):
+            mine = frames[st * ch:(st + 1) * ch]
+            feats = sam2.hiera_frames(images_for_sam, mine) if mine else {}
+            for lv in range(3):
+                send = torch.zeros((ch,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
+                if mine:
+                    send[:len(mine)].copy_(torch.cat([feats[t][lv] for t in mine], dim=0))
+                if asyn:
+                    recv = torch.empty((self.world * ch,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
+                    nbytes = recv.numel() * recv.element_size()
+                    work = self._timed("feature_all_gather (streamed, issue)", nbytes,
+                                       lambda: dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
+                    pending.append((st, lv, recv, work))
+                else:
+                    parts = self._all_gather(send, "feature_all_gather (streamed)")
+                    pending.append((st, lv, torch.cat(parts, dim=0), None))
+        for st, lv, recv, work in pending:
+            if work is not None:
+                work.wait()             # the current stream waits for the collective; the host does not
+            for r in range(self.world):
+                n_r = max(0, min(ch, counts[r] - st * ch))
+                for j in range(n_r):
+                    t = starts[r] + st * ch + j
+                    out.setdefault(t, [None, None, None])[lv] = recv[r * ch + j:r * ch + j + 1]
+        return out

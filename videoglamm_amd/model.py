@@ -255,13 +255,13 @@ class VideoGLaMMForCausalLM:
             self.capture["emb"] = emb
         return out_ids.unsqueeze(0), emb
 
-    def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens):
+    def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens, all_frames=False):
         """LLM side + Hiera features of this rank's frames, Hiera on the side stream (see _hiera_async)."""
         frames = self.comm.my_frames(sam.shape[0]) if self.comm is not None else None
         box = {}
 
         def start():
-            box["feats"], box["join"] = self._hiera_async(sam, frames)
+            box["feats"], box["join"] = self._hiera_async(sam, frames, all_frames)
 
         # Hiera goes to the side stream FIRST: it then shares the chip with the towers / LLM prefill (big-K, MFMA-bound
         # GEMMs that leave HBM idle, where Hiera's small-K GEMMs, norms and window shuffles are bandwidth-hungry) and is
@@ -270,7 +270,7 @@ class VideoGLaMMForCausalLM:
         mode = os.environ.get("VG_HIERA_START", "first")
         if mode == "serial":      # no overlap (per-kernel timing runs: bench.py's instrumented step)
             stage_mark(self.stages, "begin")
-            feats = self.sam2.hiera_frames(sam, frames)
+            feats = self.comm.hiera_all_frames(self.sam2, sam) if all_frames else self.sam2.hiera_frames(sam, frames)
             stage_mark(self.stages, "hiera_fpn")
             out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
             return out_ids, emb, feats
@@ -311,18 +311,21 @@ class VideoGLaMMForCausalLM:
         torch.cuda.current_stream(masks.device).synchronize()
         return out
 
-    def _hiera_async(self, sam, frames=None):
+    def _hiera_async(self, sam, frames=None, all_frames=False):
         """Hiera + FPN of the SAM frames on a side HIP stream.  It depends only on the pixels, not on the LLM, and it is
         MFMA/LDS-bound while the LLM decode loop is an HBM-bound GEMV chain: the two overlap on the chip.  Returns
         (features per frame, join) — call join() on the consuming stream before reading the features."""
+        # all_frames (multi-GPU video branch, r04): the rank's frames go through Hiera in chunks and every finished chunk is all-gathered right away
+        # (FrameSharder.hiera_all_frames) — the object ranks' features arrive while the later chunks and the LLM side still run
+        run = (lambda: self.comm.hiera_all_frames(self.sam2, sam)) if all_frames else (lambda: self.sam2.hiera_frames(sam, frames))
         if self.device.type != "cuda":
-            return self.sam2.hiera_frames(sam, frames), (lambda: None)
+            return run(), (lambda: None)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            feats = self.sam2.hiera_frames(sam, frames)
+            feats = run()
 
         def join():
             torch.cuda.current_stream(self.device).wait_stream(self._side)
@@ -360,14 +363,18 @@ class VideoGLaMMForCausalLM:
                                max_new_tokens=32):
         """R/model/VideoGLaMM.py:770-879; empty dict when no [SEG] was emitted (:840-842)."""
         sam = images_for_sam[0].to(self.device)
-        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens)
+        # multi-GPU: frames shard for Hiera only (the propagation is a recurrence over frames) and every rank needs every frame's features:
+        # they are streamed chunk by chunk while Hiera still runs (VG_FEATURES_STREAMED=0: one exchange of the whole clip after the last frame)
+        streamed = self.comm is not None and os.environ.get("VG_FEATURES_STREAMED", "1") == "1"
+        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens, all_frames=streamed)
         if emb.shape[0] == 0:
             return out_ids, [{}]
         hw = tuple(original_size_list[0])
         if self.comm is not None:
-            # frames shard for Hiera only (the propagation is a recurrence over frames); OBJECTS shard for the propagation
+            # OBJECTS shard for the propagation
             emb = self.comm.sync_seg_embeddings(emb)
-            feats = self.comm.gather_frame_feats(feats, sam.shape[0], self.sam2)
+            if not streamed:
+                feats = self.comm.gather_frame_feats(feats, sam.shape[0], self.sam2)
             stage_mark(self.stages, "feature_all_gather")
             masks, oids = self.comm.video_branch_objects(self.sam2, sam, emb, hw, feats, binarize=None if self._fast_masks() else self._binarize)
             host = self._to_host(masks)
