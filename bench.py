@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
                     help="llama3-8b = BASELINE configs C1-C3 (default); phi3-mini = the released checkpoint's LLM")
     ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="allow --gpus N with fewer than N devices (ranks share GPUs; VG_DIST_BACKEND=gloo): a plumbing check, NOT a scaling record — the line says so")
     return ap.parse_args()
 
 
@@ -418,7 +420,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    local %= torch.cuda.device_count()     # (plumbing checks run several ranks on one GPU: VG_DIST_BACKEND=gloo)
+    if world > torch.cuda.device_count() and not args.plumbing:
+        raise SystemExit(f"--gpus {world} on a node with {torch.cuda.device_count()} device(s): ranks would share GPUs and the line would not be a scaling "
+                         "record; pass --plumbing (with VG_DIST_BACKEND=gloo) for a plumbing check")
+    local %= torch.cuda.device_count()     # (--plumbing: several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     comm = None
@@ -433,6 +438,11 @@ def main():
         from videoglamm_amd.dist import FrameSharder
         # strong scaling (C3): rank 0 returns the whole clip like the reference's inference(); weak scaling: explicit opt-out of the mask exchange
         comm = FrameSharder(gather_masks="rank0" if args.scaling == "strong" else False)
+        # who is in the job: one entry per rank (device index, UUID, name) — the record is only a scaling record when the UUIDs are distinct
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "device": local, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        members = [None] * world
+        dist.all_gather_object(members, mine)
         if args.scaling == "strong" and not args.replicate_llm:
             os.environ.setdefault("VG_TOWERS_SHARDED", "1")
             os.environ.setdefault("VG_PREFILL_SHARDED", "1")
@@ -524,6 +534,28 @@ def main():
                    "weights": "random-init (synthetic)"},
         "load_s": round(t_load, 1),
     }
+    if world > 1:
+        # self-verifying multi-GPU record: the backend, who took part, what the collectives moved and how long the issuing stream spent in them
+        comm.profile = True
+        comm.collective_report()
+        step()                      # one extra pass in the timed (overlapped) configuration, outside the timed region
+        rep = comm.collective_report()
+        comm.profile = False
+        names = sorted(rep)
+        tt = torch.tensor([rep[k]["ms"] for k in names], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        for k, v in zip(names, tt.tolist()):
+            rep[k]["ms_max_over_ranks"] = round(v, 3)
+        uuids = sorted({m["uuid"] or f"device{m['device']}" for m in members})
+        res["distributed"] = {"backend": torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""),
+                              "ranks": members, "distinct_devices": len(uuids), "device_uuids": uuids,
+                              "valid_scaling_record": len(uuids) == world and torch.distributed.get_backend() == "nccl",
+                              "plumbing": bool(args.plumbing),
+                              "collectives": {"note": "one extra pass, rank 0's counts; ms = device time between events bracketing the collective on the stream that issues "
+                                                      "it (includes waiting for the slowest rank to arrive); async streamed feature gathers are bracketed at issue",
+                                              **rep}}
+        if len(uuids) != world:
+            res["distributed"]["warning"] = f"{world} ranks on {len(uuids)} device(s): ranks time-slice GPUs — NOT a scaling measurement"
     if not args.no_roofline:
         # (every rank runs these extra steps — a step contains the frame-sharding collectives — rank 0 reports)
         # instrumented extra step (not part of the timed region): per-launch HIP events on the launch stream.  It runs
@@ -561,6 +593,14 @@ def main():
                          **{k: {"ms": round(v, 2), "sharded": bool(shards.get(k, False))} for k, v in dur.items()},
                          "replicated_ms": round(sum(v for k, v in dur.items() if not shards.get(k, False)), 2),
                          "sharded_ms": round(sum(v for k, v in dur.items() if shards.get(k, False)), 2)}
+        if world > 1:
+            # the Amdahl bound of THIS run's split next to what was measured: a sharded stage measured on a rank already holds 1/world of the clip's work
+            rep_ms, sh_ms = res["stages"]["replicated_ms"], res["stages"]["sharded_ms"]
+            one_gpu = rep_ms + sh_ms * world
+            res["stages"]["amdahl"] = {"serial_one_gpu_ms_estimate": round(one_gpu, 2), "serial_this_run_ms": round(rep_ms + sh_ms, 2),
+                                       "speedup_bound_at_this_n": round(one_gpu / (rep_ms + sh_ms), 3), "speedup_bound_at_infinity": round(one_gpu / max(rep_ms, 1e-9), 3),
+                                       "measured_ms_per_step": res["ms_per_step"],
+                                       "note": "serialised-stream stage sums (no Hiera/LLM overlap): the bound is the ratio of the sums, the measured step overlaps streams"}
         dec_ms, dec_n = dm.summary()
         if os.environ.get("VG_BENCH_GEMM_SHAPES"):
             torch.cuda.synchronize()

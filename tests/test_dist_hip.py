@@ -96,3 +96,76 @@ def test_c3_two_ranks_on_one_gpu(cuda):
         assert r["fw_ids"] and r["fw_bitexact"] and r["fw_shard"] and r["fw_ref_iou"] > 0.999, (rank, r)
         assert r["vid_ids"] and r["vid_objects"] == 14 and r["vid_shard"] and r["vid_vs_single"] < 1e-4 and r["vid_ref_iou"] > 0.999, (rank, r)
         assert r["t1"] and r["llm_sharded_ids"] and r["llm_sharded_iou"] > 0.999, (rank, r)
+
+
+def _worker_rccl(port, q):
+    """ONE rank, backend "nccl" (= RCCL): the device-buffer branches of FrameSharder (dist.all_gather on device tensors, all_gather_into on
+    recv.chunk() views, the async all_gather_into_tensor of the streamed features) — the code the driver's multi-GPU run takes, which the
+    gloo runs above never enter."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    from test_oracle_e2e import e2e_setup
+    from videoglamm_amd.dist import FrameSharder
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    fx, sd, cfg, inp = e2e_setup()
+    res = {"backend": dist.get_backend()}
+
+    def run(model, ids_in, branch):
+        out_ids, segs = model.inference([inp["images"]], [inp["context_images"]], [inp["images_for_sam"]], ids_in[None], [(1024, 1024)],
+                                        [inp["original_size"]], max_new_tokens=inp["max_new_tokens"], use_sam2_video_branch=branch)
+        return out_ids[0].tolist(), segs[0]
+
+    single = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=dev)
+    comm = FrameSharder(profile=True)
+    full = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=dev, comm=comm)
+    ids6, ids14 = inp["input_ids"].long(), fx["input_ids8"].long()
+    os.environ["VG_TOWERS_SHARDED"] = os.environ["VG_PREFILL_SHARDED"] = "1"
+    for tag, ids_in, branch in (("fw", ids6, False), ("vid", ids14, True)):
+        ref_ids, ref_seg = run(single, ids_in, branch)
+        got_ids, got_seg = run(full, ids_in, branch)
+        res[tag + "_ids"] = got_ids == ref_ids
+        res[tag + "_bitexact"] = bool(np.array_equal(_stack(got_seg), _stack(ref_seg)))
+        res[tag + "_collectives"] = comm.collective_report()
+    # the LLM-side sharding's collectives are only entered at world > 1: call their device-buffer branches directly
+    send = torch.randn(5, 3, device=dev)
+    recv = torch.empty(5, 3, device=dev)
+    comm.all_gather_into(recv, send)
+    rows = comm.gather_rows(send[:4], 2, 2, (3,), torch.float32, dev)
+    blocks = comm.gather_blocks(send.view(1, 5, 3), 5, 1, (1, 5, 3), torch.float32, dev)
+    torch.cuda.synchronize()
+    res["direct"] = bool(torch.equal(recv, send) and torch.equal(rows, send[:4]) and torch.equal(blocks, send.view(1, 5, 3)))
+    res["direct_collectives"] = comm.collective_report()
+    os.environ["VG_FEATURES_STREAMED"] = "0"          # the one-exchange-after-Hiera form of the feature gather
+    got_ids, got_seg = run(full, ids14, True)
+    res["vid_unstreamed_bitexact"] = bool(np.array_equal(_stack(got_seg), _stack(ref_seg)))
+    res["vid_unstreamed_collectives"] = comm.collective_report()
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_device_buffer_branches_single_rank(cuda):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(31500 + os.getpid() % 2000, q))
+    p.start()
+    r = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert r["backend"] == "nccl"
+    assert r["fw_ids"] and r["fw_bitexact"] and r["vid_ids"] and r["vid_bitexact"] and r["vid_unstreamed_bitexact"], r
+    fw, vid, un = r["fw_collectives"], r["vid_collectives"], r["vid_unstreamed_collectives"]
+    assert not any("gloo" in k for k in list(fw) + list(vid) + list(un)), (fw, vid, un)          # the device-buffer branch ran
+    assert {"seg_all_gather", "mask_gather"} <= set(fw) and fw["seg_all_gather"]["bytes_received_per_rank"] == 6 * 256 * 4, fw
+    assert any(k.startswith("feature_all_gather (streamed") for k in vid) and "mask_gather" in vid, vid
+    assert "feature_all_gather" in un and not any("streamed" in k for k in un), un
+    assert r["direct"] and {"kv_all_gather", "tower_tokens_all_gather", "block_all_gather"} <= set(r["direct_collectives"]), r

@@ -86,3 +86,58 @@ def test_c4_shape_fp8_llm_path_vs_bf16(cuda):
     print(f"C4 shape, fp8 LLM path vs bf16: mask IoU per object {[round(float(v), 4) for v in iou]}, [SEG] embedding cosine {cos:.4f}")
     assert torch.isfinite(cap8["logits"]).all() and cos > 0.99 and iou.mean() > 0.98 and iou.min() > 0.95, (cos, iou.tolist())
     assert len(free) > 0
+
+
+def test_c1_workload_bf16_vs_fp32_mode(cuda):
+    """C1's exact shape (BASELINE.json configs[0], the reference's own demo shape): 8-frame 512^2-source clip, Te = 8 -> a 1697-row prompt (other
+    GEMM tile routes than C2's 3361 rows) and 512^2 output masks (vg_bilinear_mask 256^2 -> 512^2), one [SEG]."""
+    bench, args = _bench_args(["--frames", "8", "--te", "8", "--src", "512"])
+    cfg, model, step, ids = _build(bench, args, cuda)
+    assert ids.shape[1] - 8 + 208 * 8 == 1697
+    q = bench.quality(cfg, args, model, step, cuda)
+    print("C1 whole workload:", q)
+    out_ids, segs = step()
+    assert out_ids.shape[1] == ids.shape[1] + args.max_new_tokens and sorted(segs[0]) == list(range(8)) and segs[0][0][0].shape == (512, 512)
+    assert q["finite"] and q["seg_objects"] == 1
+    assert q["mask_miou_vs_fp32"] > 0.99 and q["min_frame_iou_vs_fp32"] > 0.98, q
+    assert q["ids_top1_agree"] >= 0.9 and q["seg_emb_cosine"] > 0.999, q
+    assert 0.05 < q["mask_fraction"] < 0.95
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_c4_clip_64_frames_8_objects(cuda):
+    """C4's real clip on one GPU (64 frames, 8 [SEG] objects, framewise branch): 512 (frame, object) mask-decoder instances through the fused
+    two-way path in four 128-pair launch groups.  Properties: the framewise branch treats frames independently, so (i) the clip's first 16 frames
+    equal a 16-frame clip of the same pixels, (ii) the clip with its frames reversed gives the reversed masks; the LLM side does not see the SAM
+    frames, so the ids are those of the 16-frame run."""
+    bench, args = _bench_args(["--frames", "64", "--objects", "8"])
+    cfg, model, step, ids = _build(bench, args, cuda)
+    images, context, sam, ids = bench.make_inputs(cfg, args, 1, cuda)
+
+    def run(frames):
+        cap = model.capture = {}
+        out, segs = model.inference([images], [context], [frames], ids, [(1024, 1024)], [(1024, 1024)], max_new_tokens=args.max_new_tokens)
+        model.capture = None
+        return out[0].tolist(), cap["logits"], segs
+
+    ids64, lg64, segs = run(sam)
+    gen = ids64[ids.shape[1]:]
+    assert sum(t == cfg["seg_token_idx"] for t in gen) == 8 and lg64.shape == (64, 8, 1024, 1024) and torch.isfinite(lg64).all()
+    assert sorted(segs[0]) == list(range(64)) and len(segs[0][63]) == 8 and segs[0][63][7].shape == (1024, 1024)
+    m64 = lg64 > 0
+    frac = m64.float().mean().item()
+    assert 0.02 < frac < 0.98, frac
+    del lg64
+    ids16, lg16, _ = run(sam[:16])
+    assert ids16 == ids64
+    m16 = lg16 > 0
+    inter, union = (m16 & m64[:16]).sum().item(), (m16 | m64[:16]).sum().item()
+    assert inter / max(union, 1) > 0.9995, inter / max(union, 1)            # (another chunk / pair-group composition: bf16 summation orders differ)
+    del lg16, m16
+    _, lgr, _ = run(sam.flip(0))
+    mr = (lgr > 0).flip(0)
+    inter, union = (mr & m64).sum().item(), (mr | m64).sum().item()
+    assert inter / max(union, 1) > 0.9995, inter / max(union, 1)
+    del model
+    torch.cuda.empty_cache()
