@@ -119,6 +119,17 @@ int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, i
 /* skv_dev (may be NULL): when given, the kernel uses Skv = *skv_dev + Sq read from device memory instead of the
  * host value, so one captured decode step can be replayed from a HIP graph as the KV cache grows. */
 
+/* Attention whose VALUES (and output) have DV dims while queries / keys have D (one head group, no mask): SAM2's memory cross-attention
+ * with the v-projection moved behind the attention — the reference computes softmax(q k^T) (M Wv^T + b)
+ * (R/model/segment_anything_2/sam2/modeling/sam/transformer.py:289-327, memory_attention.py:60-99); softmax rows sum to one, so that equals
+ * (softmax(q k^T) M) Wv^T + b: the projection then runs on the 4096 query rows instead of the ~28 000 memory rows and the PV half of the
+ * attention works on the memory's own 64 dims.  Built for bf16, D in (128, 256], DV = 64 (VG_ERR_UNSUPPORTED otherwise).  V rows [.., DV], O rows [.., DV];
+ * workspace (nsplit > 1): fp32, >= B*H*nsplit*Sq*(DV+2) floats. */
+int vg_attention_dv(const void* Q, const void* K, const void* V, void* O, int B, int H, int Sq, int Skv, int D, int DV,
+                    int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb,
+                    int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int dtype,
+                    float* workspace, int64_t ws_floats, int nsplit, vg_stream_t stream);
+
 /* Fused HF rotate-half RoPE + KV-cache append for one decoder layer (HF LlamaAttention.forward: apply_rotary_pos_emb
  * then cache update).  qkv: fused projection output [S, (H+2*Hkv)*D], row stride ld; q rotated in place, rotated k
  * and plain v written to k_cache/v_cache[pos+s] ([max_len,Hkv,D]).  pos = pos_dev ? *pos_dev : pos0. */

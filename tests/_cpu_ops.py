@@ -74,6 +74,10 @@ def attention(q, k, v, scale, causal=False, window=0):
     return (p @ vf).permute(0, 2, 1, 3).contiguous().to(q.dtype)
 
 
+def attention_dv(q, k, v, scale):
+    return attention(q, k, v, scale)
+
+
 def window_attention(q, k, v, scale):
     return None          # (the dedicated window kernels are a device-only route)
 

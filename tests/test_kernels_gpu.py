@@ -285,6 +285,34 @@ def test_attention(cuda, dtype, cfg):
     close(o, ref.attention(q, k, v, D ** -0.5, causal), **t)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Sq,Skv,D,DV", [(1, 1024, 2100, 256, 64),      # ragged KV, one workgroup row per 128 queries -> split-KV + merge
+                                           (8, 4096, 7 * 4096 + 64, 256, 64),     # C4's per-frame shape (8 objects, 7 memory frames + pointers): no split
+                                           (2, 320, 700, 256, 64), (1, 4096, 4096 + 4, 256, 64)])
+def test_attention_dv(cuda, dtype, B, Sq, Skv, D, DV):
+    """vg_attention_dv (SAM2 memory cross-attention on the un-projected 64-d memory): keys of 256 dims, values / output of 64, against the fp32
+    statement; and the identity the host relies on — softmax(q k^T) (M Wv^T + b) == (softmax(q k^T) M) Wv^T + b — against vg_attention on
+    the projected values."""
+    from videoglamm_amd import ops
+    if B * Sq * Skv > 3e8 and dtype == torch.float32:
+        pytest.skip("the fp32 statement of this shape is a bf16-only size")
+    q, k, v = rnd(B, Sq, 1, D, dtype=dtype, seed=1), rnd(B, Skv, 1, D, dtype=dtype, seed=2), rnd(B, Skv, 1, DV, dtype=dtype, seed=3)
+    v[:, Skv // 3] *= 6.0                      # a few large value rows and one key spike (forces the running-max rescale)
+    k[:, Skv // 2] *= 4.0
+    o = ops.attention_dv(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5)
+    assert o.shape == (B, Sq, 1, DV)
+    t = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    if B * Sq * Skv <= 3e8:
+        close(o, ref.attention(q, k, v, D ** -0.5), **t)
+    else:                                        # the big shape: a slice of the queries of two batch entries against the statement
+        for b in (0, B - 1):
+            close(o[b:b + 1, 100:356], ref.attention(q[b:b + 1, 100:356], k[b:b + 1], v[b:b + 1], D ** -0.5), **t)
+    if dtype == torch.float32 and B * Sq * Skv <= 3e8:
+        wv, bv = rnd(D, DV, seed=4, scale=DV ** -0.5), rnd(D, seed=5)
+        full = ops.attention(q.to(cuda), k.to(cuda), ops.linear(v.to(cuda), wv.to(cuda), bv.to(cuda)), D ** -0.5)
+        close(ops.linear(o, wv.to(cuda), bv.to(cuda)), full.cpu(), rtol=1e-3, atol=1e-4)
+
+
 def test_attention_fused_qkv_strides_and_spike(cuda):
     """q/k/v as strided slices of one fused projection + a key spike that forces the online-softmax rescale."""
     from videoglamm_amd import ops

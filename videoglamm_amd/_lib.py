@@ -31,6 +31,7 @@ def _sig(lib):
         "vg_gemm_window": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),
         "vg_attention_splitkv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P, L, I, P, P], c_int),
+        "vg_attention_dv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, P, L, I, P], c_int),
         "vg_window_attention": ([P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P], c_int),
         "vg_rope_kv_append": ([P, L, P, P, P, P, I, I, I, I, I, P, I, P], c_int),
         "vg_store_row": ([P, P, L, P, I, I, P], c_int),

@@ -22,6 +22,7 @@ struct AttnArgs {
   int xcd;                 // 1: (batch, head) blocks per XCD (see attn_kernel); needs (Hq * B) % 8 == 0
   float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
   const int* skv_dev;      // optional: Skv = *skv_dev + Sq read on the device (graph-replayable decode step)
+  int DV;                  // value / output head dim (== D except for the low-rank memory attention: vg_attention_dv)
   int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
                            // (row = g*Sq + q) of ONE query tile, so K/V are staged once per KV head (G*Sq <= tile)
 };
@@ -94,7 +95,10 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 // 32 query rows — 8 waves on the LDS footprint of 4, each with its own (O, m, l) over its half of the keys, merged through LDS
 // once after the last tile.  At head dim 256 the 128 accumulator registers of a wave leave room for one wave per SIMD only
 // when a wave owns whole tiles; two waves per SIMD let one wave's softmax / staging VALU run under the other's MFMAs.
-template <typename T, int DP, int BKV, int NW, int KS = 1>
+// DVP (default DP): padded head dim of V and of the output when it differs from Q / K's — SAM2's memory cross-attention keeps its values in the
+// memory's own 64 dims (softmax rows sum to one, so P (M Wv^T + b) = (P M) Wv^T + b: the v-projection moves behind the attention, onto 4096 rows
+// instead of 28 000, and the PV half of the kernel shrinks four-fold: vg_attention_dv, r04).  Only on the paths without the transpose read.
+template <typename T, int DP, int BKV, int NW, int KS = 1, int DVP = DP>
 __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 : (DP <= 128 ? VG_ATTN_MINW : 1)))) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
@@ -105,7 +109,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   constexpr int BQ = NQW * 32;
   constexpr int NT = NW * 64;
   constexpr int NG = DP * ES / 32;  // k-groups (two 16-byte chunks each) along the head dim
-  constexpr int NDT = DP / 32;
+  constexpr int NDT = DVP / 32;
+  constexpr int RSVF = DVP * ES + 16;   // V row stride where V is staged as rows (fp32)
+  constexpr int CPRV = DVP * ES / 16;
+  static_assert(DVP == DP || DP > 128, "a separate value dim only on the head-dim-256 paths");
   constexpr int NKT = BKV / 32 / KS;   // 32-key sub-tiles of a KV tile this wave multiplies
   static_assert(KS == 1 || (KS == 2 && BKV == 64 && sizeof(T) == 2), "key split: two waves per 64-key bf16 tile");
   // VTR (bf16, head dim <= 128 = the PIPE path): V goes to LDS as it comes (padded rows, like K) and the PV step's V^T fragments are read with
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   const int q0 = qtile * BQ;
   const int G = p.Hq / p.Hkv;
   const int kvh = p.fold ? head : head / G;
-  const int D = p.D, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
+  const int D = p.D, DV = p.DV, Sq = p.Sq, Skv = p.skv_dev ? (*p.skv_dev + p.Sq) : p.Skv;
   const int nrow = p.fold ? G * Sq : Sq;   // valid rows of the query tile space
   const T* Qg = (const T*)p.Q + (int64_t)b * p.q_sb + (p.fold ? 0 : (int64_t)head * p.q_sh);
   const T* Kg = (const T*)p.K + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
@@ -205,15 +212,23 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   constexpr bool VT = sizeof(T) == 2 && !VTR;
   static_assert(!VT || BKV == 64, "the transposed V image assumes 64-key tiles");
   constexpr int NKI = (BKV * CPR + NT - 1) / NT;                 // K chunks per thread per tile
-  constexpr int NVI = VT ? (16 * CPR + NT - 1) / NT : NKI;       // V items per thread: (key quad, chunk) | chunks
+  constexpr int NVI = VT ? (16 * CPRV + NT - 1) / NT : (BKV * CPRV + NT - 1) / NT;       // V items per thread: (key quad, chunk) | chunks
   u32x4_t kreg[NKI], vreg[VT ? NVI * 4 : NVI];
   auto fetch = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < NKI; ++i) {
       const int idx = tid + i * NT, row = idx / CPR, c = idx - row * CPR, key = kv0 + row;
       kreg[i] = (idx < BKV * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Kg + (int64_t)key * p.k_ss + c * KPC) : zero4;
-      if constexpr (!VT)
-        vreg[i] = (idx < BKV * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
+    }
+    if constexpr (!VT) {
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        // rows past the end of the sequence read the LAST row instead of being zero-filled: their probabilities are exactly zero (masked scores), so
+        // any finite value does — and the load is unconditional (r04: with the 64-wide value rows of vg_attention_dv the zero-filling select went
+        // wrong in fp32 exactly when one wave's four row groups were all valid and the other's last one was not: Skv % 32 in [28, 31])
+        const int idx = tid + i * NT, row = idx / CPRV, c = idx - row * CPRV, key = min(kv0 + row, Skv - 1);
+        vreg[i] = (idx < BKV * CPRV && c * KPC < DV) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
+      }
     }
     if constexpr (VT) {
 #pragma unroll
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int key = kv0 + kq * 4 + j;
-          vreg[i * 4 + j] = (item < 16 * CPR && key < Skv && c * KPC < D) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
+          vreg[i * 4 + j] = (item < 16 * CPRV && key < Skv && c * KPC < DV) ? *(const u32x4_t*)(Vg + (int64_t)key * p.v_ss + c * KPC) : zero4;
         }
       }
     }
@@ -231,16 +246,20 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
     for (int i = 0; i < NKI; ++i) {
       const int idx = tid + i * NT, row = idx / CPR, c = idx - row * CPR;
-      if (idx < BKV * CPR) {
-        *(u32x4_t*)(Ks + row * RS + c * 16) = kreg[i];
-        if constexpr (!VT) *(u32x4_t*)(Vs + row * (VTR ? RSV : RS) + c * 16) = vreg[i];
+      if (idx < BKV * CPR) *(u32x4_t*)(Ks + row * RS + c * 16) = kreg[i];
+    }
+    if constexpr (!VT) {
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int idx = tid + i * NT, row = idx / CPRV, c = idx - row * CPRV;
+        if (idx < BKV * CPRV) *(u32x4_t*)(Vs + row * (VTR ? RSV : RSVF) + c * 16) = vreg[i];
       }
     }
     if constexpr (VT) {
 #pragma unroll
       for (int i = 0; i < NVI; ++i) {
         const int item = tid + i * NT, kq = item & 15, c = item >> 4;
-        if (item < 16 * CPR) {
+        if (item < 16 * CPRV) {
           const int b4 = (kq * 4) & 15;
           const int pos = ((kq * 4) & ~15) + (b4 == 4 ? 8 : (b4 == 8 ? 4 : b4));   // key permutation inside a 16-block
           const int grp = pos >> 3, half = (pos >> 2) & 1;
@@ -426,11 +445,11 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
     } else {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        const char* vs = Vs + kt * 32 * RS;
+        const char* vs = Vs + kt * 32 * RSVF;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
           if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
-          else pv_step_f32<RS>(vs, dt * 32 + l31, h, s[kt], o[dt]);
+          else pv_step_f32<RSVF>(vs, dt * 32 + l31, h, s[kt], o[dt]);
         }
       }
     }
@@ -463,19 +482,19 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   }
   if (p.nsplit > 1) {
     if (q_row < nrow) {
-      float* pp = p.part + ((((int64_t)b * p.Hq + q_head) * p.nsplit + split) * Sq + q_idx) * (D + 2);
+      float* pp = p.part + ((((int64_t)b * p.Hq + q_head) * p.nsplit + split) * Sq + q_idx) * (DV + 2);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {       // 4 consecutive head-dim values per register quad; a partial row starts 8-byte aligned (D + 2 is even)
           const int d0 = dt * 32 + 8 * g + 4 * h;
-          if (d0 < D) {
+          if (d0 < DV) {
             const float2 lo = {o[dt][4 * g], o[dt][4 * g + 1]}, hi = {o[dt][4 * g + 2], o[dt][4 * g + 3]};
             *(float2*)(pp + d0) = lo;
             *(float2*)(pp + d0 + 2) = hi;
           }
         }
-      if (h == 0) { pp[D] = m_i * 0.6931471805599453f; pp[D + 1] = l_i; }
+      if (h == 0) { pp[DV] = m_i * 0.6931471805599453f; pp[DV + 1] = l_i; }
     }
     return;
   }
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d0 = dt * 32 + 8 * g + 4 * h;
-          if (d0 < D) {
+          if (d0 < DV) {
             if constexpr (sizeof(T) == 2) {
               uint2 v;
               v.x = f2bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
@@ -509,29 +528,30 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int d = dt * 32 + mfma32_row(r, h);
-          if (d < D) vg_elt<T>::st(Og + d, o[dt][r] * inv);
+          if (d < DV) vg_elt<T>::st(Og + d, o[dt][r] * inv);
         }
     }
   }
 }
 
-template <typename T, int DP, int BKV, int NW, int KS = 1>
+template <typename T, int DP, int BKV, int NW, int KS = 1, int DVP = DP>
 static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RS = DP * sizeof(T) + 16;
+  constexpr int RSVF = DVP * sizeof(T) + 16;
   constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
   constexpr int RSV = DP * (int)sizeof(T) + (DP == 128 ? 32 : 16);
-  constexpr int vbytes = VTR ? BKV * RSV : (sizeof(T) == 2 ? DP * 128 : BKV * RS);   // bf16, head dim 256: transposed V image, DP rows of 64 keys
+  constexpr int vbytes = VTR ? BKV * RSV : (sizeof(T) == 2 ? DVP * 128 : BKV * RSVF);   // bf16, head dim 256: transposed V image, DP rows of 64 keys
   constexpr int BQ = NW / KS * 32;
   constexpr int lds = (BQ + BKV) * RS + vbytes;
-  static_assert(KS == 1 || lds >= (NW / KS) * (DP / 32 * 16 + 2) * 64 * 4, "the key-half merge reuses the tile buffers");
+  static_assert(KS == 1 || lds >= (NW / KS) * (DVP / 32 * 16 + 2) * 64 * 4, "the key-half merge reuses the tile buffers");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<T, DP, BKV, NW, KS, DVP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(((p.Sq + BQ - 1) / BQ) * p.nsplit, p.Hq, p.B);
   if (p.fold) grid = dim3(p.nsplit, p.Hkv, p.B);
-  attn_kernel<T, DP, BKV, NW, KS><<<grid, NW * 64, lds, st>>>(p);
+  attn_kernel<T, DP, BKV, NW, KS, DVP><<<grid, NW * 64, lds, st>>>(p);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -918,7 +938,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p) {
   __shared__ float wgt[64];
   __shared__ float s_l;
-  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, D = p.D, ns = p.nsplit;
+  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z, D = p.DV, ns = p.nsplit;      // (rows of the VALUE dim)
   const float* base = p.part + (((int64_t)b * p.Hq + head) * ns * p.Sq + q) * (D + 2);
   const int64_t sstride = (int64_t)p.Sq * (D + 2);
   if (threadIdx.x < 64) {
@@ -953,12 +973,17 @@ static int dispatch_dp(const AttnArgs& p, hipStream_t st) {
   return launch_attn<T, 256, BKV, NW>(p, st);
 }
 
-extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
-                                    int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
-                                    int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
-                                    int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
-                                    int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
-                                    const int* skv_dev, vg_stream_t stream) {
+static int attention_impl(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                          int Sq, int Skv, int D, int DV, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                          int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                          int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                          int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
+                          const int* skv_dev, vg_stream_t stream) {
+  // (bf16 only: the fp32 instantiation <float, 256, 32, 2, 1, 64> mis-scored ONE key — row 27 of a 32-key tile — whenever the last tile held 28..31
+  // keys (tools/lab/dv_debug2.py: one-hot values; the <.., 256> value width of the same source is exact) and was not worth an ISA-level hunt: the
+  // fp32 parity mode zero-pads the values to the key width on the host instead (ops.attention_dv), same arithmetic on the exact-fp32 kernel)
+  VG_CHECK(DV == D || (DV == 64 && D > 128 && Hq == Hkv && causal == 0 && dtype == VG_BF16), VG_ERR_UNSUPPORTED,
+           "vg_attention_dv: a value head dim other than the query's is built for bf16, D in (128, 256], DV = 64, no GQA, no mask (D=%d DV=%d dtype=%d)", D, DV, dtype);
   VG_CHECK(nsplit <= 64, VG_ERR_ARG, "vg_attention_splitkv: nsplit must be <= 64");
   VG_CHECK(Q && K && V && O, VG_ERR_ARG, "vg_attention: null pointer");
   VG_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Sq >= 0 && Skv > 0, VG_ERR_ARG,
@@ -978,11 +1003,11 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   int split_len = 0;
   if (nsplit > 1) {
     split_len = (((Skv + nsplit - 1) / nsplit) + 63) / 64 * 64;   // whole KV tiles per split
-    VG_CHECK(workspace && ws_floats >= (int64_t)B * Hq * nsplit * Sq * (D + 2), VG_ERR_ARG,
-             "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(D+2) floats)");
+    VG_CHECK(workspace && ws_floats >= (int64_t)B * Hq * nsplit * Sq * (DV + 2), VG_ERR_ARG,
+             "vg_attention_splitkv: workspace too small (need B*Hq*nsplit*Sq*(DV+2) floats)");
   }
   AttnArgs p{Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, causal, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh,
-             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, 0, workspace, skv_dev, 0};
+             v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, nsplit, split_len, 0, workspace, skv_dev, DV, 0};
   // fold the G query heads of a KV head into one query tile when they all fit (decode: G*Sq = 4 rows): K/V staged
   // once per KV head instead of once per query head
   const int tile_rows = dtype == VG_BF16 ? 128 : 64;
@@ -998,7 +1023,9 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD (VG_ATTN_KS2, A/B knob)
   static const int ks2 = getenv("VG_ATTN_KS2") ? atoi(getenv("VG_ATTN_KS2")) : 1;
   int rc;
-  if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
+  if (DV != D) {
+    rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);
+  } else if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2>(p, st);
   } else if (dtype == VG_BF16 && nw8 && !p.fold && nsplit == 1 && Sq >= 2048 && D > 64 && D <= 128 && causal == 0) {
     rc = D <= 96 ? launch_attn<bf16_t, 96, 64, 8>(p, st) : launch_attn<bf16_t, 128, 64, 8>(p, st);
@@ -1011,6 +1038,28 @@ extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V,
   else attn_combine_kernel<float><<<grid, 256, 0, st>>>(p);
   VG_LAUNCH_CHECK();
   return VG_OK;
+}
+
+extern "C" int vg_attention_splitkv(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
+                                    int Sq, int Skv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                                    int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                                    int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                                    int causal, int dtype, float* workspace, int64_t ws_floats, int nsplit,
+                                    const int* skv_dev, vg_stream_t stream) {
+  return attention_impl(Q, K, V, O, B, Hq, Hkv, Sq, Skv, D, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, causal,
+                        dtype, workspace, ws_floats, nsplit, skv_dev, stream);
+}
+
+// Attention whose values (and output) live in DV dims while queries and keys have D: SAM2's memory cross-attention with the v-projection moved
+// behind the attention (R/modeling/sam/transformer.py:289-327 computes softmax(q k^T) (M Wv^T + b); rows of the softmax sum to one, so that is
+// (softmax(q k^T) M) Wv^T + b).  V / O rows hold DV elements; the split-KV workspace holds B*Hq*nsplit*Sq*(DV+2) floats.
+extern "C" int vg_attention_dv(const void* Q, const void* K, const void* V, void* O, int B, int H, int Sq, int Skv, int D, int DV,
+                               int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                               int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale,
+                               int dtype, float* workspace, int64_t ws_floats, int nsplit, vg_stream_t stream) {
+  VG_CHECK(DV > 0 && DV % 8 == 0, VG_ERR_ARG, "vg_attention_dv: bad DV %d", DV);
+  return attention_impl(Q, K, V, O, B, H, H, Sq, Skv, D, DV, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh, scale, 0,
+                        dtype, workspace, ws_floats, nsplit ? nsplit : 1, nullptr, stream);
 }
 
 extern "C" int vg_attention(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,

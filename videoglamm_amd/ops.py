@@ -257,6 +257,34 @@ def attention(q, k, v, scale, causal=False, window=0):
     return out
 
 
+def attention_dv(q, k, v, scale):
+    """softmax(q k^T * scale) v with values of another width than the keys: q [B,Sq,H,D], k [B,Skv,H,D], v [B,Skv,H,DV] -> [B,Sq,H,DV]
+    (vg_attention_dv: SAM2's memory cross-attention on the un-projected memory, D = 256, DV = 64)."""
+    lib = _lib.load()
+    B, Sq, H, D = q.shape
+    Skv, DV = k.shape[1], v.shape[3]
+    assert k.shape == (B, Skv, H, D) and v.shape[:3] == (B, Skv, H) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if q.dtype != torch.bfloat16:
+        # fp32 parity mode: the values zero-padded to the key width through vg_attention (exact fp32 MFMA chain), the first DV columns kept —
+        # the same arithmetic; the DV-wide kernel is built for bf16 only (vg_attention.hip: attention_impl)
+        vp = torch.zeros(B, Skv, H, D, dtype=q.dtype, device=q.device)
+        vp[..., :DV].copy_(v)
+        return attention(q, k, vp, scale)[..., :DV].contiguous()
+    out = torch.empty(B, Sq, H, DV, dtype=q.dtype, device=q.device)
+    nsplit, ws = 1, None
+    blocks = -(-Sq // 128) * H * B
+    if Skv >= 512 and blocks < 384:
+        nsplit = max(1, min(64, _SPLIT_WG_D256 // blocks, Skv // 128))
+    if nsplit > 1:
+        ws = torch.empty(B * H * nsplit * Sq * (DV + 2), dtype=torch.float32, device=q.device)
+    rc = lib.vg_attention_dv(_p(q), _p(k), _p(v), _p(out), B, H, Sq, Skv, D, DV,
+                             q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                             v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                             float(scale), _dt(q), _p(ws), 0 if ws is None else ws.numel(), nsplit, _stream())
+    _lib.check(rc, "vg_attention_dv")
+    return out
+
+
 _WIN_SHAPES = {(256, 256), (16, 16), (64, 64), (4, 16), (16, 64)}
 
 

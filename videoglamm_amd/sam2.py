@@ -14,6 +14,7 @@ import torch
 from . import ops
 
 NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
+_MEMATTN_LOWRANK = os.environ.get("VG_MEMATTN_LOWRANK", "1") == "1"   # memory cross-attention: v-projection behind the attention (A/B knob)
 
 
 def _stack_views(ts):
@@ -391,6 +392,21 @@ class SAM2:
         o = ops.attention(q.view(B, nq, 1, c), k.view(B, -1, 1, c), v.view(B, -1, 1, c), c ** -0.5)
         return self.lin(name + ".out_proj", o.view(B, nq, c), residual=residual)
 
+    def _rope_attn_lowrank(self, name, q_in, k_in, mem, n_exclude, residual):
+        """The memory cross-attention with the v-projection BEHIND the attention (r04): the reference computes softmax(q k^T) (M Wv^T + b_v)
+        (R/modeling/sam/transformer.py:289-327 with kv_in_dim = 64, memory_attention.py:60-99); the softmax rows sum to one, so that is
+        (softmax(q k^T) M) Wv^T + b_v — the attention's PV half then works on the memory's own 64 dims (vg_attention_dv: a quarter of the PV
+        MFMAs and V bytes) and the projection runs on the nq query rows instead of the ~7 x nq memory rows."""
+        q, k = self.lin(name + ".q_proj", q_in), self.lin(name + ".k_proj", k_in)
+        B, nq, c = q.shape
+        cos, sin = self.P.const(("axial_cos", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[0], torch.float32), \
+            self.P.const(("axial_sin", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[1], torch.float32)
+        ops.rope_axial_(q, cos, sin, nq, nq)
+        ops.rope_axial_(k, cos, sin, k.shape[1] - n_exclude, nq)
+        pm = ops.attention_dv(q.view(B, nq, 1, c), k.view(B, -1, 1, c), mem.view(B, -1, 1, mem.shape[-1]), c ** -0.5)
+        o = self.lin(name + ".v_proj", pm.view(B, nq, mem.shape[-1]))
+        return self.lin(name + ".out_proj", o, residual=residual)
+
     def memory_attention(self, curr, memory, memory_pos, num_obj_ptr_tokens):
         """MemoryAttention.forward — R/modeling/memory_attention.py:119-169,60-99 (batch-first throughout).
         curr [N,HW,256]; memory, memory_pos [N,M,64] -> [N,HW,256]."""
@@ -402,7 +418,8 @@ class SAM2:
             t2 = self.ln(l + "norm1", out)
             out = self._rope_attn(l + "self_attn", t2, t2, t2, 0, out)
             t2 = self.ln(l + "norm2", out)
-            out = self._rope_attn(l + "cross_attn_image", t2, mem_k, memory, num_obj_ptr_tokens, out)
+            cross = self._rope_attn_lowrank if _MEMATTN_LOWRANK and memory.shape[-1] == 64 else self._rope_attn
+            out = cross(l + "cross_attn_image", t2, mem_k, memory, num_obj_ptr_tokens, out)
             t2 = self.ln(l + "norm3", out)
             out = self.lin(l + "linear2", self.lin(l + "linear1", t2, act=ops.ACT_RELU), residual=out)
         return self.ln(m + "norm", out)
