@@ -292,7 +292,7 @@ def meter_decode_gemv(model, ops, reps=3):
         return None
     return rec[0][2], [1e3 * a.elapsed_time(b) for a, b, _ in rec]
 
-PMC_TAG = "r03_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
+PMC_TAG = "r04_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
 
 
 def quality(cfg, args, model, step, device):
@@ -633,8 +633,19 @@ def main():
             path = os.path.join(ROOT, "profiles", f"{PMC_TAG}_kt_{mode}.json")
             if pmc_ok and key and os.path.exists(path):
                 with open(path) as fh:
-                    return json.load(fh)["kernels"].get(key)
+                    doc = json.load(fh)
+                # the committed trace only speaks for the library it was taken on (tools/kt_json.py stamps its sha256): after any kernel change the
+                # trace-derived fields are dropped until the profiles are re-collected — `frac` (live events of THIS run) is the headline fraction
+                if doc.get("lib_sha16") != LIB_SHA16:
+                    stale_traces.add(os.path.basename(path))
+                    return None
+                return doc["kernels"].get(key)
             return None
+
+        import hashlib
+        so = os.path.join(ROOT, "videoglamm_amd", "csrc", "libvgkernels.so")
+        LIB_SHA16 = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+        stale_traces = set()
 
         def roof(kernel, label, scope=None, key=None):
             flops, ms, n, nbytes = gm.summary(kernel, scope)
@@ -649,18 +660,24 @@ def main():
             for mode in ("serial", "overlapped"):
                 t = trace_of(key, mode)
                 if t and n:
-                    # the same algorithmic flops per launch over the rocprofv3 average of the committed trace of that stream configuration
+                    # the same algorithmic flops per launch over the rocprofv3 average of the committed trace of that stream configuration — only when
+                    # the trace's class holds the launches the live meter counted (ops.linear): a class that also takes window / split-K / bmm launches
+                    # (r03: 136 glds launches in the trace against 104 metered) would divide one population's flops by another's time
                     r[f"avg_launch_us_trace_{mode}"] = t["avg_us"]
+                    r[f"launches_trace_{mode}"] = t["launches_per_pass"]
+                    if abs(t["launches_per_pass"] - n) > 0.02 * n:
+                        r[f"frac_trace_{mode}"] = None
+                        continue
                     r[f"frac_trace_{mode}"] = round(flops / n / (t["avg_us"] * 1e-6) / 1e12 / peak, 4)
                     if t.get("mfma_busy_frac") is not None:
                         r[f"mfma_busy_frac_{mode}"] = t["mfma_busy_frac"]
-            if "frac_trace_overlapped" in r:
+            if r.get("frac_trace_overlapped") is not None:
                 r["frac_overlapped"] = r["frac_trace_overlapped"]
             return r
         # one object per tile kernel; "roofline" is the one with the most GPU time in the step
         labels = {"glds": "gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)",
                   "k64b": "gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)",
-                  "w128": "gemm_tile_w128x8_kernel<bf16> (256x256 tile, 8 waves of 128x64: grids that fill the chip)",
+                  "w128": "gemm_tile_p8_kernel<bf16> (256x256 tile, 8 waves of 128x64, phase-split K steps; r04: replaces gemm_tile_w128x8_kernel on the 256x256 route)",
                   "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)",
                   "small64": "gemm_small64_kernel<bf16> (64x64 tile, whole K <= 256 in one DMA burst: problems of < 256 128x128 tiles — memory attention, mask decoder)"}
         roofs = {k: roof(k, labels[k], key="gemm_" + k) for k in labels}
@@ -702,6 +719,8 @@ def main():
         # "roofline" = the kernel with the most GPU time in a step; the others ride along under their own keys
         main = max(roofs, key=lambda k: roofs[k]["kernel_ms_per_step"])
         res["roofline"] = roofs.pop(main)
+        if stale_traces:
+            res["roofline"]["committed_traces_stale"] = sorted(stale_traces)      # taken on another build of the library: trace-derived fields omitted
         for k, v in roofs.items():
             res["roofline_" + k] = v
         # the mask-decoder GEMMs (S7/S8: two-way transformer projections, ConvT-as-GEMM upscaling, hypernetwork MLPs and product), over whatever

@@ -12,7 +12,9 @@ every SIMD of the chip (the 256x256-tile GEMM: 286.0 M busy cycles per launch ag
 algorithmic MFMAs + 6.6 % of row padding at M = 3361).  A PMC pass serialises the dispatches, so the counter fraction is a property of the
 kernel running alone (the "serial" configuration) whichever stream configuration the command asks for.
 usage: python tools/kt_json.py <kt.db> <out.json> <passes> <mode> "<command>" [<mfma_pmc.db>]"""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
@@ -20,6 +22,7 @@ import sys
 from pmc_json import CLASSES
 
 SIMDS_PER_XCD_SUM = 1024 / 8.0     # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs
+INIT_KERNELS = r"distribution_elementwise_grid_stride_kernel|AUnaryFunctor<float, float, float, at::native::binary_internal::MulFunctor"
 
 
 def main():
@@ -34,7 +37,11 @@ def main():
              "group by k.name, p.counter_name")
         for name, ctr, n, tot in pdb.execute(q):
             pm.setdefault(name, {})[ctr] = (n, tot)
-    res = {"round": 3, "mode": mode, "command": command, "passes": passes,
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "videoglamm_amd", "csrc", "libvgkernels.so")
+    lib_sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
+    # (model-build kernels — the synthetic weights' RNG and scaling — run once per process, not per pass: kept out of the per-pass total)
+    rows = [r for r in rows if not re.search(INIT_KERNELS, r[0])]
+    res = {"round": 4, "lib_sha16": lib_sha, "mode": mode, "command": command, "passes": passes,
            "total_kernel_ms_per_pass": round(sum(r[2] for r in rows) / 1e3 / passes, 2), "kernels": {}}
     for key, pat in CLASSES:
         sel = [r for r in rows if re.search(pat, r[0])]

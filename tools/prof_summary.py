@@ -7,8 +7,14 @@ db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 cur = db.cursor()
 rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc"))
+import re
+# synthetic-weight generation (torch RNG + scaling at model build) runs once per process: not part of a step, listed apart
+INIT = r"distribution_elementwise_grid_stride_kernel|AUnaryFunctor<float, float, float, at::native::binary_internal::MulFunctor"
+init = [r for r in rows if re.search(INIT, r[0])]
+rows = [r for r in rows if not re.search(INIT, r[0])]
 tot = sum(r[2] for r in rows)
-print(f"total kernel time {tot:.2f} ms over {steps:g} step(s) = {tot / steps:.2f} ms/step")
+print(f"total kernel time {tot:.2f} ms over {steps:g} step(s) = {tot / steps:.2f} ms/step"
+      + (f"   (+ {sum(r[2] for r in init):.1f} ms of model-build kernels — synthetic weight RNG / scaling, {sum(r[1] for r in init)} launches, once per process — not in the table)" if init else ""))
 print(f"{'ms/step':>10} {'launches/step':>14} {'avg us':>10}  kernel")
 for r in rows[:30]:
     print(f"{r[2] / steps:10.2f} {r[1] / steps:14.1f} {r[3]:10.1f}  {r[0][:110]}")

@@ -190,7 +190,7 @@ class FrameSharder:
         a local frame, so a rank without frames (T < world size) takes part in the collective with an empty block."""
         frames = self.my_frames(T)
         S = sam2.S
-        level_shapes = [(S // 4, S // 4, 32), (S // 8, S // 8, 64), (S // 16, S // 16, 256)]
+        level_shapes = sam2.level_shapes()
         levels = []
         for lv in range(3):
             stacked = torch.cat([local_feats[t][lv] for t in frames], dim=0) if frames else None      # [frames of this rank, h, w, c]
@@ -208,7 +208,7 @@ class FrameSharder:
         frames = self.my_frames(T)
         counts = self.counts(T)
         S, ch = sam2.S, max(1, sam2.frame_chunk)
-        level_shapes = [(S // 4, S // 4, 32), (S // 8, S // 8, 64), (S // 16, S // 16, 256)]
+        level_shapes = sam2.level_shapes()
         starts = [sum(counts[:r]) for r in range(self.world)]
         steps = -(-max(counts) // ch)
         asyn = images_for_sam.is_cuda and dist.get_backend(self.group) != "gloo"

@@ -41,6 +41,10 @@ def _stream():
 import contextlib as _contextlib
 
 
+_capture_lock = __import__("threading").Lock()
+_capture_depth = [0, True]      # [captures in flight, the collector was enabled when the first one began]
+
+
 @_contextlib.contextmanager
 def graph_capture(g):
     """torch.cuda.graph(g) with Python's cyclic garbage collector held off for the duration of the capture.  A capture of the decode step or of
@@ -49,15 +53,21 @@ def graph_capture(g):
     calls their destructors make are illegal while a stream is capturing and abort the process (seen r03: tests/test_kernels_gpu.py's graph
     tests followed by an end-to-end capture in one process)."""
     import gc
-    gc.collect()
-    was = gc.isenabled()
-    gc.disable()
+    # the collector is process-wide state: a lock + depth counter make nested / concurrent captures restore it exactly once (ADVICE r03)
+    with _capture_lock:
+        if _capture_depth[0] == 0:
+            gc.collect()
+            _capture_depth[1] = gc.isenabled()
+            gc.disable()
+        _capture_depth[0] += 1
     try:
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             yield
     finally:
-        if was:
-            gc.enable()
+        with _capture_lock:
+            _capture_depth[0] -= 1
+            if _capture_depth[0] == 0 and _capture_depth[1]:
+                gc.enable()
 
 
 def _f32(t):
@@ -151,7 +161,7 @@ def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
     o2, Mo, ldc = _rows2d(out)
-    assert Mo == M and out.dtype == odt
+    assert Mo == M and out.dtype == odt and out.shape[-1] == N, (tuple(out.shape), M, N, out.dtype, odt)      # (a wider / narrower `out` would be written with a wrong row stride)
     r2, ldr = None, 0
     if residual is not None:
         assert residual.dtype == odt

@@ -90,9 +90,8 @@ class SAM2:
         # ONE buffer per level for all requested frames: the chunks' last kernels write straight into their rows, so consecutive frames stay
         # consecutive views across chunk borders and the consumers' batches (_stack_views) never copy (r03: a 32-pair mask-decoder batch over two
         # 16-frame chunks cat 268 MB of FPN levels per C2 clip)
-        S, n = self.S, len(frames)
-        bufs = [torch.empty(n, S // 4, S // 4, 32, dtype=self.dtype, device=self.device), torch.empty(n, S // 8, S // 8, 64, dtype=self.dtype, device=self.device),
-                torch.empty(n, S // 16, S // 16, 256, dtype=self.dtype, device=self.device)]
+        n = len(frames)
+        bufs = [torch.empty((n,) + shp, dtype=self.dtype, device=self.device) for shp in self.level_shapes()]
         for c0 in range(0, n, self.frame_chunk):
             fr = frames[c0:c0 + self.frame_chunk]
             fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr],
@@ -102,6 +101,15 @@ class SAM2:
         return out
 
     # ------------------------------------------------------------------ small helpers
+    def level_shapes(self):
+        """(h, w, c) of the three FPN levels forward_image returns, channel widths read off the weights that produce them (conv_s0, conv_s1, the
+        neck's top lateral): hiera_frames' clip-wide buffers and dist.py's exchanges are sized from here, not from SAM2-L's 32 / 64 / 256."""
+        S = self.S
+        c0 = self.P.w(self.p + "sam_mask_decoder.conv_s0").shape[0]
+        c1 = self.P.w(self.p + "sam_mask_decoder.conv_s1").shape[0]
+        c2 = self.P.w(self.p + "image_encoder.neck.convs.0.conv").shape[0]
+        return [(S // 4, S // 4, c0), (S // 8, S // 8, c1), (S // 16, S // 16, c2)]
+
     def lin(self, name, x, **kw):
         return ops.linear(x, self.P.w(self.p + name), self.P.b(self.p + name), **kw)
 
