@@ -281,7 +281,8 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   if (PF && kv_begin < kv_end) fetch(kv_begin);
   // QREG (bf16, head dim <= 128): the wave's Q fragments stay in registers for the whole KV walk — one of every five LDS reads of a tile
   // (NG of 5 NG per 64 keys) was the same Q bytes again, and the loop is LDS-read-bound at eight waves per CU
-  constexpr bool QREG = VG_ATTN_QREG && sizeof(T) == 2 && DP <= 128;
+  // (r04: also the head-dim-256 kernel when its values are 64 wide — vg_attention_dv: 2 instead of 8 output accumulators leave room for the 64 Q registers)
+  constexpr bool QREG = VG_ATTN_QREG && sizeof(T) == 2 && (DP <= 128 || DVP <= 64);
   u32x4_t qreg[QREG ? NG : 1];
   if constexpr (QREG) {
     __syncthreads();
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
     // PIPE (bf16, head dim <= 128): the K / Q fragments of k-group g + 1 are requested before the MFMAs of group g issue, and the
     // sub-tiles' independent accumulators alternate — left to itself the compiler emits read, wait, MFMA per fragment (measured r02:
     // every MFMA of the loop then pays a full LDS round trip); head dim 256 has no registers to spare for the second fragment set
-    constexpr bool PIPE = sizeof(T) == 2 && DP <= 128;
+    constexpr bool PIPE = sizeof(T) == 2 && (DP <= 128 || DVP <= 64);
     if constexpr (PIPE) {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
