@@ -270,6 +270,12 @@ int vg_im2col(const void* x, void* cols, int B, int H, int W, int C, int kh, int
  * R/.../memory_encoder.py:81-87) */
 int vg_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C,
               int k, int dtype, vg_stream_t stream);
+/* Conv2d(k = 3, stride 2, pad 1) + bias -> LayerNorm over the channels (eps) -> GELU(erf) in ONE pass, channels-last:
+ * x:[B,H,W,Cin] -> y:[B,(H+1)/2,(W+1)/2,Cout]; w:[Cout, ldw] in the tensors' dtype with column (ky*3+kx)*Cin + c (vg_im2col's column order);
+ * bias / ln_w / ln_b fp32.  The few-channel stages of SAM2's MaskDownSampler (R/.../memory_encoder.py:17-63: 1->4->16 channels at
+ * 512^2 / 256^2 outputs, LayerNorm2d + GELU after every conv) — built for exactly the pairs 1->4 and 4->16, VG_ERR_UNSUPPORTED otherwise. */
+int vg_conv3s2_ln_gelu(const void* x, const void* w, int64_t ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
+                       void* y, int B, int H, int W, int Cin, int Cout, int dtype, vg_stream_t stream);
 /* ConvTranspose2d k2 s2 tail: g:[B,H,W,4,C] (GEMM output, tap = dy*2+dx) -> y:[B,2H,2W,C] (+bias)
  * R/.../sam/mask_decoder.py:64-73 */
 int vg_pixel_shuffle2(const void* g, const float* bias, void* y, int B, int H, int W, int C, int dtype,

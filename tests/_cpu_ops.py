@@ -292,6 +292,18 @@ def dwconv(x, w, bias, k):
     return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
 
 
+def conv3s2_ln_gelu(x, w, bias, ln_w, ln_b, eps):
+    """memory_encoder.py:17-63 on channels-last tensors: Conv2d(3, stride 2, pad 1) -> LayerNorm2d -> GELU."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if (Cin, Cout) not in ((1, 4), (4, 16)):
+        return None
+    wt = w.float()[:, : 9 * Cin].reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, stride=2, padding=1).permute(0, 2, 3, 1)
+    y = F.gelu(F.layer_norm(y, (Cout,), ln_w, ln_b, eps))
+    return y.contiguous().to(x.dtype)
+
+
 def pixel_shuffle2(g, bias, B, H, W, C):
     y = g.float().reshape(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C)
     if bias is not None:

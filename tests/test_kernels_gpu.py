@@ -313,6 +313,26 @@ def test_attention_dv(cuda, dtype, B, Sq, Skv, D, DV):
         close(ops.linear(o, wv.to(cuda), bv.to(cuda)), full.cpu(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_memory_encoder_spatial_kernels(cuda, dtype):
+    """r04: the strip depthwise 7x7 kernel (bf16: 8 channels x 4 pixels per thread; widths that are not multiples of the strip, image borders) and
+    the fused Conv2d(3, stride 2, pad 1) + LayerNorm2d + GELU stages of the mask downsampler (1 -> 4 -> 16 channels, odd sizes too)."""
+    from videoglamm_amd import ops
+    for (B, H, W, C) in ((2, 64, 64, 256), (1, 9, 13, 16), (3, 5, 4, 8)):
+        x, w, b = rnd(B, H, W, C, dtype=dtype, seed=1), rnd(49, C, seed=2, scale=0.2), rnd(C, seed=3)
+        close(ops.dwconv(x.to(cuda), w.to(cuda), b.to(cuda), 7), ref.dwconv(x, w, b, 7), **tol(dtype, 49))
+    for (B, H, W, Cin, Cout) in ((2, 64, 48, 1, 4), (2, 32, 32, 4, 16), (1, 7, 9, 4, 16), (1, 1024, 1024, 1, 4)):
+        x = rnd(B, H, W, Cin, dtype=dtype, seed=4)
+        kp = (9 * Cin + 15) // 16 * 16
+        w = torch.zeros(Cout, kp, dtype=dtype)
+        w[:, : 9 * Cin] = rnd(Cout, 9 * Cin, dtype=dtype, seed=5, scale=(9 * Cin) ** -0.5)
+        bias, lw, lb = rnd(Cout, seed=6), 1.0 + 0.2 * rnd(Cout, seed=7), 0.1 * rnd(Cout, seed=8)
+        y = ops.conv3s2_ln_gelu(x.to(cuda), w.to(cuda), bias.to(cuda), lw.to(cuda), lb.to(cuda), 1e-6)
+        assert y.shape == (B, (H + 1) // 2, (W + 1) // 2, Cout)
+        close(y, ref.conv3s2_ln_gelu(x, w, bias, lw, lb, 1e-6), **(dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)))
+    assert ops.conv3s2_ln_gelu(rnd(1, 8, 8, 16, dtype=dtype).to(cuda), rnd(64, 144, dtype=dtype).to(cuda), None, None, None, 1e-6) is None
+
+
 def test_attention_fused_qkv_strides_and_spike(cuda):
     """q/k/v as strided slices of one fused projection + a key spike that forces the online-softmax rescale."""
     from videoglamm_amd import ops

@@ -62,6 +62,7 @@ def _sig(lib):
         "vg_permute5": ([P, P, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), I, P], c_int),
         "vg_im2col": ([P, P, I, I, I, I, I, I, I, I, I, I, P], c_int),
         "vg_dwconv": ([P, P, P, P, I, I, I, I, I, I, P], c_int),
+        "vg_conv3s2_ln_gelu": ([P, P, L, P, P, P, F, P, I, I, I, I, I, I, P], c_int),
         "vg_pixel_shuffle2": ([P, P, P, I, I, I, I, I, P], c_int),
         "vg_pool2": ([P, P, I, I, I, I, L, I, I, P], c_int),
         "vg_window_partition": ([P, P, I, I, I, I, I, I, P], c_int),

@@ -91,10 +91,183 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const void* x, const float*
     st_any(y, i, dt, acc);
   }
 }
+// bf16, 8 channels x 4 consecutive output pixels per thread (r04): 16-byte loads, a loaded input pixel feeds up to four outputs and a row of taps is
+// loaded once per strip — 42 load instructions per output instead of 147 two-byte ones.  The taps of an output are accumulated in the scalar
+// kernel's order (ky, then kx, out-of-image taps skipped), so the two kernels agree bit for bit.  Measured on the memory encoder's fuser
+// ([8, 64, 64, 256], k = 7; C4's clip on the video branch): 365 us per launch with the scalar kernel = 58 ms of a 907 ms clip.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int P = K / 2, SW = 4;
+  const int CG = C / 8, WS = (W + SW - 1) / SW;
+  const int64_t n = (int64_t)B * H * WS * CG;
+  SP_LOOP(i, n) {
+    const int cg = (int)(i % CG);
+    int64_t r = i / CG;
+    const int sx = (int)(r % WS); r /= WS;
+    const int oy = (int)(r % H);
+    const int b = (int)(r / H);
+    const int c0 = cg * 8, ox0 = sx * SW;
+    float acc[SW][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float bv = bias ? bias[c0 + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < SW; ++j) acc[j][e] = bv;
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy - P + ky;
+      if (iy < 0 || iy >= H) continue;
+      float wk[K][8];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const f32x4_t w0 = *(const f32x4_t*)(w + (int64_t)(ky * K + kx) * C + c0), w1 = *(const f32x4_t*)(w + (int64_t)(ky * K + kx) * C + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wk[kx][e] = w0[e]; wk[kx][4 + e] = w1[e]; }
+      }
+      const bf16_t* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+#pragma unroll
+      for (int t = 0; t < SW + K - 1; ++t) {
+        const int ix = ox0 - P + t;
+        if (ix < 0 || ix >= W) continue;
+        const u32x4_t xv = *(const u32x4_t*)(row + (int64_t)ix * C);
+        float xf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xf[2 * e] = __uint_as_float(xv[e] << 16); xf[2 * e + 1] = __uint_as_float(xv[e] & 0xffff0000u); }
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+          const int kx = t - j;
+          if (kx >= 0 && kx < K) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(xf[e], wk[kx][e], acc[j][e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SW; ++j) {
+      if (ox0 + j < W) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf2(acc[j][2 * e], acc[j][2 * e + 1]);
+        *(u32x4_t*)(y + (((int64_t)b * H + oy) * W + ox0 + j) * C + c0) = o;
+      }
+    }
+  }
+}
+
 extern "C" int vg_dwconv(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                          int dtype, vg_stream_t stream) {
   VG_CHECK(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && (k & 1), VG_ERR_ARG, "vg_dwconv: bad args");
+  if (dtype == VG_BF16 && k == 7 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) == 0) {
+    const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (C / 8);
+    dwconv_strip_kernel<7><<<sp_grid(n), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, w, bias, (bf16_t*)y, B, H, W, C);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   dwconv_kernel<<<sp_grid((int64_t)B * H * W * C), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, B, H, W, C, k, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// SAM2 memory encoder, mask downsampler stages with few channels (R/modeling/memory_encoder.py:17-63: Conv2d(k = 3, stride 2, pad 1) -> LayerNorm2d
+// -> GELU, the stages 1 -> 4 and 4 -> 16 channels; 16 -> 64 stays a GEMM: 9216 FMAs per output pixel are too many for a thread — that instantiation
+// spilled 2.2 KB per lane and made the clip slower): ONE pass, a thread per output pixel with all COUT channels in registers — the conv's 9 CIN inputs against
+// weights broadcast from LDS, then the channel LayerNorm and the GELU on the fp32 sums.  As im2col + GEMM + norm + activation (four launches on
+// [N x 512^2, 4]-shaped operands: K = 9 padded to 16, N = 4 ...) these three stages were im2col 29 + norm 34 + GEMM / GELU ~20 ms of C4's 907 ms
+// video-branch clip.  x [B, H, W, CIN] -> y [B, H/2, W/2, COUT] channels-last; w [COUT, ldw] in the tensors' dtype, column (ky * 3 + kx) * CIN + c.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3s2_ln_gelu_kernel(const void* __restrict__ x, const void* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                              const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, void* __restrict__ y,
+                                                              int B, int H, int W, int dt) {
+  __shared__ __attribute__((aligned(16))) float ws[9 * CIN * COUT];      // [k = tap * CIN + c][COUT]: a thread reads the COUT weights of input k as float4s
+  for (int idx = threadIdx.x; idx < 9 * CIN * COUT; idx += 256) {
+    const int o = idx % COUT, k = idx / COUT;
+    ws[idx] = ld_any(w, (int64_t)o * ldw + k, dt);
+  }
+  __syncthreads();
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)B * Ho * Wo;
+  SP_LOOP(i, n) {
+    const int ox = (int)(i % Wo);
+    int64_t r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll 1
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const int64_t base = (((int64_t)b * H + iy) * W + ix) * CIN;
+        const float* wk = ws + (ky * 3 + kx) * CIN * COUT;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float xv = ld_any(x, base + c, dt);
+#pragma unroll
+          for (int o4 = 0; o4 < COUT / 4; ++o4) {
+            const f32x4_t wv = *(const f32x4_t*)(wk + c * COUT + o4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o4 * 4 + e] = fmaf(xv, wv[e], acc[o4 * 4 + e]);
+          }
+        }
+      }
+    }
+    float mean = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) mean += acc[o];
+    mean *= 1.0f / COUT;
+    float var = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) { const float d = acc[o] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(var * (1.0f / COUT) + eps);
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = vg_act((acc[o] - mean) * rstd * lnw[o] + lnb[o], VG_ACT_GELU);
+    if (dt == VG_BF16) {
+      bf16_t* yo = (bf16_t*)y + i * COUT;
+      if constexpr (COUT >= 8) {
+#pragma unroll
+        for (int q = 0; q < COUT / 8; ++q) {
+          u32x4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = f2bf2(acc[q * 8 + 2 * e], acc[q * 8 + 2 * e + 1]);
+          *(u32x4_t*)(yo + q * 8) = v;
+        }
+      } else {
+        uint2 v;
+        v.x = f2bf2(acc[0], acc[1]);
+        v.y = f2bf2(acc[2], acc[3]);
+        *(uint2*)yo = v;
+      }
+    } else {
+      float* yo = (float*)y + i * COUT;
+#pragma unroll
+      for (int q = 0; q < COUT / 4; ++q) {
+        const f32x4_t v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        *(f32x4_t*)(yo + q * 4) = v;
+      }
+    }
+  }
+}
+extern "C" int vg_conv3s2_ln_gelu(const void* x, const void* w, int64_t ldw, const float* bias, const float* ln_w, const float* ln_b, float eps, void* y,
+                                  int B, int H, int W, int Cin, int Cout, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && w && ln_w && ln_b && y && B > 0 && H > 0 && W > 0, VG_ERR_ARG, "vg_conv3s2_ln_gelu: bad args");
+  VG_CHECK(dtype == VG_F32 || dtype == VG_BF16, VG_ERR_ARG, "vg_conv3s2_ln_gelu: bad dtype %d", dtype);
+  VG_CHECK(((uintptr_t)y & 15) == 0, VG_ERR_ARG, "vg_conv3s2_ln_gelu: y must be 16-byte aligned");
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 1 && Cout == 4) conv3s2_ln_gelu_kernel<1, 4><<<sp_grid(n), 256, 0, st>>>(x, w, (int)ldw, bias, ln_w, ln_b, eps, y, B, H, W, dtype);
+  else if (Cin == 4 && Cout == 16) conv3s2_ln_gelu_kernel<4, 16><<<sp_grid(n), 256, 0, st>>>(x, w, (int)ldw, bias, ln_w, ln_b, eps, y, B, H, W, dtype);
+  else {
+    vg_set_error("vg_conv3s2_ln_gelu: built for the channel pairs 1->4 and 4->16 (got %d->%d)", Cin, Cout);
+    return VG_ERR_UNSUPPORTED;
+  }
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -747,6 +747,23 @@ def dwconv(x, w, bias, k):
     return out
 
 
+def conv3s2_ln_gelu(x, w, bias, ln_w, ln_b, eps):
+    """Conv2d(k 3, stride 2, pad 1) + LayerNorm2d + GELU in one pass (vg_conv3s2_ln_gelu): x [B,H,W,Cin] channels-last, w [Cout, Kpad] in
+    vg_im2col's column order -> [B,(H+1)/2,(W+1)/2,Cout]; None when the channel pair is not one the kernel is built for."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if (Cin, Cout) not in ((1, 4), (4, 16)) or w.dtype != x.dtype:
+        return None
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cout, dtype=x.dtype, device=x.device)
+    assert w.stride(1) == 1 and w.shape[1] >= 9 * Cin
+    rc = lib.vg_conv3s2_ln_gelu(_p(x), _p(w), w.stride(0), _p(_f32(bias)), _p(_f32(ln_w)), _p(_f32(ln_b)), float(eps), _p(out), B, H, W, Cin, Cout,
+                                _dt(x), _stream())
+    _lib.check(rc, "vg_conv3s2_ln_gelu")
+    return out
+
+
 def pixel_shuffle2(g, bias, B, H, W, C):
     """g: GEMM output [B*H*W, 4*C] (tap-major) -> [B, 2H, 2W, C] (+bias)."""
     lib = _lib.load()

@@ -14,6 +14,7 @@ import torch
 from . import ops
 
 NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
+_MEMENC_FUSED = os.environ.get("VG_MEMENC_FUSED", "1") == "1"         # memory encoder: fused conv + LayerNorm2d + GELU stages (A/B knob)
 _MEMATTN_LOWRANK = os.environ.get("VG_MEMATTN_LOWRANK", "1") == "1"   # memory cross-attention: v-projection behind the attention (A/B knob)
 
 
@@ -441,6 +442,12 @@ class SAM2:
         x, H = mask, self.S
         for i in range(4):
             w = self.P.conv_w(f"{self.p}{e}mask_downsampler.encoder.{3 * i}")
+            if _MEMENC_FUSED:      # the few-channel stages (1 -> 4 -> 16): conv + LayerNorm2d + GELU in one pass (r04)
+                ln = f"{self.p}{e}mask_downsampler.encoder.{3 * i + 1}"
+                y = ops.conv3s2_ln_gelu(x, w, self.P.b(f"{self.p}{e}mask_downsampler.encoder.{3 * i}"), self.P.f32(ln + ".weight"), self.P.f32(ln + ".bias"), 1e-6)
+                if y is not None:
+                    x = y
+                    continue
             cols, Ho, Wo = ops.im2col(x, 3, 3, 2, 1, w.shape[1])
             x = ops.linear(cols, w, self.P.b(f"{self.p}{e}mask_downsampler.encoder.{3 * i}"))
             x = ops.activation(self.ln(f"{e}mask_downsampler.encoder.{3 * i + 1}", x, 1e-6), ops.ACT_GELU).view(N, Ho, Wo, -1)
