@@ -243,6 +243,10 @@ int vg_rope_half(void* x, int64_t x_ss, int64_t x_sh, const float* cos, const fl
  * R/model/segment_anything_2/sam2/modeling/position_encoding.py:174-216, sam/transformer.py:306-312 */
 int vg_rope_axial(void* x, const float* cos, const float* sin, int B, int N, int C, int n_rope,
                   int n_grid, int dtype, vg_stream_t stream);
+/* The same rotation on a STRIDED view holding H heads of Ch channels per row (bf16): x[b, n, h*Ch + c] at x + b*sb + n*ld (elements), every head
+ * with the one [n_grid, Ch/2] table — the q | k columns of a fused q|k|v projection in one in-place launch (SAM2 memory self-attention, r04). */
+int vg_rope_axial_heads(void* x, int64_t ld, int64_t sb, const float* cos, const float* sin, int B, int H, int Ch, int n_rope,
+                        int n_grid, int dtype, vg_stream_t stream);
 /* out[i,:] = table[ids[i],:]   (nn.Embedding) */
 int vg_embed(const int64_t* ids, const void* table, void* out, int64_t n, int D, int dtype,
              vg_stream_t stream);

@@ -199,6 +199,14 @@ def rope_axial_(x, cos, sin, n_rope, n_grid):
     return x
 
 
+def rope_axial_heads_(x, heads, cos, sin, n_rope, n_grid):
+    Ch = 2 * cos.shape[1]
+    for h in range(heads):
+        part = x[..., h * Ch:(h + 1) * Ch].contiguous()
+        x[..., h * Ch:(h + 1) * Ch] = rope_axial_(part, cos, sin, n_rope, n_grid)
+    return x
+
+
 def embed(ids, table):
     return table[ids.reshape(-1)]
 

@@ -333,6 +333,28 @@ def test_memory_encoder_spatial_kernels(cuda, dtype):
     assert ops.conv3s2_ln_gelu(rnd(1, 8, 8, 16, dtype=dtype).to(cuda), rnd(64, 144, dtype=dtype).to(cuda), None, None, None, 1e-6) is None
 
 
+def test_rope_axial_heads(cuda):
+    """the vectorised / strided axial RoPE (r04) against the scalar kernel's arithmetic: bit for bit on a contiguous tensor (vg_rope_axial routes bf16
+    there), and on the q | k columns of a fused q|k|v row (two heads, stride 3 C) against per-head rotations; tokens past n_rope untouched."""
+    from videoglamm_amd import ops
+    B, N, C, grid = 2, 70, 64, 64
+    cos, sin = torch.cos(rnd(grid, C // 2, seed=1)), torch.sin(rnd(grid, C // 2, seed=1))
+    x = rnd(B, N, C, dtype=torch.bfloat16, seed=2)
+    y = ops.rope_axial_(x.clone().to(cuda), cos.to(cuda), sin.to(cuda), 64, grid)
+    close(y, ref.rope_axial_(x.clone(), cos, sin, 64, grid), rtol=1e-2, atol=1e-2)
+    xf = x.float()
+    a, b = xf[:, :64, 0::2], xf[:, :64, 1::2]
+    exact = torch.stack([a * cos - b * sin, a * sin + b * cos], dim=-1).reshape(B, 64, C).to(torch.bfloat16)
+    close(y[:, :64], exact, rtol=8e-3, atol=1e-3)           # (one bf16 ulp: the device contracts a c - b s into an fma)
+    assert torch.equal(y[:, 64:].cpu(), x[:, 64:])
+    qkv = rnd(B, N, 3 * C, dtype=torch.bfloat16, seed=3)
+    z = ops.rope_axial_heads_(qkv.clone().to(cuda), 2, cos.to(cuda), sin.to(cuda), 64, grid).cpu()
+    for h in range(2):
+        part = ops.rope_axial_(qkv[..., h * C:(h + 1) * C].contiguous().to(cuda), cos.to(cuda), sin.to(cuda), 64, grid).cpu()
+        assert torch.equal(z[..., h * C:(h + 1) * C], part)
+    assert torch.equal(z[..., 2 * C:], qkv[..., 2 * C:])
+
+
 def test_attention_fused_qkv_strides_and_spike(cuda):
     """q/k/v as strided slices of one fused projection + a key spike that forces the online-softmax rescale."""
     from videoglamm_amd import ops

@@ -56,6 +56,7 @@ def _sig(lib):
         "vg_threshold": ([P, P, L, P], c_int),
         "vg_rope_half": ([P, L, L, P, P, I, I, I, I, I, P], c_int),
         "vg_rope_axial": ([P, P, P, I, I, I, I, I, I, P], c_int),
+        "vg_rope_axial_heads": ([P, L, L, P, P, I, I, I, I, I, I, P], c_int),
         "vg_embed": ([P, P, P, L, I, I, P], c_int),
         "vg_argmax": ([P, L, I, P, I, P], c_int),
         "vg_multimask_select": ([P, P, P, P, P, P, P, I, L, I, F, F, I, I, P], c_int),

@@ -203,11 +203,47 @@ __global__ __launch_bounds__(256) void rope_axial_kernel(void* x, const float* c
     st_any(x, base + 1, dt, a * s + bb * c);
   }
 }
+// bf16, four complex pairs (16 bytes) per thread, rows of ld elements holding H heads of Ch channels each (one table for every head): the q | k
+// columns of a fused q|k|v projection are rotated in ONE launch, in place, as a strided view (r04).  Same arithmetic per pair as the scalar kernel
+// (a c - b s, a s + b c in fp32, one rounding), so the two agree bit for bit.
+__global__ __launch_bounds__(256) void rope_axial_vec_kernel(bf16_t* x, int64_t ld, int64_t sb, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                             int B, int H, int Ch, int n_rope, int n_grid) {
+  const int q8 = Ch / 8, hc = Ch / 2;
+  const int64_t n = (int64_t)B * n_rope * H * q8;
+  PW_LOOP(i, n) {
+    const int c8 = (int)(i % q8);
+    int64_t t = i / q8;
+    const int h = (int)(t % H); t /= H;
+    const int tok = (int)(t % n_rope);
+    const int b = (int)(t / n_rope);
+    bf16_t* px = x + (int64_t)b * sb + (int64_t)tok * ld + h * Ch + c8 * 8;
+    const int g = tok % n_grid;
+    const f32x4_t c = *(const f32x4_t*)(cs + (int64_t)g * hc + c8 * 4), sv = *(const f32x4_t*)(sn + (int64_t)g * hc + c8 * 4);
+    u32x4_t v = *(const u32x4_t*)px;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __uint_as_float(v[e] << 16), bb = __uint_as_float(v[e] & 0xffff0000u);
+      v[e] = (uint32_t)f2bf(a * c[e] - bb * sv[e]) | ((uint32_t)f2bf(a * sv[e] + bb * c[e]) << 16);
+    }
+    *(u32x4_t*)px = v;
+  }
+}
+extern "C" int vg_rope_axial_heads(void* x, int64_t ld, int64_t sb, const float* cos, const float* sin, int B, int H, int Ch, int n_rope, int n_grid,
+                                   int dtype, vg_stream_t stream) {
+  VG_CHECK(x && cos && sin && B > 0 && H > 0 && Ch > 0 && Ch % 8 == 0 && n_rope >= 0 && n_grid > 0 && ld >= (int64_t)H * Ch && ld % 8 == 0 && sb % 8 == 0 &&
+               ((uintptr_t)x & 15) == 0 && dtype == VG_BF16, VG_ERR_ARG, "vg_rope_axial_heads: bad args (bf16, 16-byte aligned rows, Ch a multiple of 8)");
+  if (n_rope == 0) return VG_OK;
+  rope_axial_vec_kernel<<<pw_grid((int64_t)B * n_rope * H * (Ch / 8)), 256, 0, (hipStream_t)stream>>>((bf16_t*)x, ld, sb, cos, sin, B, H, Ch, n_rope, n_grid);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
 extern "C" int vg_rope_axial(void* x, const float* cos, const float* sin, int B, int N, int C, int n_rope, int n_grid,
                              int dtype, vg_stream_t stream) {
   VG_CHECK(x && cos && sin && B > 0 && N > 0 && C % 2 == 0 && n_rope >= 0 && n_rope <= N && n_grid > 0, VG_ERR_ARG,
            "vg_rope_axial: bad args");
   if (n_rope == 0) return VG_OK;
+  if (dtype == VG_BF16 && C % 8 == 0 && ((uintptr_t)x & 15) == 0)
+    return vg_rope_axial_heads(x, C, (int64_t)N * C, cos, sin, B, 1, C, n_rope, n_grid, dtype, stream);
   rope_axial_kernel<<<pw_grid((int64_t)B * n_rope * C / 2), 256, 0, (hipStream_t)stream>>>(x, cos, sin, B, N, C, n_rope, n_grid, dtype);
   VG_LAUNCH_CHECK();
   return VG_OK;

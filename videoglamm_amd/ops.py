@@ -678,6 +678,18 @@ def rope_axial_(x, cos, sin, n_rope, n_grid):
     return x
 
 
+def rope_axial_heads_(x, heads, cos, sin, n_rope, n_grid):
+    """in place on the first heads * Ch columns of x [B, N, >= heads*Ch] (row / batch strides free, columns contiguous; bf16): every head of
+    Ch = 2 * cos.shape[1] channels rotated with the one table — q | k of a fused q|k|v projection in one launch."""
+    lib = _lib.load()
+    B, N, _ = x.shape
+    Ch = 2 * cos.shape[1]
+    assert x.stride(2) == 1 and x.shape[2] >= heads * Ch and x.dtype == torch.bfloat16
+    rc = lib.vg_rope_axial_heads(_p(x), x.stride(1), x.stride(0), _p(_f32(cos)), _p(_f32(sin)), B, heads, Ch, int(n_rope), int(n_grid), _dt(x), _stream())
+    _lib.check(rc, "vg_rope_axial_heads")
+    return x
+
+
 def embed(ids, table):
     lib = _lib.load()
     ids = ids.contiguous().view(-1)

@@ -14,6 +14,7 @@ import torch
 from . import ops
 
 NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
+_SELFATTN_FUSED = os.environ.get("VG_SELFATTN_FUSED", "1") == "1"     # memory self-attention: fused q|k|v projection + one RoPE launch (A/B knob)
 _MEMENC_FUSED = os.environ.get("VG_MEMENC_FUSED", "1") == "1"         # memory encoder: fused conv + LayerNorm2d + GELU stages (A/B knob)
 _MEMATTN_LOWRANK = os.environ.get("VG_MEMATTN_LOWRANK", "1") == "1"   # memory cross-attention: v-projection behind the attention (A/B knob)
 
@@ -392,6 +393,17 @@ class SAM2:
     # ------------------------------------------------------------------ S5 memory attention
     def _rope_attn(self, name, q_in, k_in, v_in, n_exclude, residual):
         """RoPEAttention.forward (1 head) — R/modeling/sam/transformer.py:289-327."""
+        if _SELFATTN_FUSED and q_in is k_in and k_in is v_in and n_exclude == 0 and q_in.dtype == torch.bfloat16:
+            # self-attention (r04): ONE q|k|v projection (the rows are read once), ONE RoPE launch over the q | k columns of it, attention on views
+            w, b = self.P.fused([self.p + name + ".q_proj", self.p + name + ".k_proj", self.p + name + ".v_proj"])
+            qkv = ops.linear(q_in, w, b)
+            B, nq, c3 = qkv.shape
+            c = c3 // 3
+            cos, sin = self.P.const(("axial_cos", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[0], torch.float32), \
+                self.P.const(("axial_sin", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[1], torch.float32)
+            ops.rope_axial_heads_(qkv, 2, cos, sin, nq, nq)
+            o = ops.attention(qkv[..., :c].unsqueeze(2), qkv[..., c:2 * c].unsqueeze(2), qkv[..., 2 * c:].unsqueeze(2), c ** -0.5)
+            return self.lin(name + ".out_proj", o.view(B, nq, c), residual=residual)
         q, k, v = self.lin(name + ".q_proj", q_in), self.lin(name + ".k_proj", k_in), self.lin(name + ".v_proj", v_in)
         B, nq, c = q.shape
         cos, sin = self.P.const(("axial_cos", c, nq), lambda: _axial_cos_sin(c, int(math.sqrt(nq)))[0], torch.float32), \
