@@ -486,7 +486,8 @@ def test_bilinear_mask(cuda, N, Hi, Wi, Ho, Wo):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 16, 16, 8, 144, 432), (1, 20, 12, 7, 72, 40), (3, 64, 64, 14, 64, 192), (2, 8, 8, 4, 288, 288)])
+@pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 16, 16, 8, 144, 432), (1, 20, 12, 7, 72, 40), (3, 64, 64, 14, 64, 192), (2, 8, 8, 4, 288, 288),
+                                         (16, 64, 64, 16, 576, 1728)])      # the last: Hiera stage 3's windowed qkv -> the 256x256 phase-split kernel's gather (r04)
 def test_gemm_window(cuda, dtype, B, H, W, ws, K, N):
     """window_partition folded into the A-row gather and window_unpartition + residual into the epilogue scatter,
     incl. shapes that need the reference's zero padding (20x12 / 7, 64x64 / 14)."""

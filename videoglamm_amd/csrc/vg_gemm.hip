@@ -1549,7 +1549,11 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       w128_attr = true;
     }
     int ntw, mtw;
-    const bool big = route_w128(p.M, p.N, p.K, (int)sizeof(T), p.a_op, p.wmode, p.vec_out, batch, &ntw, &mtw);
+    // (r04: a padding-free power-of-two window GATHER rides on the phase-split kernel — Hiera stage 3's windowed qkv; everything else windowed
+    // stays on the 128x128 kernels)
+    static const int p8_win = env_knob("VG_GEMM_P8", 1) && env_knob("VG_GEMM_P8_WINDOW", 1) && (knob_w128() == 1 || knob_w128() == 3);
+    const int wroute = (p8_win && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
+    const bool big = route_w128(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, &ntw, &mtw);
     if constexpr (sizeof(T) == 2) {
       if (route_small64(p.M, p.N, p.K, 2, p.a_op, p.wmode, p.vec_out, batch) && !p.sa) {
         const int nseg = p.K / 64;

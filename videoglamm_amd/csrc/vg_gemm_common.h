@@ -214,4 +214,5 @@ __device__ __forceinline__ bool epi_dispatch(int act, bool res, bool gam, F&& f)
 
 // vg_gemm_p8.hip: the phase-split 256x256-tile bf16 kernel (launched from launch_gemm's 256x256 route)
 bool vg_gemm_p8_eligible(const GemmArgs& p, int batch);
+bool vg_gemm_p8_window_ok(int wmode, int wsh, int wH, int wW, int wws);
 int vg_gemm_p8_launch(const GemmArgs& q, int out_is_bf16, int wgs, hipStream_t st);

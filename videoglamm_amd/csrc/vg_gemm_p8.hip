@@ -352,6 +352,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
         const int tr = (lr >> 6) * 128 + q * 64 + (lr & 63);
         int gm = bm * 256 + tr;
         gm = gm < M ? gm : M - 1;
+        // wmode 1 (r04, vg_gemm_window's gather on this kernel): GEMM row = window-order index, the source row is its image-order row — only for
+        // power-of-two windows that tile the image exactly (every Hiera stage of a 1024^2 input: no padding rows, shifts and masks only)
+        // — there the map is a bit-field swap: window order m = [b, wy, wx | rr | cc], image order = [b, wy, rr | wx | cc]
+        if (p.wmode == 1) {
+          const int a = p.wsh & 0xff, nw = (p.wsh >> 8) & 0xff;          // log2 of the window side / of the windows per image row
+          const int rr = (gm >> a) & ((1 << a) - 1), wx = (gm >> (2 * a)) & ((1 << nw) - 1);
+          gm = (gm & ~((((1 << (a + nw)) - 1)) << a)) | (wx << a) | (rr << (a + nw));
+        }
         soff[q][i] = (uint32_t)gm * (uint32_t)(p.lda * 2) + chunk * 16;
         const int tc = (lr >> 5) * 64 + q * 32 + (lr & 31);
         int gn;
@@ -530,10 +538,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
 
 }  // namespace
 
+// the window gather this kernel takes: A rows gathered (mode 1), windows a power of two that tile the image exactly (no padding rows: the 32-bit
+// source offsets cannot reach the zero row)
+bool vg_gemm_p8_window_ok(int wmode, int wsh, int wH, int wW, int wws) {
+  return wmode == 1 && wsh >= 0 && wws > 0 && wH % wws == 0 && wW % wws == 0;
+}
+
 // Launcher (vg_gemm.hip's route_w128 decides; this only checks what the 32-bit source offsets need)
 bool vg_gemm_p8_eligible(const GemmArgs& p, int batch) {
   const int64_t arows = p.M, wrows = p.a_op == 1 ? 2 * (int64_t)p.N : p.N;
-  return p.K % 64 == 0 && p.K >= 128 && arows * p.lda * 2 < (int64_t)1 << 32 && wrows * p.ldw * 2 < (int64_t)1 << 32 && !p.sa && !p.wmode && p.vec_out;
+  const bool win_ok = p.wmode == 0 || vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws);
+  return p.K % 64 == 0 && p.K >= 128 && arows * p.lda * 2 < (int64_t)1 << 32 && wrows * p.ldw * 2 < (int64_t)1 << 32 && !p.sa && win_ok && p.vec_out;
 }
 
 template <typename TO>
