@@ -57,6 +57,17 @@ __device__ __forceinline__ void p8_store_tail(TO* cp, const float* v, int nvalid
 }
 __device__ __forceinline__ void p8_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// wmode 2 (vg_gemm_window's scatter: window_unpartition + residual add in the epilogue) for power-of-two windows that tile the image: GEMM row
+// m = [b, wy, wx | rr | cc] goes to image row [b, wy, rr | wx | cc] — a bit-field swap (see setup()).  Wave-uniform branch.
+__device__ __forceinline__ int p8_out_row(const GemmArgs& p, int m) {
+  if (p.wmode == 2) {
+    const int a = p.wsh & 0xff, nw = (p.wsh >> 8) & 0xff;
+    const int rr = (m >> a) & ((1 << a) - 1), wx = (m >> (2 * a)) & ((1 << nw) - 1);
+    m = (m & ~((((1 << (a + nw)) - 1)) << a)) | (wx << a) | (rr << (a + nw));
+  }
+  return m;
+}
+
 // bf16 output without a residual: packed staging, one pass per 32-row fragment (NC = 64 columns per wave; the SwiGLU form: 32).
 // INTERIOR (wave-uniform, chosen once per tile): the wave's 128 x NC block lies inside M x N — no per-lane bounds code at all.
 template <int NC, bool INTERIOR>
@@ -74,6 +85,10 @@ __device__ __forceinline__ void p8_flush_packed(const GemmArgs& p, const char* s
 #pragma unroll
   for (int k = 0; k < 32 / RPI; ++k) {
     char* cp = cbase + k * RPI * rstride;
+    if (p.wmode == 2) {        // scattered rows: cbase belongs to row m0 + lane / CPR (the caller's), this pass's row is k * RPI further in WINDOW order
+      const int mr = m0 + lane / CPR;
+      cp = cbase + ((int64_t)p8_out_row(p, mr + k * RPI) - mr) * rstride;
+    }
     if constexpr (INTERIOR) {
       epi_store16(cp, d[k], p.nt);
     } else {
@@ -163,8 +178,9 @@ __device__ __forceinline__ void p8_epi_plain_body(const GemmArgs& p, f32x16_t (&
             const int m = m0 + k * 16 + (lane >> 2), col = c0w + (lane & 3) * 8;
             const u32x4_t z = {0u, 0u, 0u, 0u};
             const bool ok = INTERIOR || (m < M && col + 8 <= N);
+            const int mo = p8_out_row(p, m);
 #pragma unroll
-            for (int w = 0; w < (sizeof(TO) == 2 ? 1 : 2); ++w) rv[k][w] = ok ? *(const u32x4_t*)((const char*)(R + (int64_t)m * rs + col) + 16 * w) : z;
+            for (int w = 0; w < (sizeof(TO) == 2 ? 1 : 2); ++w) rv[k][w] = ok ? *(const u32x4_t*)((const char*)(R + (int64_t)mo * rs + col) + 16 * w) : z;
           }
         }
 #pragma unroll
@@ -181,7 +197,8 @@ __device__ __forceinline__ void p8_epi_plain_body(const GemmArgs& p, f32x16_t (&
           float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
           const int m = m0 + row, col = c0w + c8 * 8, nvalid = INTERIOR ? 8 : N - col;
           if (!INTERIOR && (m >= M || nvalid <= 0)) continue;
-          TO* cp = C + (int64_t)m * p.ldc + col;
+          const int mo = p8_out_row(p, m);
+          TO* cp = C + (int64_t)mo * p.ldc + col;
           if (nvalid >= 8) {
             if constexpr (sizeof(TO) == 2) {
               if constexpr (RES) {
@@ -203,7 +220,7 @@ __device__ __forceinline__ void p8_epi_plain_body(const GemmArgs& p, f32x16_t (&
             }
           } else {
             if constexpr (RES)
-              for (int e = 0; e < nvalid; ++e) v[e] += vg_elt<TO>::ld(R + (int64_t)m * rs + col + e);
+              for (int e = 0; e < nvalid; ++e) v[e] += vg_elt<TO>::ld(R + (int64_t)mo * rs + col + e);
             p8_store_tail<TO>(cp, v, nvalid);
           }
         }
@@ -538,16 +555,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
 
 }  // namespace
 
-// the window gather this kernel takes: A rows gathered (mode 1), windows a power of two that tile the image exactly (no padding rows: the 32-bit
+// the window forms this kernel takes: A rows gathered (mode 1) or C / R rows scattered (mode 2), windows a power of two that tile the image exactly (no padding rows: the 32-bit
 // source offsets cannot reach the zero row)
 bool vg_gemm_p8_window_ok(int wmode, int wsh, int wH, int wW, int wws) {
-  return wmode == 1 && wsh >= 0 && wws > 0 && wH % wws == 0 && wW % wws == 0;
+  return (wmode == 1 || wmode == 2) && wsh >= 0 && wws > 0 && wH % wws == 0 && wW % wws == 0;
 }
 
 // Launcher (vg_gemm.hip's route_w128 decides; this only checks what the 32-bit source offsets need)
 bool vg_gemm_p8_eligible(const GemmArgs& p, int batch) {
   const int64_t arows = p.M, wrows = p.a_op == 1 ? 2 * (int64_t)p.N : p.N;
-  const bool win_ok = p.wmode == 0 || vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws);
+  const bool win_ok = p.wmode == 0 || (vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws) && !(p.wmode == 2 && p.a_op == 1));
   return p.K % 64 == 0 && p.K >= 128 && arows * p.lda * 2 < (int64_t)1 << 32 && wrows * p.ldw * 2 < (int64_t)1 << 32 && !p.sa && win_ok && p.vec_out;
 }
 
