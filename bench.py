@@ -122,7 +122,12 @@ class GemmMeter:
             M = B * (-(-H // ws)) * (-(-W // ws)) * ws * ws
             N, K = w.shape
             nbytes = (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size() * (2 if k.get("residual") is not None else 1)
-            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, True), self.scope))
+            # (r04: power-of-two windows that tile the image ride on the 256x256 phase-split kernel — the launcher routes them as if they were not
+            # windowed (vg_gemm.hip: launch_gemm's `wroute`); every other window shape stays on the 128x128 kernels)
+            p2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
+            on_p8 = (p2(ws) and H % ws == 0 and W % ws == 0 and p2(H // ws) and p2(W // ws) and x.dtype == torch.bfloat16
+                     and os.environ.get("VG_GEMM_P8", "1") != "0" and os.environ.get("VG_GEMM_P8_WINDOW", "1") != "0")
+            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, not on_p8), self.scope))
             self.shapes.append((M, N, K))
             return y
         from videoglamm_amd import sam2 as _sam2
