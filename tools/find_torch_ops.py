@@ -1,6 +1,6 @@
 """Debug aid: every aten op torch itself launches during ONE inference step of the C2 workload (the product's arithmetic is all vg_* kernels:
 what shows up here is data movement — copies, cats, casts, index ops), grouped by op and call site inside videoglamm_amd, with the bytes it moves.
-usage: python tools/find_torch_ops.py [framewise|video]"""
+usage: python tools/find_torch_ops.py [framewise|video] [bench.py arguments]"""
 import collections
 import os
 import sys
@@ -15,12 +15,12 @@ from videoglamm_amd import synth  # noqa: E402
 from videoglamm_amd.model import VideoGLaMMForCausalLM  # noqa: E402
 
 branch = sys.argv[1] if len(sys.argv) > 1 else "framewise"
-sys.argv = sys.argv[:1]
+sys.argv = sys.argv[:1] + sys.argv[2:]          # further arguments go to bench.parse() (e.g. --frames 64 --objects 8)
 args = bench.parse()
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 cfg = synth.videoglamm_llama3_8b()
-cfg["forced_tokens"] = {8: cfg["seg_token_idx"]}
+cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
 sd = synth.device_state_dict(synth.manifest(cfg), dev, torch.bfloat16)
 model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev)
 images, context, sam, ids = bench.make_inputs(cfg, args, 1, dev)
