@@ -126,7 +126,7 @@ class GemmMeter:
             # windowed (vg_gemm.hip: launch_gemm's `wroute`); every other window shape stays on the 128x128 kernels)
             p2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
             on_p8 = (p2(ws) and H % ws == 0 and W % ws == 0 and p2(H // ws) and p2(W // ws) and x.dtype == torch.bfloat16
-                     and os.environ.get("VG_GEMM_P8", "1") != "0" and os.environ.get("VG_GEMM_P8_WINDOW", "1") != "0")
+                     and os.environ.get("VG_GEMM_P8", "1") != "0")
             self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, not on_p8), self.scope))
             self.shapes.append((M, N, K))
             return y
@@ -557,7 +557,7 @@ def main():
                               "valid_scaling_record": len(uuids) == world and torch.distributed.get_backend() == "nccl",
                               "plumbing": bool(args.plumbing),
                               "collectives": {"note": "one extra pass, rank 0's counts; ms = device time between events bracketing the collective on the stream that issues "
-                                                      "it (includes waiting for the slowest rank to arrive); async streamed feature gathers are bracketed at issue",
+                                                      "it (includes waiting for the slowest rank to arrive); async streamed feature gathers (FrameSharder(stream_features=True) / VG_FEATURES_STREAMED=1, off by default) run from issue to the consuming stream's wait",
                                               **rep}}
         if len(uuids) != world:
             res["distributed"]["warning"] = f"{world} ranks on {len(uuids)} device(s): ranks time-slice GPUs — NOT a scaling measurement"

@@ -595,8 +595,63 @@ def gen_host():
     save("host_rows.npz", **out)
 
 
+def gen_host_pv():
+    """The reference's own chat.preprocess_vision (R/chat.py:402-489), type="video" and type="image", called the way R/chat.py:540-553 calls it:
+    what sits at each of the five return positions.  The CLIP processor is built offline as in gen_host; the cv2-based InternVideo2 processor
+    (cv2 absent) is a stand-in that returns one zero tensor per frame, so position 0 of the video case pins shape and position only."""
+    ri.install()
+    ri._mod("decord", VideoReader=None, cpu=None)                    # chat.py imports it at module level; load_video is not called
+    from PIL import Image
+    import torchvision.transforms.functional as tvf
+
+    tvf.to_pil_image = Image.fromarray
+    tvf.resize = lambda img, size: img.resize((size[1], size[0]), Image.BILINEAR)
+    import model.segment_anything.utils.transforms as tr
+    tr.resize, tr.to_pil_image = tvf.resize, tvf.to_pil_image
+    import importlib
+    chat = importlib.import_module("chat")
+    from transformers import CLIPImageProcessor
+    from utils.enc_preprocessors import EncPreprocessor_VideoGPTPlus
+    from utils.sam_transforms import SAM_v2_Preprocess
+    enc = EncPreprocessor_VideoGPTPlus.__new__(EncPreprocessor_VideoGPTPlus)
+    enc.num_frames, enc.frame_resolution_iv, enc.frame_resolution_clip = 4, 224, 336
+    enc.image_processor = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}, do_resize=True, do_center_crop=True,
+                                             do_normalize=True, do_rescale=True, do_convert_rgb=True, resample=3,
+                                             image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711])
+    enc.video_processor = type("NoIV2", (), {"preprocess": staticmethod(lambda frames: {"pixel_values": [torch.zeros(3, 224, 224) for _ in frames]})})()
+    conv_generator = type("Conv", (), {"NUM_FRAMES": 4})()
+    out = {}
+    frames = [np.random.RandomState(20 + i).randint(0, 256, size=(48, 64, 3)).astype(np.uint8) for i in range(6)]     # 6 frames > NUM_FRAMES: sub-sampled
+    ret = chat.preprocess_vision([list(frames)], type="video", enc_preprocessor=enc, sam_preprocessor=SAM_v2_Preprocess(),
+                                 conv_generator=conv_generator, precision="fp32")
+    assert len(ret) == 5
+    out["video_pos0_shape"] = np.array(ret[0][0].shape)
+    out["video_pos1_sub"], out["video_pos1_mean"] = ret[1][0][:, :, ::7, ::7], ret[1][0].mean(dim=(2, 3))
+    out["video_pos2_sub"], out["video_pos2_mean"] = ret[2][0][:, :, ::16, ::16], ret[2][0].mean(dim=(2, 3))
+    out["video_pos3"], out["video_pos4"] = np.array(ret[3]), np.array(ret[4])
+    image = np.random.RandomState(31).randint(0, 256, size=(60, 80, 3)).astype(np.uint8)
+    ret = chat.preprocess_vision([[image]], type="image", enc_preprocessor=enc, sam_preprocessor=SAM_v2_Preprocess(),
+                                 conv_generator=conv_generator, precision="fp32")
+    assert len(ret) == 5 and ret[1] is None
+    out["image_pos0_sub"], out["image_pos0_mean"] = ret[0][0][:, :, ::7, ::7], ret[0][0].mean(dim=(2, 3))
+    out["image_pos2_sub"], out["image_pos2_mean"] = ret[2][0][:, :, ::16, ::16], ret[2][0].mean(dim=(2, 3))
+    out["image_pos3"], out["image_pos4"] = np.array(ret[3]), np.array(ret[4])
+    # ConvGenerator_VideoGPTPlus.apply_for_chat(type='image' / 'video', use_mm_start_end False / True) on the toy tokenizer
+    from utils.conv_generator import ConvGenerator_VideoGPTPlus
+    for base in ("phi3", "llama3_1"):
+        for mm in (False, True):
+            cg = ConvGenerator_VideoGPTPlus(use_mm_start_end=mm, base_type=base)
+            cg.NUM_FRAMES = 4
+            for kind in ("video", "image"):
+                out[f"chat_ids_{base}_{int(mm)}_{kind}"] = cg.apply_for_chat("Please segment the red car .", type=kind, tokenizer=ToyTokenizer()).numpy()
+    save("host_pv.npz", **out)
+
+
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("host", "all")):
     gen_host()
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("host_pv", "all")):
+    gen_host_pv()
 
 
 def gen_postproc():

@@ -59,7 +59,7 @@ def test_gemm_routing_rules():
     assert route(1697, 4096, 4096) == 1                    # C1 o_proj: 112 tiles of 256^2 do not fill the chip -> 128x128 kernel
     assert route(1697, 14336, 4096, glu=1) == 3            # C1 gate|up + SwiGLU: 256x256 kernel
     assert route(3361, 4096, 14336) == 3                   # C2 down
-    assert route(32768, 1728, 576) == 3                    # Hiera stage 3 (K x 2 B = 1152): the phase-split 256x256 kernel since r04 (VG_W128_MINKB)
+    assert route(32768, 1728, 576) == 3                    # Hiera stage 3 (K x 2 B = 1152): the phase-split 256x256 kernel since r04
     assert route(32768, 1728, 576, win=1) == 4             # ... its window-gathering form stays on the single-stage whole-line kernel
     assert route(131072, 1152, 288) == 2                   # Hiera stage 2 (K x 2 B = 576): 64-byte-step kernel
     assert route(524288, 432, 144) == 2                    # Hiera stage 1: 64-byte-step kernel

@@ -49,6 +49,15 @@ def _worker(rank, world, port, q):
     local, lf = shard.framewise(m, images, text, hw)
     assert lf == [2 * rank, 2 * rank + 1] and torch.equal(local, masks[2 * rank:2 * rank + 2])
     feats = comm.hiera_all_frames(m, images)
+    # the streamed exchange on its own communicator: chunks sized from the per-rank frame count (2 frames -> 2 steps of 1 frame, not one step
+    # padded to SAM2.frame_chunk), same features as the single exchange after the last frame
+    streamer = FrameSharder(stream_features=True)
+    assert streamer.stream_features and streamer.feat_group is not None and not comm.stream_features
+    assert streamer.stream_plan(T, m.frame_chunk)[:2] == (1, 2) and streamer.stream_plan(32, 16)[:2] == (4, 4) and streamer.stream_plan(1, 16)[:2] == (1, 1)
+    feats_s = streamer.hiera_all_frames(m, images)
+    feats_u = comm.gather_frame_feats(m.hiera_frames(images, comm.my_frames(T)), T, m)
+    assert sorted(feats_s) == sorted(feats_u) == sorted(feats) == list(range(T))
+    assert all(torch.equal(a, b) and torch.equal(a, c) for t in range(T) for a, b, c in zip(feats_s[t], feats_u[t], feats[t]))
     vid = m.video_branch(images, emb, hw, frame_feats=feats)
     # object-sharded propagation: rank r runs the recurrence for its object, masks all-gathered along the object axis
     vid_obj, oids = comm.video_branch_objects(m, images, emb, hw, feats)

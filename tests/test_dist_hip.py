@@ -124,7 +124,7 @@ def _worker_rccl(port, q):
         return out_ids[0].tolist(), segs[0]
 
     single = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=dev)
-    comm = FrameSharder(profile=True)
+    comm = FrameSharder(profile=True, stream_features=True)
     full = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=dev, comm=comm)
     ids6, ids14 = inp["input_ids"].long(), fx["input_ids8"].long()
     os.environ["VG_TOWERS_SHARDED"] = os.environ["VG_PREFILL_SHARDED"] = "1"
@@ -143,7 +143,7 @@ def _worker_rccl(port, q):
     torch.cuda.synchronize()
     res["direct"] = bool(torch.equal(recv, send) and torch.equal(rows, send[:4]) and torch.equal(blocks, send.view(1, 5, 3)))
     res["direct_collectives"] = comm.collective_report()
-    os.environ["VG_FEATURES_STREAMED"] = "0"          # the one-exchange-after-Hiera form of the feature gather
+    comm.stream_features = False                      # the one-exchange-after-Hiera form of the feature gather (the default)
     got_ids, got_seg = run(full, ids14, True)
     res["vid_unstreamed_bitexact"] = bool(np.array_equal(_stack(got_seg), _stack(ref_seg)))
     res["vid_unstreamed_collectives"] = comm.collective_report()

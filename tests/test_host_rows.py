@@ -63,9 +63,59 @@ def test_frame_sampling_and_padding():
     assert host.pad_or_truncate(list(range(9)), 4) == [0, 1, 2, 3]
 
 
+def test_preprocess_vision_matches_reference_positions():
+    """The five return values of preprocess_vision, position by position, against the reference's own chat.preprocess_vision called the way
+    R/chat.py:540-553 calls it (tests/golden/host_pv.npz; make_golden.py:gen_host_pv): (enc_image, enc_context_image, image_sam,
+    original_size_list, resize_list) — r04 returned the last two swapped.  6 frames > NUM_FRAMES = 4: sub-sampled for the encoders, all for SAM."""
+    fx = G.fixture("host_pv.npz")
+    frames = [np.random.RandomState(20 + i).randint(0, 256, size=(48, 64, 3)).astype(np.uint8) for i in range(6)]
+    cg = host.ConvGenerator_VideoGPTPlus(False, "phi3", num_frames=4)
+    ret = host.preprocess_vision([list(frames)], type="video", enc_preprocessor=host.EncPreprocessor_VideoGPTPlus(4),
+                                 sam_preprocessor=host.SAM_v2_Preprocess(), conv_generator=cg, precision="fp32")
+    assert len(ret) == 5
+    enc_image, enc_context_image, image_sam, original_size_list, resize_list = (r if r is None or not torch.is_tensor(r[0]) else [r[0].cpu()] for r in ret)
+    assert list(enc_image[0].shape) == fx["video_pos0_shape"].long().tolist() and enc_image[0].dtype == torch.float32
+    torch.testing.assert_close(enc_context_image[0][:, :, ::7, ::7], fx["video_pos1_sub"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(enc_context_image[0].mean(dim=(2, 3)), fx["video_pos1_mean"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(image_sam[0][:, :, ::16, ::16], fx["video_pos2_sub"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(image_sam[0].mean(dim=(2, 3)), fx["video_pos2_mean"], rtol=1e-5, atol=1e-5)
+    assert [list(x) for x in original_size_list] == fx["video_pos3"].long().tolist() == [[48, 64]]
+    assert [list(x) for x in resize_list] == fx["video_pos4"].long().tolist() == [[768, 1024]]
+    # default arguments = the reference's objects; bf16 / fp16 cast like R/chat.py:437 (fp16 -> bf16 on this build)
+    d = host.preprocess_vision([list(frames)], conv_generator=cg, precision="bf16")
+    assert d[0][0].dtype == d[1][0].dtype == d[2][0].dtype == torch.bfloat16 and d[3] == [(48, 64)] and d[4] == [(768, 1024)]
+    assert torch.equal(d[2][0].cpu(), image_sam[0].bfloat16())
+    # type="image" (R/chat.py:458-487): the CLIP tensor at position 0, None at position 1, one SAM frame
+    image = np.random.RandomState(31).randint(0, 256, size=(60, 80, 3)).astype(np.uint8)
+    ret = host.preprocess_vision([[image]], type="image", conv_generator=cg, precision="fp32")
+    assert len(ret) == 5 and ret[1] is None
+    torch.testing.assert_close(ret[0][0].cpu()[:, :, ::7, ::7], fx["image_pos0_sub"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(ret[0][0].cpu().mean(dim=(2, 3)), fx["image_pos0_mean"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(ret[2][0].cpu()[:, :, ::16, ::16], fx["image_pos2_sub"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ret[2][0].cpu().mean(dim=(2, 3)), fx["image_pos2_mean"], rtol=1e-5, atol=1e-5)
+    assert [list(x) for x in ret[3]] == fx["image_pos3"].long().tolist() and [list(x) for x in ret[4]] == fx["image_pos4"].long().tolist()
+    import pytest
+    with pytest.raises(AssertionError):
+        host.preprocess_vision([list(frames), list(frames)])            # "Batch size must be 1"
+    with pytest.raises(AssertionError):
+        host.preprocess_vision([list(frames)], type="image")            # "Time dimension must be 1"
+
+
+def test_conv_generator_matches_reference():
+    """ConvGenerator_VideoGPTPlus.apply_for_chat, both types, with and without <im_start>/<vid_start> wrapping, vs the reference's class."""
+    fx = G.fixture("host_pv.npz")
+    for base in ("phi3", "llama3_1"):
+        for mm in (False, True):
+            cg = host.ConvGenerator_VideoGPTPlus(use_mm_start_end=mm, base_type=base, num_frames=4)
+            for kind in ("video", "image"):
+                ids = cg.apply_for_chat("Please segment the red car .", type=kind, tokenizer=ToyTokenizer()).cpu()
+                assert ids.tolist() == fx[f"chat_ids_{base}_{int(mm)}_{kind}"].long().tolist(), (base, mm, kind)
+                assert (ids == host.IMAGE_TOKEN_INDEX).sum() == (4 if kind == "video" else 1)
+
+
 def test_preprocess_vision_shapes_and_write_masks(tmp_path):
     frames = [np.random.RandomState(i).randint(0, 256, size=(48, 64, 3)).astype(np.uint8) for i in range(5)]
-    images, context, sam, resize, orig = host.preprocess_vision(frames, num_frames=4)
+    images, context, sam, orig, resize = host.preprocess_vision([frames], conv_generator=host.ConvGenerator_VideoGPTPlus(num_frames=4), precision="fp32")
     assert images[0].shape == (4, 3, 224, 224) and context[0].shape == (4, 3, 336, 336)
     assert sam[0].shape == (5, 3, 1024, 1024) and orig == [(48, 64)] and resize == [(768, 1024)]
     segs = {0: {0: np.zeros((48, 64), bool)}, 1: {0: np.ones((48, 64), bool)}}

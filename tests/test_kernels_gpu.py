@@ -637,9 +637,9 @@ BIG = [  # (M, N, K, glu): bf16 shapes the launcher routes to the 256x256-tile k
 ]
 
 
-def _check_big_gemm(cuda, M, N, K, glu):
+def _check_big_gemm(cuda, M, N, K, glu, routed=True):
     from videoglamm_amd import _lib, ops
-    assert _lib.load().vg_gemm_route(M, N, K, 1, 1 if glu else 0, 0) == 3, "this shape must take the 256x256-tile kernel"
+    assert (_lib.load().vg_gemm_route(M, N, K, 1, 1 if glu else 0, 0) == 3) == routed, "this shape must take the 256x256-tile kernel"
     dtype = torch.bfloat16
     x = rnd(M, K, dtype=dtype, seed=1)
     w = rnd((2 if glu else 1) * N, K, dtype=dtype, seed=2, scale=K ** -0.5)
@@ -674,14 +674,12 @@ def test_gemm_tail_rows_split(cuda):
 
 
 @pytest.mark.parametrize("M,N,K,glu", BIG)
-def test_gemm_w128x8(cuda, M, N, K, glu):
+def test_gemm_p8(cuda, M, N, K, glu):
     """the default (eight-wave) 256x256-tile kernel on the bench's heaviest bf16 GEMMs, against the fp32 statement."""
-    import os
-    assert os.environ.get("VG_GEMM_W128", "1") == "1"
     _check_big_gemm(cuda, M, N, K, glu)
 
 
-def test_gemm_w128x8_persistent_queue(cuda):
+def test_gemm_p8_persistent_queue(cuda):
     """the persistent 256x256 kernel's tile queue: more tiles than CUs over a BATCH of problems (tiles of all batch entries form one
     queue; every workgroup walks several tiles and prefetches the next tile's first K step under the last), K = 1152 (18 K steps: the
     short-K shapes r02 routes here), against the per-entry GEMMs that take other kernels."""
@@ -696,8 +694,9 @@ def test_gemm_w128x8_persistent_queue(cuda):
         close(y[b], a[b].float().cpu() @ w[b].float().cpu().t(), rtol=2e-2, atol=0.3)
 
 
-def test_gemm_w128_four_wave(cuda):
-    """the four-wave variant (VG_GEMM_W128=5) of the same kernel: the knob is read once per process, so a child process runs it."""
+def test_gemm_route_knobs(cuda):
+    """VG_GEMM_P8=0 (the 256x256 route switched off: the same shapes on the 128x128 kernels) and VG_ATTN_XCD=0 (attention workgroups in plain
+    dispatch order) are the A/B knobs the launchers still read; they are read once per process, so a child process runs them."""
     import os
     import subprocess
     import sys
@@ -705,23 +704,13 @@ def test_gemm_w128_four_wave(cuda):
     code = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
             "import test_kernels_gpu as t\n"
             "from videoglamm_amd import _lib\n"
-            "assert _lib.load().vg_init(0) > 0\n"
+            "lib = _lib.load(); assert lib.vg_init(0) > 0\n"
             "dev = torch.device('cuda:0')\n"
-            "for c in t.BIG[:3]: t._check_big_gemm(dev, *c)\n"
-            "print('four-wave ok')\n") % (os.path.dirname(here), here)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_GEMM_W128="5"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "four-wave ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    # the eight-wave kernel with one workgroup per tile (VG_W128_PERSIST=0: no tile queue, no cross-tile prefetch) and the attention
-    # kernels in plain dispatch order (VG_ATTN_XCD=0) are the other halves of this round's A/B knobs: same results
-    code2 = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
-             "import test_kernels_gpu as t\n"
-             "from videoglamm_amd import _lib\n"
-             "assert _lib.load().vg_init(0) > 0\n"
-             "dev = torch.device('cuda:0')\n"
-             "for c in t.BIG[:2]: t._check_big_gemm(dev, *c)\n"
-             "for c in t.ATT: t.test_attention(dev, torch.bfloat16, c)\n"
-             "print('knobs ok')\n") % (os.path.dirname(here), here)
-    r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, VG_W128_PERSIST="0", VG_ATTN_XCD="0"), capture_output=True, text=True, timeout=900)
+            "assert all(lib.vg_gemm_route(M, N, K, 1, 1 if g else 0, 0) != 3 for M, N, K, g in t.BIG)\n"
+            "for c in t.BIG[:3]: t._check_big_gemm(dev, *c, routed=False)\n"
+            "for c in t.ATT: t.test_attention(dev, torch.bfloat16, c)\n"
+            "print('knobs ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_GEMM_P8="0", VG_ATTN_XCD="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

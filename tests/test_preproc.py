@@ -112,15 +112,22 @@ def test_resize_cv_hip(cuda):
 def check_pipeline(device, hw, T, num_frames):
     from videoglamm_amd import host, preproc as PP
     frames = clip(T, hw, 40)
-    ref = host.preprocess_vision(frames, num_frames)
-    got = PP.preprocess_vision(torch.from_numpy(np.stack(frames)).to(device), num_frames)
-    assert got[3] == ref[3] and got[4] == ref[4]                                  # resize_list, original_size_list
+    cg = host.ConvGenerator_VideoGPTPlus(num_frames=num_frames)
+    ref = host.preprocess_vision([frames], conv_generator=cg, precision="fp32")
+    got = PP.preprocess_vision([torch.from_numpy(np.stack(frames)).to(device)], conv_generator=cg, precision="fp32")
+    assert got[3] == ref[3] == [tuple(hw)] and got[4] == ref[4]                   # original_size_list, resize_list (R/chat.py:489's order)
     for name, g, r in zip(("images", "context_images"), got[:2], ref[:2]):
         assert g[0].shape == r[0].shape and g[0].dtype == torch.float32
-        assert torch.equal(g[0].cpu(), r[0]), (name, (g[0].cpu() - r[0]).abs().max())
-    g, r = got[2][0].cpu(), ref[2][0]
+        assert torch.equal(g[0].cpu(), r[0].cpu()), (name, (g[0].cpu() - r[0].cpu()).abs().max())
+    g, r = got[2][0].cpu(), ref[2][0].cpu()
     assert g.shape == r.shape
-    if ref[3][0] == (1024, 1024):
+    # type="image": the CLIP tensor of the one frame at position 0, no context stream
+    gi = PP.preprocess_vision([[frames[0]]], type="image", precision="fp32")
+    ri = host.preprocess_vision([[frames[0]]], type="image", precision="fp32")
+    assert gi[1] is None and ri[1] is None and gi[3] == ri[3] and gi[4] == ri[4]
+    assert torch.equal(gi[0][0].cpu(), ri[0][0].cpu()) and gi[2][0].shape == ri[2][0].shape == (1, 3, 1024, 1024)
+    assert PP.preprocess_vision([frames], conv_generator=cg, precision="bf16")[2][0].dtype == torch.bfloat16
+    if ref[4][0] == (1024, 1024):
         assert torch.equal(g, r)                                                   # no stretch: bit-exact
     else:
         torch.testing.assert_close(g, r, rtol=1e-5, atol=1e-5)                     # fp32 bilinear stretch

@@ -31,7 +31,8 @@ for hw in ((512, 512), (480, 854)):
     frames = [rng.randint(0, 256, hw + (3,)).astype(np.uint8) for _ in range(8)]
     stack = np.stack(frames)
     t0 = time.time()
-    ref = host.preprocess_vision(frames, 8)
+    cg = host.ConvGenerator_VideoGPTPlus(num_frames=8)
+    ref = host.preprocess_vision([frames], conv_generator=cg, precision="fp32")
     t_host = time.time() - t0
     t0 = time.time()
     on_dev = [t[0].to(dev) for t in ref[:3]]
@@ -41,7 +42,7 @@ for hw in ((512, 512), (480, 854)):
     pinned = torch.from_numpy(stack).pin_memory()
     us_up = timed(lambda: pinned.to(dev, non_blocking=True))
     x = torch.from_numpy(stack).to(dev)
-    us_all = timed(lambda: preproc.preprocess_vision(x, 8))
+    us_all = timed(lambda: preproc.preprocess_vision([x], conv_generator=cg, precision="fp32"))
     us_sam = timed(lambda: preproc.sam_preprocess(x))
     us_iv2 = timed(lambda: preproc.iv2_preprocess(x))
     us_clip = timed(lambda: preproc.clip_preprocess(x))

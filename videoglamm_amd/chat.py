@@ -94,8 +94,8 @@ def initialize_model_videogptplus(model_base, precision="fp16", local_rank=0, lo
     return model, tokenizer
 
 
-def load_frames(path, max_frames=64):
-    """<= 64 frames like R/chat.py:386,392-395."""
+def load_video(path, max_frames=64):
+    """load_video — R/chat.py:380-398: <= 64 frames, B x T x (H x W x C).  (No decord here: a frames directory or an .npy clip.)"""
     if path.endswith(".npy"):
         frames = list(np.load(path))
     else:
@@ -106,7 +106,14 @@ def load_frames(path, max_frames=64):
     if len(frames) > max_frames:
         idx = np.linspace(0, len(frames) - 1, max_frames, dtype=int)
         frames = [frames[i] for i in idx]
-    return frames
+    return [frames]
+
+
+def load_image(path):
+    """load_image — R/chat.py:370-378: B x T x (H x W x C) with B = T = 1."""
+    from PIL import Image
+
+    return [[np.array(Image.open(path).convert("RGB"))]]
 
 
 def main():
@@ -116,27 +123,30 @@ def main():
     base = args.base_model_type.split("|")[1]
     model, tokenizer = initialize_model_videogptplus(args.llava_version_or_path, args.precision, args.local_rank, args.load_in_8bit,
                                                      args.load_in_4bit, args.use_sam2_video_branch, base, device=f"cuda:{args.local_rank}")
-    num_frames = int(os.environ.get("NUM_FRAMES", 16))
+    conv_generator = host.ConvGenerator_VideoGPTPlus(args.use_mm_start_end, base)
+    enc_preprocessor, sam_preprocessor = host.EncPreprocessor_VideoGPTPlus(), host.SAM_v2_Preprocess()
     while True:
         path = args.video or input("Please input the image/video path: ")
-        frames = load_frames(path)
+        kind = "image" if os.path.splitext(path)[1].lower() in (".jpg", ".jpeg", ".png") else "video"        # R/chat.py:540
+        np_images = load_image(path) if kind == "image" else load_video(path)
         # row H1 on the device: the uint8 clip is uploaded once, the three inputs are made in HBM (preproc.py);
         # VG_HOST_PREPROCESS=1 keeps the PIL / numpy pipeline of host.py (same tensors, ~0.9 s per 8-frame clip on the host)
-        if os.environ.get("VG_HOST_PREPROCESS", "0") == "1" or len({f.shape for f in frames}) != 1:
-            images, context, sam, resize_list, original_size_list = host.preprocess_vision(frames, num_frames)
-        else:
-            preproc.DEVICE = f"cuda:{args.local_rank}"
-            images, context, sam, resize_list, original_size_list = preproc.preprocess_vision(frames, num_frames)
+        on_host = os.environ.get("VG_HOST_PREPROCESS", "0") == "1" or len({f.shape for f in np_images[0]}) != 1
+        preproc.DEVICE = f"cuda:{args.local_rank}"
+        enc_image, enc_context_image, image_sam, original_size_list, resize_list = (host if on_host else preproc).preprocess_vision(
+            np_images, type=kind, enc_preprocessor=enc_preprocessor, sam_preprocessor=sam_preprocessor, conv_generator=conv_generator,
+            precision=args.precision)
         prompt = args.prompt_text or input("Please input your prompt: ")
-        input_ids = host.apply_for_chat(prompt, tokenizer, num_frames, base)
-        output_ids, video_segments = model.inference(images, context, sam, input_ids, resize_list, original_size_list,
+        input_ids = conv_generator.apply_for_chat(prompt, type=kind, tokenizer=tokenizer)
+        output_ids, video_segments = model.inference(images=enc_image, context_images=enc_context_image, images_for_sam=image_sam,
+                                                     input_ids=input_ids, resize_list=resize_list, original_size_list=original_size_list,
                                                      max_new_tokens=args.max_new_tokens,
                                                      use_sam2_video_branch=args.use_sam2_video_branch)
         text = host.decode_text(output_ids, tokenizer)
         print("text_output: ", text)
         save_dir = os.path.join(args.vis_save_path, os.path.basename(path.rstrip("/")).split(".")[0])
         os.makedirs(save_dir, exist_ok=True)
-        host.write_masks(video_segments[0], np.stack(frames), save_dir)
+        host.write_masks(video_segments[0], np.stack(np_images[0]), save_dir)
         with open(os.path.join(save_dir, "caption.txt"), "w") as fh:       # R/chat.py:594-596
             fh.write(text)
         if args.prompt_text and args.video:

@@ -4,8 +4,8 @@
 //   gemm_tile_glds_kernel    128x128 tile, 4 waves, 128-byte K steps staged by LDS-DMA into swizzled unpadded rows, two stages,
 //                            two workgroups per CU.  Carries the window gather/scatter (vg_gemm_window), the SwiGLU epilogue,
 //                            split-K (vg_gemm_splitk) and, instantiated on bytes, the fp8 x fp8 GEMM (vg_gemm_f8).
-//   gemm_tile_w128x8_kernel  256x256 tile, 8 waves of 128x64 (two per SIMD), whole-line DMAs issued between MFMAs, persistent (one workgroup
-//   gemm_tile_w128_kernel    per CU walks the tile queue): grids that fill the chip (the 4-wave variant, 128x128 per wave, is the A/B twin).
+//   gemm_tile_p8_kernel      (vg_gemm_p8.hip) 256x256 tile, 8 waves, phase-split pipeline, persistent: bf16 grids that fill the chip.  (The lock-step
+//                            256x256 kernels of r01-r03 it replaced were removed in r05; DESIGN_HISTORY.md has their measurements.)
 //   gemm_tile_s128_kernel    128x128 tile, ONE 128-byte-row stage, four workgroups per CU: 1024 <= K*es <= 3072 bytes.
 //   gemm_tile_k64b_kernel    128x128 tile, 64-byte K steps, four workgroups per CU: K*es < 1024 bytes.
 //   (r01's register-staged and 3-stage-ring A/B twins were removed at the end of r02; their measurements are in DESIGN.md section 5)
@@ -408,7 +408,7 @@ __device__ __forceinline__ void gemm_epilogue64x32(const GemmArgs& p, f32x16_t (
     gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
   }
   const bool fast = p.vec_out && !p.sa && n0w + 64 <= N;     // wave-uniform: whole 16-byte groups -> the straight-line form
-  auto pass32 = [&](auto ic) {           // (instantiated by hand: see gemm_tile_w128x8_kernel's epilogue)
+  auto pass32 = [&](auto ic) {           // (instantiated by hand, like the 256x256 kernel's epilogue)
     constexpr int i = decltype(ic)::value;
     if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
 #pragma unroll
@@ -698,511 +698,6 @@ __global__ __launch_bounds__(256, 4) void gemm_tile_s128_kernel(GemmArgs p) {
   gemm_epilogue64x32<TO>(p, acc, smem, bm * GBM + wm * 64, bn * GBN + wn * 64, bz, wave, lane);
 }
 
-// 256x256 output tile / 256 threads: FOUR waves, each owning 128x128 (4x4 MFMA tiles, 256 accumulator registers), one
-// workgroup per CU.  Two measurements shape it (tools/mfma_peak.hip, tools/dma_peak.hip, r01):
-//   * the inner loop of this kernel alone (16 MFMAs + 8 ds_read_b128 per group, no global memory) runs at 2.2 PFLOP/s,
-//     the register-only MFMA ceiling of the part: fragment reads are not what holds the GEMMs near 1 PFLOP/s;
-//   * the CU's global->LDS path moves ~one 128-byte line per two cycles: 105-136 GB/s per CU when a lane group fetches
-//     whole lines (128-byte rows), but only 60-68 GB/s with 64-byte row pieces (half of every line is thrown away).
-//     A 128x128 tile per workgroup needs 32 KB per 512 MFMA cycles (64 B/clk: the whole path), a 256x256 tile half that.
-// So: 128-byte K steps (whole lines), two 64 KB stages, and the 16 DMA instructions of the next stage are issued ONE AT A
-// TIME between MFMAs over the first three quarters of a step — a wave issues in order, so a burst of DMAs that backs up
-// the address path stalls the MFMAs queued behind it.  The fragments of the next MFMA group are read while the current
-// group issues; only the first group after the barrier waits for its reads.
-// Needs K % (128 / sizeof(T)) == 0, no GLU epilogue, no window maps; the launcher sends only shapes that fill the chip.
-#ifndef VG_W128_PLAN
-#define VG_W128_PLAN 1
-#endif
-template <typename T, typename TO>
-__global__ __launch_bounds__(256, 1) void gemm_tile_w128_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);
-  constexpr int BK = 128 / sizeof(T);
-  constexpr int TA = 256 * 128, STAGE = 2 * TA;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int bm, bn;
-  gemm_tile_of(wgid, gridDim.y, gridDim.x, p.gn, bm, bn);
-  const int bz = blockIdx.z;
-  const int M = p.M, N = p.N, K = p.K;
-  const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-  const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-
-  // wave w stages rows [64w, 64w+64) of each operand: 8 DMA instructions of 8 rows (8 lanes per 128-byte row) each
-  const T* src[16];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = wave * 64 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = bm * 256 + row, gn = bn * 256 + row;
-    gm = gm < M ? gm : M - 1;
-    gn = gn < N ? gn : N - 1;
-    if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
-      const int o = bn * 128 + (row & 127);
-      gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
-    }
-    src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
-    src[8 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
-  }
-  auto dma = [&](int kt, int buf, int i) {      // instruction i of stage kt: 0..7 A pieces, 8..15 W pieces
-    char* dst = smem + buf * STAGE + (i >> 3) * TA + wave * 64 * 128 + (i & 7) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-
-  f32x16_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int ra = wm * 128 + l31, rb = wn * 128 + l31;
-  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r + 32 i share the key
-  const int nk = K / BK;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dma(0, 0, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  u32x4_t fa[2][4], fb[2][4];          // fragment sets of two consecutive MFMA groups
-  // fragment x (0..3 = A row tiles, 4..7 = W row tiles) of group g of the stage in `buf`
-  auto frag = [&](int buf, int g, int x) -> u32x4_t {
-    const int c = 2 * g + h;
-    if (x < 4) return *(const u32x4_t*)(smem + buf * STAGE + (ra + x * 32) * 128 + ((c ^ swa) << 4));
-    return *(const u32x4_t*)(smem + buf * STAGE + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
-  };
-#pragma unroll
-  for (int x = 0; x < 8; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(0, 0, x);
-
-  // one K step = 4 groups x 8 slots; a slot = 2 MFMAs, then one fragment read of the next group, then (first three
-  // groups, while a next stage exists) at most one DMA instruction of the next stage.  sched_barrier pins the order.
-  auto step = [&](int kt, int buf, bool has_next) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cur = g & 1, nxt = cur ^ 1;
-      if (g == 0) __builtin_amdgcn_s_waitcnt(0xC07F);       // the first group's fragments (read after the barrier)
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) {
-        MmaOp<T>::run(fa[cur][(2 * sl) >> 2], fb[cur][(2 * sl) & 3], acc[(2 * sl) >> 2][(2 * sl) & 3]);
-        MmaOp<T>::run(fa[cur][(2 * sl + 1) >> 2], fb[cur][(2 * sl + 1) & 3], acc[(2 * sl + 1) >> 2][(2 * sl + 1) & 3]);
-        if (g < 3) {
-          const u32x4_t v = frag(buf, g + 1, sl);
-          if (sl < 4) fa[nxt][sl] = v; else fb[nxt][sl - 4] = v;
-        }
-#if VG_W128_PLAN == 1
-        const int di = g * 8 + sl;                          // 8 + 8 DMA instructions over groups 0..1
-        if (has_next && g < 2) dma(kt + 1, buf ^ 1, di);
-#else
-        const int di = g * 6 + sl;                          // 6 + 6 + 4 DMA instructions over groups 0..2
-        if (has_next && g < 3 && sl < (g < 2 ? 6 : 4)) dma(kt + 1, buf ^ 1, di);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (g < 3) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                 // next group's fragments: requested >= 2 MFMAs ago
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
-    const int buf = kt & 1;
-    step(kt, buf, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage kt+1 landed ...
-    __builtin_amdgcn_s_barrier();                           // ... everyone's did, and everyone is done with stage kt
-#pragma unroll
-    for (int x = 0; x < 8; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  step(kt, kt & 1, false);
-  __syncthreads();   // the epilogue reuses the ring as fp32 staging: 4 waves x 32 rows x 132 floats
-
-  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-  const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-  constexpr int ES = 132;
-  float* ws = (float*)smem + wave * 32 * ES;
-  const int cg = lane & 15, rsub = lane >> 4;
-  const int n0 = (p.a_op == 1 ? bn * 128 : bn * 256 + wn * 128) + cg * 8;
-  float bv[8], gv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-    vg_lds_barrier();
-    if (p.a_op == 1) {
-      // SwiGLU: waves (wm,0) / (wm,1) staged the gate / up halves of the same 32 rows x 128 outputs; each finishes 16
-      // of the rows: y = round(silu(round(gate + b_g))) * round(up + b_u)  (the arithmetic of gemm_epilogue128's GLU)
-      const float* wg = (const float*)smem + (wm * 2) * 32 * ES;
-      const float* wu = wg + 32 * ES;
-#pragma unroll 1
-      for (int pass = 0; pass < 4; ++pass) {
-        const int ml = wn * 16 + pass * 4 + rsub;
-        const int m = bm * 256 + wm * 128 + i * 32 + ml;
-        if (m >= M || n0 >= N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float g = wg[ml * ES + cg * 8 + e] + bv[e];
-          float u = wu[ml * ES + cg * 8 + e] + ((p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f);
-          if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-          g = vg_silu(g);
-          if (sizeof(TO) == 2) g = bf2f(f2bf(g));
-          v[e] = g * u;
-        }
-        TO* cp = C + (int64_t)m * p.ldc + n0;
-        if (n0 + 8 <= N) {
-          if constexpr (sizeof(TO) == 2) {
-            u32x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            *(u32x4_t*)cp = o;
-          } else {
-            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-            *(f32x4_t*)cp = o0;
-            *(f32x4_t*)(cp + 4) = o1;
-          }
-        } else {
-          for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
-        }
-      }
-      continue;
-    }
-#pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {     // not unrolled: nothing in here indexes the accumulators
-      const int ml = pass * 4 + rsub;
-      const int m = bm * 256 + wm * 128 + i * 32 + ml;
-      if (m >= M || n0 >= N) continue;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-      TO* cp = C + (int64_t)m * p.ldc + n0;
-      const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
-      if (n0 + 8 <= N && p.vec_out) {
-        if constexpr (sizeof(TO) == 2) {
-          if (rp) {
-            const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-          }
-          u32x4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-          *(u32x4_t*)cp = o;
-        } else {
-          if (rp) {
-            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          }
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *(f32x4_t*)cp = o0;
-          *(f32x4_t*)(cp + 4) = o1;
-        }
-      } else {
-        for (int e = 0; e < 8 && n0 + e < N; ++e) {
-          float o = v[e];
-          if (rp) o += vg_elt<TO>::ld(rp + e);
-          vg_elt<TO>::st(cp + e, o);
-        }
-      }
-    }
-  }
-}
-
-// The same 256x256 tile on EIGHT waves (2 in M x 4 in N, 128x64 each: 128 accumulator registers, two waves per SIMD): while
-// one wave of a SIMD waits for the next stage's DMAs or sits in the barrier the other one keeps the matrix pipe busy — the
-// four-wave kernel spends 21 % of its wave time there with nobody to cover.  Default since r01 (+1...8 % on the LLM shapes);
-// VG_GEMM_W128=5 (shape rule) / 2 (forced) select the four-wave kernel.
-template <typename T, typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_tile_w128x8_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KPC = 16 / sizeof(T);
-  constexpr int BK = 128 / sizeof(T);
-  constexpr int TA = 256 * 128, STAGE = 2 * TA;
-  // LDS map (160 KB): stage 0 | 32 KB spare | stage 1.  The fp32 epilogue staging (8 waves x 32 rows x 68 floats = 69632 B) of a
-  // tile whose last K step sat in stage b covers stage b plus 4 KB of the spare, never the other stage — which is receiving the
-  // NEXT tile's first K step by then (persistent workgroups: see the tile loop below).
-  constexpr int SPARE = 32 * 1024, EPI = 8 * 32 * 68 * 4;
-  auto sbase = [](int buf) { return buf ? STAGE + SPARE : 0; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, h = lane >> 5;
-  const int M = p.M, N = p.N, K = p.K;
-  const int mt = (M + 255) / 256, nt = p.a_op == 1 ? (N + 127) / 128 : (N + 255) / 256;
-  const int per = mt * nt, total = per * p.nbatch;
-  const int xq = total >> 3, xr = total & 7;
-
-  // persistent: workgroup w runs tiles w, w + gridDim.x, ... in the order the hardware would have dispatched them (same XCD
-  // remap, same column-group walk), so the tiles in flight at any time still share their A / W panels through the XCDs' L2s
-  int bm, bn, bz;
-  const T* src[8];
-  auto setup = [&](int lin) {
-    const int xcd = lin & 7;
-    const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-    bz = wgid / per;
-    gemm_tile_of(wgid - bz * per, mt, nt, p.gn, bm, bn);
-    const T* A = (const T*)p.A + (int64_t)bz * p.sA;
-    const T* W = (const T*)p.W + (int64_t)bz * p.sW;
-    // wave w stages rows [32w, 32w+32) of each operand: 4 DMA instructions of 8 rows (8 lanes per 128-byte row) each
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wave * 32 + i * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      int gm = bm * 256 + row, gn = bn * 256 + row;
-      gm = gm < M ? gm : M - 1;
-      gn = gn < N ? gn : N - 1;
-      if (p.a_op == 1) {     // fused SwiGLU: W rows 0..127 of the tile = gate rows, 128..255 = up rows of the SAME 128 outputs
-        const int o = bn * 128 + (row & 127);
-        gn = (o < N ? o : N - 1) + (row < 128 ? 0 : N);
-      }
-      src[i] = A + (int64_t)gm * p.lda + chunk * KPC;
-      src[4 + i] = W + (int64_t)gn * p.ldw + chunk * KPC;
-    }
-  };
-  auto dma = [&](int kt, int buf, int i) {      // instruction i of stage kt: 0..3 A pieces, 4..7 W pieces
-    char* dst = smem + sbase(buf) + (i >> 2) * TA + wave * 32 * 128 + (i & 3) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-
-  const int ra = wm * 128 + l31, rb = wn * 64 + l31;
-  const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;       // rows r + 32 i share the key
-  const int nk = K / BK;
-  f32x16_t acc[4][2];
-  u32x4_t fa[2][4], fb[2][2];          // fragment sets of two consecutive MFMA groups
-  auto frag = [&](int buf, int g, int x) -> u32x4_t {       // x: 0..3 A row tiles, 4..5 W row tiles
-    const int c = 2 * g + h;
-    if (x < 4) return *(const u32x4_t*)(smem + sbase(buf) + (ra + x * 32) * 128 + ((c ^ swa) << 4));
-    return *(const u32x4_t*)(smem + sbase(buf) + TA + (rb + (x - 4) * 32) * 128 + ((c ^ swb) << 4));
-  };
-  // one K step = 4 groups x 4 slots; a slot = 2 MFMAs, then one or two fragment reads of the next group (6 per group), then
-  // (first three groups, while a next stage exists) at most one DMA instruction of the next stage (3 + 3 + 2).  `kt + 1` is the
-  // K step the DMAs fetch (through src[]: on a tile's last step that is step 0 of the workgroup's NEXT tile)
-  auto step = [&](int kt, int buf, bool has_next) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cur = g & 1, nxt = cur ^ 1;
-      if (g == 0) __builtin_amdgcn_s_waitcnt(0xC07F);
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
-        MmaOp<T>::run(fa[cur][sl], fb[cur][0], acc[sl][0]);
-        MmaOp<T>::run(fa[cur][sl], fb[cur][1], acc[sl][1]);
-        if (g < 3) {
-          // reads 0..5 of the next group over the four slots: 2, 2, 1, 1
-          const int r0 = sl < 2 ? 2 * sl : 2 + sl, r1 = sl < 2 ? r0 + 2 : r0 + 1;
-#pragma unroll
-          for (int x = r0; x < r1; ++x) {
-            const u32x4_t v = frag(buf, g + 1, x);
-            if (x < 4) fa[nxt][x] = v; else fb[nxt][x - 4] = v;
-          }
-        }
-#ifndef VG_W128X8_PLAN
-#define VG_W128X8_PLAN 0
-#endif
-#if VG_W128X8_PLAN == 0
-        const int di = g * 3 + sl;                          // 3 + 3 + 2 DMA instructions over groups 0..2
-        if (has_next && g < 3 && sl < (g < 2 ? 3 : 2)) dma(kt + 1, buf ^ 1, di);
-#elif VG_W128X8_PLAN == 1
-        if (has_next && g < 2) dma(kt + 1, buf ^ 1, g * 4 + sl);          // 4 + 4 over groups 0..1
-#elif VG_W128X8_PLAN == 2
-        if (has_next && g == 0) { dma(kt + 1, buf ^ 1, 2 * sl); dma(kt + 1, buf ^ 1, 2 * sl + 1); }   // all eight in group 0
-#else
-        if (has_next && g == 0 && sl == 0) {                                // all eight before the step's first fragment read returns
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dma(kt + 1, buf ^ 1, i);
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (g < 3) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-
-  auto epilogue = [&](int bm, int bn, int bz, int ebase) {
-    TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-    const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-    constexpr int ES = 68;
-    float* ws = (float*)(smem + ebase) + wave * 32 * ES;
-    const int cg = lane & 7, rsub = lane >> 3;
-    const int n0w = p.a_op == 1 ? bn * 128 + (wn & 1) * 64 : bn * 256 + wn * 64;
-    const int n0 = n0w + cg * 8;
-    const bool fast = n0w + 64 <= N && !p.sa;      // wave-uniform: whole 16-byte groups -> the straight-line forms
-    float bv[8], gv[8], bu[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-      gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-      bu[e] = (p.a_op == 1 && p.bias && n0 + e < N) ? p.bias[N + n0 + e] : 0.f;
-    }
-    // (the four 32-row passes are instantiated by hand: with the dispatch lambda inside, "#pragma unroll" on a loop over i is not
-    // honoured, and a run-time acc[i] sends the accumulators to scratch)
-    auto pass32 = [&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      if (i) vg_lds_barrier();      // (NOT __syncthreads: its fence would wait for the previous pass's global stores to be acknowledged)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + j * 32 + l31] = acc[i][j][r];
-      vg_lds_barrier();
-      const int mrow = bm * 256 + wm * 128 + i * 32;
-      if (p.a_op == 1) {
-        // SwiGLU: waves (wm, c) / (wm, c + 2) staged the gate / up halves of the same 32 rows x 64 outputs; each finishes 16 rows:
-        // y = round(silu(round(gate + b_g))) * round(up + b_u)  (the arithmetic of gemm_epilogue128's GLU)
-        const float* wg = (const float*)(smem + ebase) + (wm * 4 + (wn & 1)) * 32 * ES;
-        const float* wu = wg + 2 * 32 * ES;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const int ml = (wn >> 1) * 16 + pass * 8 + rsub;
-          const int m = mrow + ml;
-          if (m >= M || n0 >= N) continue;
-          float gx[8], ux[8];
-          if (fast) {
-            const f32x4_t g0 = *(const f32x4_t*)(wg + ml * ES + cg * 8), g1 = *(const f32x4_t*)(wg + ml * ES + cg * 8 + 4);
-            const f32x4_t u0 = *(const f32x4_t*)(wu + ml * ES + cg * 8), u1 = *(const f32x4_t*)(wu + ml * ES + cg * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { gx[e] = g0[e]; gx[4 + e] = g1[e]; ux[e] = u0[e]; ux[4 + e] = u1[e]; }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gx[e] = wg[ml * ES + cg * 8 + e]; ux[e] = wu[ml * ES + cg * 8 + e]; }
-          }
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float g = gx[e] + bv[e];
-            float u = ux[e] + bu[e];
-            if (sizeof(TO) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }
-            g = vg_silu(g);
-            if (sizeof(TO) == 2) g = bf2f(f2bf(g));
-            v[e] = g * u;
-          }
-          TO* cp = C + (int64_t)m * p.ldc + n0;
-          if (n0 + 8 <= N) {
-            if constexpr (sizeof(TO) == 2) {
-              u32x4_t o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-              epi_store16(cp, o, p.nt);
-            } else {
-              f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-              *(f32x4_t*)cp = o0;
-              *(f32x4_t*)(cp + 4) = o1;
-            }
-          } else {
-            for (int e = 0; e < 8 && n0 + e < N; ++e) vg_elt<TO>::st(cp + e, v[e]);
-          }
-        }
-        return;
-      }
-      if (fast && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
-            epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 4, ES, 8, decltype(gam)::value != 0>(p, ws, mrow, n0, cg, rsub, bv, gv, C, R);
-          }))
-        return;
-#pragma unroll 1
-      for (int pass = 0; pass < 4; ++pass) {     // edge tiles (N not a whole 16-byte group here)
-        const int ml = pass * 8 + rsub;
-        const int m = mrow + ml;
-        if (m >= M || n0 >= N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = vg_act(ws[ml * ES + cg * 8 + e] + bv[e], p.act) * gv[e];
-        TO* cp = C + (int64_t)m * p.ldc + n0;
-        const TO* rp = R ? R + (int64_t)m * p.ldr + n0 : nullptr;
-        if (n0 + 8 <= N && p.vec_out) {
-          if constexpr (sizeof(TO) == 2) {
-            if (rp) {
-              const u32x4_t rv = *(const u32x4_t*)rp;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rv[e] << 16); v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u); }
-            }
-            u32x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf2(v[2 * e], v[2 * e + 1]);
-            epi_store16(cp, o, p.nt);
-          } else {
-            if (rp) {
-              const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-            }
-            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-            *(f32x4_t*)cp = o0;
-            *(f32x4_t*)(cp + 4) = o1;
-          }
-        } else {
-          for (int e = 0; e < 8 && n0 + e < N; ++e) {
-            float o = v[e];
-            if (rp) o += vg_elt<TO>::ld(rp + e);
-            vg_elt<TO>::st(cp + e, o);
-          }
-        }
-      }
-    };
-    pass32(epi_ic<0>{});
-    pass32(epi_ic<1>{});
-    pass32(epi_ic<2>{});
-    pass32(epi_ic<3>{});
-  };
-
-  int t = blockIdx.x;
-  if (t >= total) return;
-  setup(t);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma(0, 0, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int base = 0;                        // the stage holding K step 0 of the current tile
-  while (true) {
-#pragma unroll
-    for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(base, 0, x);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __builtin_amdgcn_sched_barrier(0);
-    int kt = 0;
-    for (; kt + 1 < nk; ++kt) {
-      const int buf = (base + kt) & 1;
-      step(kt, buf, true);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int x = 0; x < 6; ++x) (x < 4 ? fa[0][x] : fb[0][x - 4]) = frag(buf ^ 1, 0, x);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // last K step of the tile: its DMA slots fetch K step 0 of this workgroup's next tile into the other stage, so the next
-    // tile starts without a load round trip and this tile's output stores drain under the next tile's first K step
-    const int last = (base + kt) & 1;
-    const int tn = t + gridDim.x;
-    const bool more = tn < total;
-    const int cbm = bm, cbn = bn, cbz = bz;
-    if (more) setup(tn);
-    step(-1, last, more);
-    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                   // everyone is done reading stage `last`: the epilogue stages fp32 tiles there
-    epilogue(cbm, cbn, cbz, last ? STAGE + SPARE + STAGE - EPI : 0);
-    if (!more) break;
-    vg_lds_barrier();                  // staging reads done: stage `last` may take the next tile's K step 1
-    base = last ^ 1;
-    t = tn;
-  }
-}
-
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& a, const u32x4_t& b);
 template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& a, const u32x4_t& b) {
   float s = 0.f;
@@ -1465,40 +960,34 @@ static int env_knob(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-static int knob_variant() { static const int v = env_knob("VG_GEMM_VARIANT", 1284); return v; }
-static int knob_k64b() { static const int v = env_knob("VG_GEMM_K64B", 1); return v; }
-static int env_knob_s128() { static const int v = env_knob("VG_GEMM_S128", 1); return v; }
-static int knob_w128() { static const int v = env_knob("VG_GEMM_W128", 1); return v; }
+static int knob_p8() { static const int v = env_knob("VG_GEMM_P8", 1); return v; }    // 0: no 256x256 route (A/B), 2: every eligible bf16 shape
 // small problems with a short K: fewer than 256 tiles of 128x128 (the chip is not filled), K = 64 / 128 / 192 / 256 bf16 -> gemm_small64_kernel
 static bool route_small64(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch) {
-  static const int on = env_knob("VG_GEMM_SMALL64", 1);
-  if (!on || es != 2 || a_op || wmode || !vec_out || M <= 16 || K % 64 != 0 || K > 256) return false;
+  if (es != 2 || a_op || wmode || !vec_out || M <= 16 || K % 64 != 0 || K > 256) return false;
   return ((M + 127) / 128) * ((N + 127) / 128) * batch < 256;
 }
 // few K-steps per tile (K x element size <= 3 KB): the 64-byte-step kernel with four workgroups per CU
 // (measured r01, tools/bench_gemm.py: +20...50 % on the Hiera / tower shapes up to K = 1408, -10...15 % from K = 2304 up)
 static bool route_small_k(int64_t K, int es, int a_op) {
-  const int v = knob_variant();
-  return knob_k64b() && (v == 1283 || v == 1284) && K * es <= 3072 && a_op == 0;
+  return K * es <= 3072 && a_op == 0;
 }
 // single-stage 128-byte-row kernel: the small-K shapes with at least four whole-line K steps (measured r01: +16...18 % on
 // Hiera stage 3 / 4 and +7...14 % on the tower shapes over the 64-byte-row kernel; K = 144 / 288 stay there)
 static bool route_s128(int64_t K, int es, int a_op) {
-  const int k = env_knob_s128();
-  return (k == 1 && route_small_k(K, es, a_op) && K * es >= 1024) || (k == 2 && a_op == 0);
+  return route_small_k(K, es, a_op) && K * es >= 1024;
 }
 // 256x256 tile, 128x128 per wave: bf16, whole 128-byte K steps, and the 256-tiles must use the chip well: (useful
 // fraction of the tiles' area) x (fill of the rounds of 256 workgroups) >= 0.7 — Hiera's N = 576 outputs or 168-tile
 // grids stay on the 128x128 kernels (measured r01, tools/bench_gemm.py).  a_op == 1: a tile is 256 rows x 128 outputs
-static bool route_w128(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch, int* ntw_out, int* mtw_out) {
+static bool route_p8(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch, int* ntw_out, int* mtw_out) {
   const int ntw = (int)(a_op == 1 ? (N + 127) / 128 : (N + 255) / 256), mtw = (int)((M + 255) / 256);
   if (ntw_out) { *ntw_out = ntw; *mtw_out = mtw; }
-  const int w = knob_w128();
+  const int w = knob_p8();
   // (r02, persistent kernel + straight-line epilogue: from K x es = 2304 B — Hiera stage 4, InternVideo2 — the 256x256 kernel beats the
   // single-stage 128x128 one by 2...9 %; K = 1024 / 576 stay there)
-  static const int smallk_min = env_knob("VG_W128_MINKB", 1152);     // r04: with the phase-split kernel also K = 576 (Hiera stage 3): C2 268.5 -> 266.7 ms same-box
+  constexpr int smallk_min = 1152;     // r04: with the phase-split kernel also K = 576 (Hiera stage 3): C2 268.5 -> 266.7 ms same-box
   if (!w || es != 2 || (route_small_k(K, es, a_op) && K * es < smallk_min) || wmode || K % (128 / es) != 0 || !vec_out) return false;
-  if (w == 2 || w == 4) return true;       // 2 / 4: force the 4-wave / 8-wave kernel on every eligible shape (3: 8-wave, shape rule)
+  if (w == 2) return true;       // 2: force the 256x256 kernel on every eligible shape
   const int64_t t256 = (int64_t)ntw * mtw * batch;
   const double useful = (double)M * N / ((double)mtw * 256 * ntw * (a_op == 1 ? 128 : 256));
   const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
@@ -1511,28 +1000,13 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     if (p.a_op == 1) launch_skinny<T, TO, true>(p, batch, st);
     else launch_skinny<T, TO, false>(p, batch, st);
   } else {
-    // tile walk (gemm_tile_of): VG_GEMM_GN = N-tiles per column group; 0 (default) = 4, i.e. a 4 x 16 patch of
-    // concurrent tiles per XCD; a huge value = plain row-major
-    static int gn_env = -1;
-    if (gn_env < 0) {
-      const char* e = getenv("VG_GEMM_GN");
-      gn_env = e ? atoi(e) : 0;
-    }
-    auto pick_gn = [&](int mt, int nt) {
-      int g = gn_env > 0 ? gn_env : 4;   // measured r01 (tools/bench_gemm.py): 4 >= 8 > 16 > row-major on every C1 shape
-      return g < 1 ? 1 : (g > nt ? nt : g);
-    };
+    // tile walk (gemm_tile_of): column groups of 4 N-tiles, i.e. a 4 x 16 patch of concurrent tiles per XCD
+    // (measured r01, tools/bench_gemm.py: 4 >= 8 > 16 > row-major on every C1 shape)
+    auto pick_gn = [&](int mt, int nt) { return nt < 4 ? nt : 4; };
     GemmArgs q = p;
     q.gn = pick_gn((p.M + GBM - 1) / GBM, (p.N + GBN - 1) / GBN);
-    // streaming stores for big outputs with sector-aligned rows (epi_store16): VG_GEMM_NT = 0 never, 1 (default) by this rule, 2 always
-    static const int nt_mode = env_knob("VG_GEMM_NT", 1);
-    static const int nt_mb = env_knob("VG_GEMM_NT_MB", 128);
-    q.nt = nt_mode == 2 || (nt_mode == 1 && p.vec_out && (p.ldc * (int64_t)sizeof(TO)) % 64 == 0 &&
-                            (int64_t)p.M * p.N * (int64_t)sizeof(TO) * batch >= (int64_t)nt_mb << 20);
-    // VG_GEMM_VARIANT = 644: the 64-byte-step kernel for every shape (A/B knob); default: the 128x128 LDS-DMA kernel with all 16 fragment
-    // reads of a K step requested up front.  (The register-staged kernels 1281 / 1282 / 641 / 642, the group-by-group fragment reads 1283
-    // and the 256x128 three-stage ring, r01's A/B twins, were removed at the end of r02: -10 % / 0 / +-3 %)
-    const int variant = knob_variant();
+    // streaming stores for big outputs (>= 128 MB, r03) with sector-aligned rows (epi_store16)
+    q.nt = p.vec_out && (p.ldc * (int64_t)sizeof(TO)) % 64 == 0 && (int64_t)p.M * p.N * (int64_t)sizeof(TO) * batch >= (int64_t)128 << 20;
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, batch);
     // the fp32 epilogue staging needs 4 x 64 x 68 floats = 69632 B of LDS whatever the K step
     const int lds128 = 4 * 128 * 144;
@@ -1542,18 +1016,11 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       glds_attr = true;
     }
     const bool small_k = route_small_k(p.K, (int)sizeof(T), p.a_op);
-    static bool w128_attr = false;
-    if (!w128_attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_tile_w128_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 256 * 128);
-      (void)hipFuncSetAttribute((const void*)gemm_tile_w128x8_kernel<T, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      w128_attr = true;
-    }
     int ntw, mtw;
     // (r04: a padding-free power-of-two window GATHER rides on the phase-split kernel — Hiera stage 3's windowed qkv; everything else windowed
     // stays on the 128x128 kernels)
-    static const int p8_win = env_knob("VG_GEMM_P8", 1) && env_knob("VG_GEMM_P8_WINDOW", 1) && (knob_w128() == 1 || knob_w128() == 3);
-    const int wroute = (p8_win && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
-    const bool big = route_w128(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, &ntw, &mtw);
+    const int wroute = (knob_p8() == 1 && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
+    const bool big = route_p8(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, &ntw, &mtw) && vg_gemm_p8_eligible(p, batch);
     if constexpr (sizeof(T) == 2) {
       if (route_small64(p.M, p.N, p.K, 2, p.a_op, p.wmode, p.vec_out, batch) && !p.sa) {
         const int nseg = p.K / 64;
@@ -1570,23 +1037,14 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       }
     }
     if (big) {
-      dim3 gridw(ntw, mtw, batch);
-      q.gn = pick_gn(mtw, ntw);
-      static const int stagger = env_knob("VG_W128_STAGGER", 0);
-      q.stagger = stagger;
-      q.nbatch = batch;
-      // persistent: one workgroup per CU walks the tile queue (VG_W128_PERSIST=0: one workgroup per tile, as before r02)
-      static const int persist = env_knob("VG_W128_PERSIST", 1);
-      static const int ncu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-      const int64_t tot = (int64_t)ntw * mtw * batch;
-      const int wgs = (int)(persist && tot > ncu ? ncu : tot);
-      // r04: the phase-split pipeline (vg_gemm_p8.hip) takes every bf16 shape of this route; VG_GEMM_P8=0 restores the lock-step kernels
-      static const int p8 = env_knob("VG_GEMM_P8", 1);
       if constexpr (sizeof(T) == 2) {
-        if (p8 && vg_gemm_p8_eligible(q, batch)) return vg_gemm_p8_launch(q, sizeof(TO) == 2, wgs, st);
+        q.gn = pick_gn(mtw, ntw);
+        q.nbatch = batch;
+        // persistent: one workgroup per CU walks the tile queue
+        static const int ncu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int64_t tot = (int64_t)ntw * mtw * batch;
+        return vg_gemm_p8_launch(q, sizeof(TO) == 2, (int)(tot > ncu ? ncu : tot), st);
       }
-      if (knob_w128() != 2 && knob_w128() != 5) gemm_tile_w128x8_kernel<T, TO><<<wgs, 512, 160 * 1024, st>>>(q);   // 2 / 5: the 4-wave kernel
-      else gemm_tile_w128_kernel<T, TO><<<gridw, 256, 2 * 2 * 256 * 128, st>>>(q);
     } else if (route_s128(p.K, (int)sizeof(T), p.a_op)) {
       gemm_tile_s128_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
     } else if (small_k) {
@@ -1597,8 +1055,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
       gemm_tile_glds_kernel<T, TO, true><<<gridg, 256, lds128, st>>>(q);
     } else if (p.wmode) {
       gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
-    } else if (variant == 644) gemm_tile_k64b_kernel<T, TO><<<grid, 256, 4 * 32 * 68 * 4, st>>>(q);
-    else gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
+    } else gemm_tile_glds_kernel<T, TO, true><<<grid, 256, lds128, st>>>(q);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -1761,7 +1218,7 @@ extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int 
   if (M <= 16) return 0;
   const int es = in_dtype == VG_BF16 ? 2 : 4;
   if (route_small64(M, N, K, es, a_op, windowed, 1, 1)) return 5;
-  if (route_w128(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
+  if (route_p8(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
   if (route_s128(K, es, a_op)) return 4;
   if (route_small_k(K, es, a_op)) return 2;
   return 1;

@@ -23,7 +23,6 @@ struct GemmArgs {
   // go to part[z][M][N], a second kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
   int nbatch;   // persistent 256x256 kernel: batch count (tiles of all batch entries form one queue)
-  int stagger;  // 256x256 kernels: first-round workgroup w sleeps (w & 3) * stagger * ~4 us before its first load (phase desynchronisation knob)
   int nt;       // output tiles leave with non-temporal (streaming) stores: large outputs whose rows are whole 64-byte sectors (launch_gemm)
 };
 

@@ -497,10 +497,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
   };
   int t = blockIdx.x;
   if (t >= total) return;
-  if (p.stagger > 0) {       // VG_W128_STAGGER (lab knob): de-phase the workgroups' epilogue store bursts — workgroup w starts ((w >> 3) % 8) * stagger * ~0.25 us late
-    const int n = ((blockIdx.x >> 3) & 7) * p.stagger;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-  }
   int lane_t = lane;
   asm volatile("" : "+v"(lane_t));            // tile-invariant address terms stay inside the tile (hoisted, they are live across the K loop: spills)
   setup(t, lane_t);

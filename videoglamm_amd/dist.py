@@ -33,13 +33,25 @@ from . import ops
 
 
 class FrameSharder:
-    def __init__(self, group=None, gather_masks=True, profile=False):
+    def __init__(self, group=None, gather_masks=True, profile=False, stream_features=None, stream_steps=4):
+        """stream_features (video branch): True = the FPN features are all-gathered chunk by chunk, on a communicator of their own, while Hiera
+        still runs (hiera_all_frames); False = one exchange after the last frame (gather_frame_feats).  Default: VG_FEATURES_STREAMED, off —
+        the streamed order has not been timed on an N-GPU node yet (no such node was reachable in r04 / r05)."""
         assert dist.is_initialized(), "init torch.distributed first (torchrun: one process per GPU)"
         assert gather_masks in (True, False, "rank0")
         self.group = group
         self.gather_masks = gather_masks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stream_features = (os.environ.get("VG_FEATURES_STREAMED", "0") == "1") if stream_features is None else bool(stream_features)
+        self.stream_steps = max(1, int(stream_steps))
+        # a process group runs its collectives in order on ONE internal stream: the streamed feature gathers get their own communicator, or the
+        # text side's small collectives (tower tokens, K/V rows, [SEG]) would queue behind every Hiera chunk of the slowest rank.  new_group is
+        # collective over the default group, and every rank constructs its FrameSharder with the same arguments.
+        self.feat_group = group
+        if self.stream_features and self.world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self.feat_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
         # profile (bench.py --gpus N): every collective is bracketed by events on the stream that issues it and its payload is counted, so that a
         # scaling record shows what was exchanged, how often and for how long — collective_report()
         self.profile = profile
@@ -198,43 +210,62 @@ class FrameSharder:
             levels.append(self.gather_blocks(stacked, T, 0, (T,) + level_shapes[lv], sam2.dtype, sam2.device, name="feature_all_gather"))
         return {t: [levels[lv][t:t + 1] for lv in range(3)] for t in range(T)}
 
+    def stream_plan(self, T, frame_chunk):
+        """(chunk, steps, counts) of the streamed exchange: the largest per-rank block is cut into about `stream_steps` chunks (never more
+        frames than SAM2.frame_chunk per Hiera launch group, never fewer than one), so that several exchanges exist to overlap with the
+        remaining chunks — r04 used frame_chunk (16) itself: one step and 4x zero padding at 8 ranks x 4 frames."""
+        counts = self.counts(T)
+        most = max(counts)
+        ch = max(1, min(max(1, frame_chunk), -(-most // self.stream_steps)))
+        return ch, -(-most // ch) if most else 0, counts
+
     def hiera_all_frames(self, sam2, images_for_sam):
         """frame-sharded Hiera + FPN with the features STREAMED to every rank (video branch: the object ranks need all frames): the rank's frames
-        go through Hiera in chunks (SAM2.frame_chunk) and a chunk's three levels are all-gathered — asynchronously under RCCL — while the next
-        chunk is being computed, instead of one exchange of the whole clip's features after the last frame (r04; 8.4 MB per frame at SAM2-L).
-        Every rank runs the same number of chunk steps (blocks differ by at most one frame; a step a rank has no frame for sends an empty,
-        padded block) -> {frame: fpn levels} for all T frames."""
+        go through Hiera in chunks (stream_plan) and a chunk's three levels are all-gathered — asynchronously, on the feature communicator, under
+        RCCL — while the next chunk is being computed, instead of one exchange of the whole clip's features after the last frame (8.4 MB per
+        frame at SAM2-L).  Every rank runs the same number of steps; a step's blocks are padded to the largest block any rank has IN THAT STEP
+        (blocks differ by at most one frame, so the padding is at most one frame per rank and step) -> {frame: fpn levels} for all T frames."""
         T = images_for_sam.shape[0]
         frames = self.my_frames(T)
-        counts = self.counts(T)
-        S, ch = sam2.S, max(1, sam2.frame_chunk)
+        ch, steps, counts = self.stream_plan(T, sam2.frame_chunk)
         level_shapes = sam2.level_shapes()
         starts = [sum(counts[:r]) for r in range(self.world)]
-        steps = -(-max(counts) // ch)
-        asyn = images_for_sam.is_cuda and dist.get_backend(self.group) != "gloo"
+        asyn = images_for_sam.is_cuda and dist.get_backend(self.feat_group) != "gloo"
+        es = torch.empty((), dtype=sam2.dtype).element_size()
         pending, out = [], {}
         for st in range(steps):
             mine = frames[st * ch:(st + 1) * ch]
+            n_step = [max(0, min(ch, counts[r] - st * ch)) for r in range(self.world)]
+            pad = max(n_step)
             feats = sam2.hiera_frames(images_for_sam, mine) if mine else {}
             for lv in range(3):
-                send = torch.zeros((ch,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
+                per_frame = es
+                for d in level_shapes[lv]:
+                    per_frame *= d
+                payload = sum(n_step) * per_frame                      # what the ranks actually hold in this step, without the padding
+                send = torch.zeros((pad,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
                 if mine:
                     send[:len(mine)].copy_(torch.cat([feats[t][lv] for t in mine], dim=0))
                 if asyn:
-                    recv = torch.empty((self.world * ch,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
-                    nbytes = recv.numel() * recv.element_size()
-                    work = self._timed("feature_all_gather (streamed, issue)", nbytes,
-                                       lambda: dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
-                    pending.append((st, lv, recv, work))
+                    recv = torch.empty((self.world * pad,) + level_shapes[lv], dtype=sam2.dtype, device=sam2.device)
+                    e0 = None
+                    if self.profile:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    work = dist.all_gather_into_tensor(recv, send, group=self.feat_group, async_op=True)
+                    pending.append((st, lv, recv, work, pad, n_step, e0, payload))
                 else:
                     parts = self._all_gather(send, "feature_all_gather (streamed)")
-                    pending.append((st, lv, torch.cat(parts, dim=0), None))
-        for st, lv, recv, work in pending:
+                    pending.append((st, lv, torch.cat(parts, dim=0), None, pad, n_step, None, payload))
+        for st, lv, recv, work, pad, n_step, e0, payload in pending:
             if work is not None:
                 work.wait()             # the current stream waits for the collective; the host does not
+                if e0 is not None:      # issue -> completion as seen by the consuming stream (the time the exchange had to hide in)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._events.setdefault("feature_all_gather (streamed, issue to consumed)", []).append((e0, e1, int(payload)))
             for r in range(self.world):
-                n_r = max(0, min(ch, counts[r] - st * ch))
-                for j in range(n_r):
+                for j in range(n_step[r]):
                     t = starts[r] + st * ch + j
-                    out.setdefault(t, [None, None, None])[lv] = recv[r * ch + j:r * ch + j + 1]
+                    out.setdefault(t, [None, None, None])[lv] = recv[r * pad + j:r * pad + j + 1]
         return out

@@ -119,14 +119,71 @@ def clip_preprocess(frame_u8, size=336):
     return torch.from_numpy(np.transpose(x, (2, 0, 1))).float()
 
 
-def preprocess_vision(np_frames, num_frames=16):
-    """preprocess_vision(type='video') — R/chat.py:402-456: returns the reference's five inputs
-    (images, context_images, images_for_sam, resize_list, original_size_list), batch of one."""
-    enc_frames = pad_or_truncate(subsample_frames(np_frames, num_frames), num_frames)
-    images = torch.stack([iv2_preprocess(f) for f in enc_frames])
-    context = torch.stack([clip_preprocess(f) for f in enc_frames])
-    sam, shapes = zip(*[sam_preprocess(f) for f in np_frames])
-    return [images], [context], [torch.stack(sam)], [shapes[0]], [tuple(np_frames[0].shape[:2])]
+NUM_FRAMES = int(os.environ.get("NUM_FRAMES", 16))     # R/model/videogpt_plus/constants.py (the reference reads the same variable)
+
+
+class SAM_v2_Preprocess:
+    """R/utils/sam_transforms.py:77-79."""
+    def preprocess(self, x):
+        return sam_preprocess(np.asarray(x))
+
+
+class EncPreprocessor_VideoGPTPlus:
+    """R/utils/enc_preprocessors.py:106-166: a list of frames -> {'images': NUM_FRAMES InternVideo2 tensors, 'context_images': NUM_FRAMES CLIP
+    tensors} (truncated / last frame repeated); a single image -> {'images': its CLIP tensor, 'context_images': None}."""
+    def __init__(self, num_frames=None):
+        self.num_frames = NUM_FRAMES if num_frames is None else num_frames
+        self.frame_resolution_iv, self.frame_resolution_clip = 224, 336
+
+    def preprocess(self, pil_images):
+        if not isinstance(pil_images, list):
+            return {"images": clip_preprocess(np.asarray(pil_images), self.frame_resolution_clip), "context_images": None}
+        frames = [np.asarray(f) for f in pad_or_truncate(pil_images, self.num_frames)]
+        return {"images": [iv2_preprocess(f, self.frame_resolution_iv) for f in frames],
+                "context_images": [clip_preprocess(f, self.frame_resolution_clip) for f in frames]}
+
+
+def precision_dtype(precision):
+    """R/chat.py:437 `x.bfloat16() if precision == "bf16" else (x.half() if precision == "fp16" else x.float())`; "fp16" is bf16 on this
+    build (chat.initialize_model_videogptplus warns about it once per load: there is no fp16 compute path)."""
+    return torch.float32 if precision == "fp32" else torch.bfloat16
+
+
+def _to_model(x, precision):
+    x = x.to(precision_dtype(precision))
+    return x.cuda(non_blocking=True) if torch.cuda.is_available() else x
+
+
+def preprocess_vision(np_images, type="video", enc_preprocessor=None, sam_preprocessor=None, conv_generator=None, precision="fp16"):
+    """preprocess_vision — R/chat.py:402-489, same parameters, same five return values in the same order.
+    np_images: B x T x (H x W x C) uint8 arrays, batch of one (what load_video / load_image return).
+    -> (enc_image, enc_context_image, image_sam, original_size_list, resize_list): lists of one [T',3,h,w] tensor (enc_context_image is None
+    for type="image"), [(H, W)] of the source frames, [(h, w)] of the longest-side resize."""
+    assert len(np_images) == 1, "Batch size must be 1"
+    enc_preprocessor = enc_preprocessor or EncPreprocessor_VideoGPTPlus(getattr(conv_generator, "NUM_FRAMES", None))
+    sam_preprocessor = sam_preprocessor or SAM_v2_Preprocess()
+    if type == "video":
+        frames = list(np_images[0])
+        enc = enc_preprocessor.preprocess(subsample_frames(frames, getattr(conv_generator, "NUM_FRAMES", None) or enc_preprocessor.num_frames))
+        enc_image = [_to_model(torch.stack(enc["images"], dim=0), precision)]
+        ctx = enc["context_images"]
+        enc_context_image = None if ctx is None else [_to_model(torch.stack(ctx, dim=0), precision)]
+        original_size_list = [tuple(frames[0].shape[:2])]
+        sam, shapes = zip(*[sam_preprocessor.preprocess(f) for f in frames])
+        image_sam, resize_list = [_to_model(torch.stack(sam, dim=0), precision)], [shapes[0]]
+    elif type == "image":
+        assert len(np_images[0]) == 1, "Time dimension must be 1"
+        image_np = np_images[0][0]
+        enc = enc_preprocessor.preprocess(image_np)
+        enc_image = [_to_model(enc["images"].unsqueeze(0), precision)]
+        ctx = enc["context_images"]
+        enc_context_image = None if ctx is None else [_to_model(ctx.unsqueeze(0), precision)]
+        original_size_list = [tuple(image_np.shape[:2])]
+        sam, shape = sam_preprocessor.preprocess(image_np)
+        image_sam, resize_list = [_to_model(sam.unsqueeze(0), precision)], [shape]
+    else:
+        raise ValueError(f"type must be 'video' or 'image', got {type!r}")
+    return enc_image, enc_context_image, image_sam, original_size_list, resize_list
 
 
 # ----------------------------------------------------------------------------------------------- H2
@@ -167,13 +224,44 @@ def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX
     return torch.tensor(ids, dtype=torch.long)
 
 
-def apply_for_chat(prompt_text, tokenizer, num_frames=16, base_type="llama3_1"):
-    """ConvGenerator_VideoGPTPlus.apply_for_chat(type='video') — R/utils/conv_generator.py:86-111 -> input_ids [1,L]."""
-    prompt = DEFAULT_VIDEO_TOKEN + "\n" + prompt_text
-    prompt = prompt.replace(DEFAULT_VIDEO_TOKEN, DEFAULT_IMAGE_TOKEN * num_frames)
-    roles = TEMPLATES[base_type]["roles"]
-    prompt = get_prompt(base_type, [(roles[0], prompt), (roles[1], "")])
-    return tokenizer_image_token(prompt, tokenizer).unsqueeze(0)
+DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN = "<im_start>", "<im_end>"          # R/model/videogpt_plus/constants.py
+DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN = "<vid_start>", "<vid_end>"
+
+
+class ConvGenerator_VideoGPTPlus:
+    """The inference half of R/utils/conv_generator.py:201-222 + ConvGenerator_Base.apply_for_chat (:86-131)."""
+    NUM_FRAMES = NUM_FRAMES
+
+    def __init__(self, use_mm_start_end=False, base_type="phi3", num_frames=None):
+        if base_type not in TEMPLATES:
+            raise ValueError("Invalid base_llm_type")
+        self.use_mm_start_end, self.base_type = use_mm_start_end, base_type
+        if num_frames is not None:
+            self.NUM_FRAMES = num_frames
+
+    def apply_for_chat(self, prompt_text, type="video", tokenizer=None):
+        """-> input_ids [1, L] (on the GPU when there is one, like the reference's .cuda())."""
+        if type == "video":
+            prompt = DEFAULT_VIDEO_TOKEN + "\n" + prompt_text
+            replace_token, vid_replace_token = DEFAULT_IMAGE_TOKEN, DEFAULT_IMAGE_TOKEN * self.NUM_FRAMES
+            if self.use_mm_start_end:
+                replace_token = DEFAULT_IM_START_TOKEN + replace_token + DEFAULT_IM_END_TOKEN
+                vid_replace_token = DEFAULT_VID_START_TOKEN + vid_replace_token + DEFAULT_VID_END_TOKEN
+            prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, replace_token).replace(DEFAULT_VIDEO_TOKEN, vid_replace_token)
+        elif type == "image":
+            prompt = DEFAULT_IMAGE_TOKEN + "\n" + prompt_text
+            if self.use_mm_start_end:
+                prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN)
+        else:
+            raise ValueError(f"type must be 'video' or 'image', got {type!r}")
+        roles = TEMPLATES[self.base_type]["roles"]
+        ids = tokenizer_image_token(get_prompt(self.base_type, [(roles[0], prompt), (roles[1], "")]), tokenizer).unsqueeze(0)
+        return ids.cuda() if torch.cuda.is_available() else ids
+
+
+def apply_for_chat(prompt_text, tokenizer, num_frames=16, base_type="llama3_1", type="video"):
+    """ConvGenerator_VideoGPTPlus(base_type).apply_for_chat as a function -> input_ids [1,L] on the host."""
+    return ConvGenerator_VideoGPTPlus(False, base_type, num_frames).apply_for_chat(prompt_text, type, tokenizer).cpu()
 
 
 # ----------------------------------------------------------------------------------------------- H4

@@ -364,8 +364,9 @@ class VideoGLaMMForCausalLM:
         """R/model/VideoGLaMM.py:770-879; empty dict when no [SEG] was emitted (:840-842)."""
         sam = images_for_sam[0].to(self.device)
         # multi-GPU: frames shard for Hiera only (the propagation is a recurrence over frames) and every rank needs every frame's features:
-        # they are streamed chunk by chunk while Hiera still runs (VG_FEATURES_STREAMED=0: one exchange of the whole clip after the last frame)
-        streamed = self.comm is not None and os.environ.get("VG_FEATURES_STREAMED", "1") == "1"
+        # one exchange of the whole clip after the last frame (default), or — FrameSharder(stream_features=True) — streamed chunk by chunk on a
+        # communicator of their own while Hiera still runs
+        streamed = self.comm is not None and self.comm.stream_features
         out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens, all_frames=streamed)
         if emb.shape[0] == 0:
             return out_ids, [{}]

@@ -685,6 +685,7 @@ def rope_axial_heads_(x, heads, cos, sin, n_rope, n_grid):
     B, N, _ = x.shape
     Ch = 2 * cos.shape[1]
     assert x.stride(2) == 1 and x.shape[2] >= heads * Ch and x.dtype == torch.bfloat16
+    assert 0 <= int(n_rope) <= N and cos.shape[0] >= int(n_grid) > 0, "vg_rope_axial_heads has no row count to check n_rope against: the wrapper does"
     rc = lib.vg_rope_axial_heads(_p(x), x.stride(1), x.stride(0), _p(_f32(cos)), _p(_f32(sin)), B, heads, Ch, int(n_rope), int(n_grid), _dt(x), _stream())
     _lib.check(rc, "vg_rope_axial_heads")
     return x

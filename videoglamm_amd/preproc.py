@@ -122,12 +122,29 @@ def clip_preprocess(frames, size=336):
     return ops.normalize_u8(x, host.CLIP_MEAN, host.CLIP_STD, 1, crop=((nh - size) // 2, (nw - size) // 2, size, size))
 
 
-def preprocess_vision(np_frames, num_frames=16):
-    """preprocess_vision(type='video'), R/chat.py:402-456, with the pixel work on the device: the clip is uploaded once as
-    uint8; returns the reference's five inputs (images, context_images, images_for_sam, resize_list, original_size_list)."""
-    frames = _frames(np_frames)
+def preprocess_vision(np_images, type="video", enc_preprocessor=None, sam_preprocessor=None, conv_generator=None, precision="fp16"):
+    """preprocess_vision — R/chat.py:402-489 (same parameters, same five values in the same order) with the pixel work on the device: the clip
+    is uploaded once as uint8.  np_images: B x T x (H x W x C), batch of one; a clip is a list of equal-sized frames or one [T,H,W,3] uint8
+    array / device tensor.  The preprocessor objects only carry NUM_FRAMES here (the arithmetic is host.py's, bit for bit); anything but
+    host.py's own classes is refused — use host.preprocess_vision with custom preprocessors.
+    -> (enc_image, enc_context_image, image_sam, original_size_list, resize_list)."""
+    assert len(np_images) == 1, "Batch size must be 1"
+    if not (enc_preprocessor is None or isinstance(enc_preprocessor, host.EncPreprocessor_VideoGPTPlus)) or \
+            not (sam_preprocessor is None or isinstance(sam_preprocessor, host.SAM_v2_Preprocess)):
+        raise TypeError("the device pre-processing path implements host.EncPreprocessor_VideoGPTPlus / host.SAM_v2_Preprocess only")
+    dt = host.precision_dtype(precision)
+    cast = (lambda x: x) if dt == torch.float32 else (lambda x: x.to(dt))
+    frames = _frames(np_images[0])
     T = frames.shape[0]
-    idx = host.pad_or_truncate(host.subsample_frames(list(range(T)), num_frames), num_frames)
-    enc = frames[torch.tensor(idx, device=frames.device)]
+    original_size_list = [tuple(frames.shape[1:3])]
     sam, shape = sam_preprocess(frames)
-    return [iv2_preprocess(enc)], [clip_preprocess(enc)], [sam], [shape], [tuple(frames.shape[1:3])]
+    if type == "image":
+        assert T == 1, "Time dimension must be 1"
+        return [cast(clip_preprocess(frames))], None, [cast(sam)], original_size_list, [shape]
+    if type != "video":
+        raise ValueError(f"type must be 'video' or 'image', got {type!r}")
+    num_frames = getattr(conv_generator, "NUM_FRAMES", None) or getattr(enc_preprocessor, "num_frames", None) or host.NUM_FRAMES
+    n_enc = getattr(enc_preprocessor, "num_frames", None) or num_frames
+    idx = host.pad_or_truncate(host.subsample_frames(list(range(T)), num_frames), n_enc)
+    enc = frames[torch.tensor(idx, device=frames.device)]
+    return [cast(iv2_preprocess(enc))], [cast(clip_preprocess(enc))], [cast(sam)], original_size_list, [shape]
