@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-quality", action="store_true", help="skip the fp32 parity-mode re-run that fills the \"quality\" object")
+    ap.add_argument("--no-video-record", action="store_true", help="skip the video-branch sub-run that fills the \"video_branch\" object of a framewise line")
+    ap.add_argument("--video-steps", type=int, default=5, help="timed steps of the video-branch sub-run")
     ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
                     help="llama3-8b = BASELINE configs C1-C3 (default); phi3-mini = the released checkpoint's LLM")
     ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
@@ -213,6 +215,17 @@ class AttnMeter:
         self.o_pool = self.ops.window_attention
         self._in_win = False
         self.ops.attention, self.ops.attention_windows = timed, timed_win
+        self.o_dv = self.ops.attention_dv
+
+        def timed_dv(q, k, v, scale):      # SAM2 memory cross-attention with the v-projection behind it: QK^T on D dims, PV on the memory's own DV dims
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.o_dv(q, k, v, scale)
+            e1.record()
+            B, Sq, H, D = q.shape
+            self.rec.append((2.0 * B * H * Sq * k.shape[1] * (D + v.shape[-1]), e0, e1, f"{self.dp(D)}_dv{v.shape[-1]}", (B, H, Sq, k.shape[1], D, v.shape[-1])))
+            return y
+        self.ops.attention_dv = timed_dv
 
         def pooled_or_inner(q, k, v, scale):     # attention_windows calls window_attention itself: meter only the direct (q-pooled) calls
             return self.o_pool(q, k, v, scale) if q.shape[1] == k.shape[1] else timed_pooled(q, k, v, scale)
@@ -222,6 +235,7 @@ class AttnMeter:
     def __exit__(self, *exc):
         self.ops.attention, self.ops.attention_windows = self.o_attn, self.o_win
         self.ops.window_attention = self.o_pool
+        self.ops.attention_dv = self.o_dv
 
     def summary(self):
         torch.cuda.synchronize()
@@ -413,6 +427,79 @@ def cpu_baseline(cfg, args):
                        f"({t_clip:.1f}s), InternVideo2-1B chunk/4 ({t_iv2:.1f}s), 1 of {L} LLM layers on the {S_llm}-row prompt ({t_layer:.2f}s); clip time "
                        f"= {T} x SAM + {args.te} x (CLIP + IV2) + {G + 1} re-forwards x {L} layers (the oracle restates generate(use_cache=False)) "
                        f"= {t_vision:.0f}s vision + {t_llm:.0f}s LLM; vision alone: {T / t_vision:.4f} frames/sec")
+
+
+def attn_roofs(am, traffic_of=lambda key: None, peak=2500.0):
+    """one roofline object per attention kernel class of an AttnMeter pass (QK^T and PV on the MFMA: the north star's "attention-GEMM roofline")."""
+    roofs = {}
+    for dp, (fl, ms, n) in sorted(am.summary().items(), key=lambda kv: str(kv[0])):
+        if ms <= 0:
+            continue
+        ach = fl / (ms * 1e-3) / 1e12
+        if dp == "window":
+            roofs["attn_window"] = {"bound": "hbm", "kernel": "win256_attn_kernel<72> / tiny_win_attn_kernel<72, wq, wk> (Hiera's windows: one workgroup per 256-token window and head, "
+                                                                "one wave per 16- / 64-token window and head; bounded by the fused q|k|v projection's bytes)",
+                                    "achieved_tflops": round(ach, 1), "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+                                    "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2), "traffic": traffic_of("attn_window")}
+            continue
+        label = (f"attn_kernel<bf16, 256, 64, 8, 2, DV = {str(dp).split('_dv')[1]}> (vg_attention_dv: SAM2 memory cross-attention, v-projection behind the attention; "
+                 "flops = 2 Sq Skv (D + DV); + the split-KV merge)") if "_dv" in str(dp) else \
+            f"attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)"
+        roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": label,
+                                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
+                                "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
+                                "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2)}
+    return roofs
+
+
+def video_record(args, model, ops, inputs):
+    """The SAM2 video branch (memory attention + memory encoder + the predictor's recurrence: S4 / S5 / S9 / S10 — the half of the path the
+    framewise default never launches) on the SAME clip, as a sub-record of the framewise line: timed steps bracketed like the headline
+    (inputs resident in HBM -> ids + masks on the host), then one instrumented eager pass for the attention rooflines and the stage split,
+    and the launch count of the propagation read off its captured HIP graph."""
+    images, context, sam, ids = inputs
+
+    def vstep():
+        return model.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)],
+                               max_new_tokens=args.max_new_tokens, use_sam2_video_branch=True)
+    vstep()                     # eager pass + graph capture of the propagation
+    vstep()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.video_steps):
+        out = vstep()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    T = sam.shape[0]
+    rec = {"what": "the same clip through use_sam2_video_branch=True (R/model/VideoGLaMM.py:770-879): timed exactly like the headline, after it",
+           "steps": args.video_steps, "warmup": 2, "ms_per_step": round(1e3 * dt / args.video_steps, 2), "value": round(T * args.video_steps / dt, 3),
+           "unit": "frames/sec", "objects": len(next(iter(out[1][0].values()))) if out[1][0] else 0}
+    nodes = model.sam2.video_graph_nodes()
+    if nodes:
+        k, (kern, cpy, other) = next(iter(nodes.items()))
+        rec["propagation_graph"] = {"frames": k[0], "objects": k[1], "kernel_nodes": kern, "memcpy_nodes": cpy, "other_nodes": other,
+                                    "kernel_launches_per_tracked_frame": round(kern / max(k[0] - 1, 1), 1)}
+    knobs = {"VG_HIERA_START": "serial", "VG_TOWERS_OVERLAP": "0", "VG_VIDEO_GRAPH": "0"}
+    prev = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        vstep()
+        with AttnMeter(ops) as am:
+            vstep()
+        model.stages = []
+        vstep()
+        marks, model.stages = model.stages, None
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for k, v in attn_roofs(am).items():
+        if k in ("attn_d256", "attn_d256_dv64"):
+            rec["roofline_" + ("attn_dv" if "_dv" in k else "attn_d256_self")] = v
+    rec["stages_eager_serial_ms"] = {b[0]: round(1e3 * (b[1] - a[1]), 2) for a, b in zip(marks, marks[1:]) if b[0] not in ("start", "begin")}
+    return rec
 
 
 def main():
@@ -698,20 +785,7 @@ def main():
                                         "avg_launch_us": round(avg, 1), "kernel_ms_per_step": round(per_step, 2),
                                         "note": "timed on eager replays of the decode step; the timed region runs it inside a HIP graph"}
         # attention kernels, one object per head-dim instantiation (the north star's "attention-GEMM roofline": QK^T and PV on the MFMA)
-        for dp, (fl, ms, n) in sorted(am.summary().items(), key=lambda kv: str(kv[0])):
-            if ms <= 0:
-                continue
-            ach = fl / (ms * 1e-3) / 1e12
-            if dp == "window":
-                roofs["attn_window"] = {"bound": "hbm", "kernel": "win256_attn_kernel<72> / tiny_win_attn_kernel<72, wq, wk> (Hiera's windows: one workgroup per 256-token window and head, "
-                                                                    "one wave per 16- / 64-token window and head; bounded by the fused q|k|v projection's bytes)",
-                                        "achieved_tflops": round(ach, 1), "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3),
-                                        "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2), "traffic": traffic_of("attn_window")}
-                continue
-            roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": f"attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)",
-                                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
-                                    "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
-                                    "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2)}
+        roofs.update(attn_roofs(am, traffic_of))
         if os.environ.get("VG_BENCH_ATTN_SHAPES") and rank == 0:      # per-shape table of the attention launches (stderr)
             by = {}
             for fl, e0, e1, dp, shp in am.rec:
@@ -752,6 +826,8 @@ def main():
             res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 + decode_attn_kernel per layer)",
                                       "achieved": round(tbs * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tbs / 8.0, 4),
                                       "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
+    if world == 1 and not use_video and not args.tiny and not args.no_video_record:
+        res["video_branch"] = video_record(args, model, ops, (images, context, sam, ids))
     if world == 1 and not args.no_quality and not args.tiny:
         res["quality"] = quality(cfg, args, model, step, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:      # the CPU leg runs at N = 1 only

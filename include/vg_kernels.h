@@ -47,6 +47,10 @@ int vg_version(void);
 const char* vg_last_error(void);
 /* Binds nothing; checks that `device` is a gfx950 part. Returns CU count (>0) or a negative code. */
 int vg_init(int device);
+/* Node census of a captured HIP graph (hipGraph_t): counts[0] = kernel nodes, counts[1] = memcpy nodes, counts[2] = every other node.
+ * Measurement aid for the graph-replayed loops (the SAM2 propagation the reference runs as Python calls per frame,
+ * R/model/segment_anything_2/sam2/sam2_video_predictor.py:744-827; the decode step): launches per replay, read off the graph itself. */
+int vg_graph_node_counts(void* graph, int64_t* counts);
 
 /* ---- dense contraction (MFMA) ------------------------------------------------------------------
  * C[b] = ((act(A[b] @ W[b]^T + bias)) * gamma) + R[b]      A:[M,K] lda, W:[N,K] ldw, C:[M,N] ldc

@@ -1,0 +1,166 @@
+"""The SAM2 VIDEO branch at full architecture size (-m gpu): S4 / S5 / S9 / S10 of SURVEY.md §8 — memory attention over 4096 queries x
+~28 700 memory keys (attn_kernel<256, ..., DV = 64> with split-KV), the memory encoder on 1024^2 masks, a 7-slot bank of [N,4096,64]
+memories with roll-over, the graph-replayed propagation — which the micro fixtures (256^2 image, 256 tokens per frame) pin in arithmetic but
+not in shape.  (a) fp32-HIP against the CPU oracle (oracle/sam2.py:video_branch, the restatement pinned to the reference's predictor on the
+micro fixtures) on SAM2-L, T = 9, N = 2; (b) the C2 workload with use_sam2_video_branch=True, bf16 against the fp32 parity mode (bench.py's
+`quality` object as a test), graph replay on; (c) C4 as BASELINE.json states it: 64 frames, 8 [SEG] objects AND the fp8 LLM path in one run."""
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+from oracle import sam2 as osam, seeded
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_sam2_large_video_branch_fp32_vs_oracle(cuda):
+    """SAM2-L, T = 9 frames (the 7-slot memory bank rolls over at frame 8: frame 1's memory leaves), N = 2 objects, 1024^2 inputs, masks at
+    480 x 640.  fp32 parity mode of the HIP path (r04's reformulations ON: v-projection behind the attention, fused q|k|v + RoPE, fused
+    memory-encoder stages) vs the oracle: low-res logits within 1e-3 * max(1, |logit|) — the north star's bar —, object pointers, object
+    scores, the bf16-rounded memories of every frame (one bf16 rounding step of slack where the fp32 values straddle a rounding boundary),
+    and the graph-replayed propagation bit-identical to the eager loop."""
+    from videoglamm_amd import synth
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+    cfg = synth.SAM2_L
+    T, N, hw = 9, 2, (480, 640)
+    sd = seeded.seeded_state_dict(synth.sam2_manifest(cfg), 2, seeded.sam2_overrides())
+    sd = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(19)
+    images = torch.randn(T, 3, 1024, 1024, generator=g)
+    text = torch.randn(N, 256, generator=g) * 0.5
+    t0 = time.time()
+    ref_vid, ref = osam.video_branch(sd, "", cfg, images, text, hw)
+    t_oracle = time.time() - t0
+    ref_vid = torch.stack(ref_vid)[:, :, 0]                                                   # [T,N,H,W]
+    m = SAM2(Params(sd, cuda, torch.float32), "", cfg)
+    trace = {}
+    vid = m.video_branch(images.to(cuda), text.to(cuda), hw, trace)
+    low, rlow = trace["low_res"].float().cpu(), ref["low_res"]
+    assert low.shape == rlow.shape == (T, N, 1, 256, 256) and torch.isfinite(low).all()
+    scale = rlow.abs().clamp_min(1.0)
+    err = ((low - rlow).abs() / scale)
+    per_frame = err.flatten(1).max(dim=1).values
+    print(f"SAM2-L video branch T={T} N={N}: oracle {t_oracle:.0f} s on {torch.get_num_threads()} threads; |logit| max {float(rlow.abs().max()):.2f}; "
+          f"fp32 HIP vs oracle max err / max(1,|logit|) per frame {[f'{float(v):.1e}' for v in per_frame]}")
+    scores = torch.stack([trace["frame0_obj_logits"].view(-1)] + [trace[f"obj_logits_{t}"].view(-1) for t in range(1, T)]).float().cpu()
+    rscores = torch.stack([ref["frame0_obj_logits"].view(-1)] + [ref[f"obj_logits_{t}"].view(-1) for t in range(1, T)])
+    assert (rscores > 0).all(), "an absent object fills its mask with NO_OBJ_SCORE: the logit check would be vacuous"
+    torch.testing.assert_close(scores, rscores, rtol=1e-3, atol=1e-3)
+    assert float(err.max()) <= 1e-3, per_frame
+    torch.testing.assert_close(trace["obj_ptr"].float().cpu(), ref["obj_ptr"], rtol=1e-3, atol=1e-3)
+    mr = ref_vid > 0
+    assert 0.01 < float(mr.float().mean()) < 0.99
+    mv = vid.float().cpu() > 0
+    iou = float((mv & mr).sum() / (mv | mr).sum().clamp_min(1))
+    assert iou > 0.999, iou
+    flips = []
+    for t in range(T):
+        got, want = trace["maskmem"][t].float().cpu(), ref["maskmem"][t].flatten(2).permute(0, 2, 1)     # [N, 4096, 64]
+        torch.testing.assert_close(got, want, rtol=1e-2, atol=2e-3)                                      # bf16-stored: one rounding step of slack
+        flips.append(float((got != want).float().mean()))
+    print(f"  bf16-rounded memories: fraction of elements one rounding step apart per frame {[f'{f:.1e}' for f in flips]}")
+    assert max(flips) < 0.02, flips
+    # the product default: the same clip replayed from the captured HIP graph
+    feats = m.hiera_frames(images.to(cuda))
+    assert torch.equal(m.video_branch_graphed(images.to(cuda), text.to(cuda), hw, feats), vid)
+    kern, cpy, other = next(iter(m.video_graph_nodes().values()))
+    print(f"  propagation graph: {kern} kernel nodes, {cpy} memcpy nodes, {other} others for {T - 1} tracked frames")
+    assert kern > 0
+
+
+def _bench_args(argv):
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py"] + argv
+    try:
+        return bench, bench.parse()
+    finally:
+        sys.argv = old
+
+
+def _build(bench, args, cuda, llm_extra=None):
+    from videoglamm_amd import synth
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+    cfg = synth.videoglamm_llama3_8b()
+    if llm_extra:
+        cfg["llm"] = dict(cfg["llm"], **llm_extra)
+    cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
+    sd = synth.device_state_dict(synth.manifest(cfg), cuda, torch.bfloat16)
+    model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=cuda)
+    del sd
+    images, context, sam, ids = bench.make_inputs(cfg, args, 1, cuda)
+
+    def step():
+        return model.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=args.max_new_tokens,
+                               use_sam2_video_branch=args.branch == "video")
+    return cfg, model, step, ids, (images, context, sam)
+
+
+def test_c2_workload_video_branch_bf16_vs_fp32_mode(cuda):
+    """test_c2_workload_bf16_vs_fp32_mode's twin on the video branch: 32 frames x 1024^2, Llama-3-8B + SAM2-L, the propagation replayed from
+    its HIP graph (the product default), bf16 against the same clip in fp32 parity mode (teacher-forced ids).  A recurrence over 31 frames
+    accumulates bf16 noise where the framewise branch cannot, hence the separate bounds."""
+    bench, args = _bench_args(["--branch", "video"])
+    assert os.environ.get("VG_VIDEO_GRAPH", "1") == "1"
+    cfg, model, step, ids, _ = _build(bench, args, cuda)
+    q = bench.quality(cfg, args, model, step, cuda)
+    print("C2 whole workload, video branch:", q)
+    out_ids, segs = step()
+    assert out_ids.shape[1] == ids.shape[1] + args.max_new_tokens and sorted(segs[0]) == list(range(32)) and segs[0][31][0].shape == (1024, 1024)
+    assert q["finite"] and q["seg_objects"] == 1
+    assert q["mask_miou_vs_fp32"] > 0.99 and q["min_frame_iou_vs_fp32"] > 0.97, q
+    assert q["ids_top1_agree"] >= 0.9 and q["seg_emb_cosine"] > 0.999, q
+    assert 0.02 < q["mask_fraction"] < 0.98
+    nodes = model.sam2.video_graph_nodes()
+    assert len(nodes) == 1 and next(iter(nodes))[:2] == (32, 1), nodes          # the replayed graph is what ran
+    # a second clip through the same graph: same ids, same masks (static buffers refreshed, nothing stale)
+    out2, segs2 = step()
+    assert out2[0].tolist() == out_ids[0].tolist() and all((segs2[0][t][0] == segs[0][t][0]).all() for t in (0, 15, 31))
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_c4_64_frames_8_objects_fp8_llm_path(cuda):
+    """BASELINE.json's C4 as stated, on one GPU: 64 frames, 8 [SEG] objects AND the fp8 LLM path (fp8 MFMA prefill + e4m3 decode weights) in
+    one run.  The ids are those of the 16-frame fp8 run (the LLM side never sees the SAM frames); the masks of the first 16 frames equal that
+    run's (frames are independent in the framewise branch); against the bf16 LLM path teacher-forced to the same ids the masks stay close
+    (e4m3's 3 mantissa bits in the [SEG] embedding: test_c4_shape_fp8_llm_path_vs_bf16's bound)."""
+    bench, args = _bench_args(["--frames", "64", "--objects", "8", "--prefill", "fp8", "--decode-weights", "fp8"])
+    cfg, model, step, ids, (images, context, sam) = _build(bench, args, cuda, llm_extra=dict(prefill_gemm="fp8", decode_weights="fp8"))
+
+    def run(mdl, frames):
+        cap = mdl.capture = {}
+        out, segs = mdl.inference([images], [context], [frames], ids, [(1024, 1024)], [(1024, 1024)], max_new_tokens=args.max_new_tokens)
+        mdl.capture = None
+        return out[0].tolist(), cap["logits"] > 0, cap["emb"].float(), segs
+
+    ids64, m64, e64, segs = run(model, sam)
+    gen = ids64[ids.shape[1]:]
+    assert sum(t == cfg["seg_token_idx"] for t in gen) == 8 and m64.shape == (64, 8, 1024, 1024)
+    assert sorted(segs[0]) == list(range(64)) and len(segs[0][63]) == 8
+    frac = m64.float().mean().item()
+    assert 0.02 < frac < 0.98, frac
+    ids16, m16, _, _ = run(model, sam[:16])
+    assert ids16 == ids64
+    inter, union = (m16 & m64[:16]).sum().item(), (m16 | m64[:16]).sum().item()
+    assert inter / max(union, 1) > 0.9995, inter / max(union, 1)
+    del model, m16
+    torch.cuda.empty_cache()
+    args16 = _bench_args(["--frames", "64", "--objects", "8"])[1]
+    cfgb, mb, _, _, _ = _build(bench, args16, cuda)
+    mb.cfg["forced_tokens"] = {i: t for i, t in enumerate(gen)}                 # the bf16 LLM path teacher-forced to the fp8 run's ids
+    idsb, mbf, eb, _ = run(mb, sam)
+    assert idsb == ids64
+    iou = (mbf & m64).sum(dim=(0, 2, 3)).double() / (mbf | m64).sum(dim=(0, 2, 3)).double().clamp_min(1)
+    cos = torch.nn.functional.cosine_similarity(e64, eb).min().item()
+    print(f"C4 (64 frames, 8 objects, fp8 LLM path) vs the bf16 LLM path: mask IoU per object {[round(float(v), 4) for v in iou]}, [SEG] embedding cosine {cos:.4f}")
+    assert cos > 0.99 and iou.mean() > 0.98 and iou.min() > 0.95, (cos, iou.tolist())
+    del mb
+    torch.cuda.empty_cache()

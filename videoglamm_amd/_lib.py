@@ -23,6 +23,7 @@ def _sig(lib):
         "vg_version": ([], c_int),
         "vg_last_error": ([], c_char_p),
         "vg_init": ([I], c_int),
+        "vg_graph_node_counts": ([P, ctypes.POINTER(c_int64)], c_int),
         "vg_gemm": ([P, L, L, P, L, L, P, L, L, P, P, P, L, L, I, I, I, I, I, I, I, I, P], c_int),
         "vg_gemm_splitk": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P, L, P], c_int),
         "vg_quantize_fp8_rows": ([P, L, P, L, P, L, I, I, P], c_int),

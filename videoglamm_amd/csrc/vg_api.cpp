@@ -31,3 +31,32 @@ extern "C" int vg_init(int device) {
   }
   return prop.multiProcessorCount;
 }
+
+extern "C" int vg_graph_node_counts(void* graph, int64_t* counts) {
+  if (!graph || !counts) {
+    vg_set_error("vg_graph_node_counts: null argument");
+    return VG_ERR_ARG;
+  }
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+  if (e != hipSuccess) {
+    vg_set_error("vg_graph_node_counts: hipGraphGetNodes failed: %s", hipGetErrorString(e));
+    return VG_ERR_ARG;
+  }
+  counts[0] = counts[1] = counts[2] = 0;
+  if (n == 0) return VG_OK;
+  hipGraphNode_t* nodes = new hipGraphNode_t[n];
+  e = hipGraphGetNodes((hipGraph_t)graph, nodes, &n);
+  for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+    hipGraphNodeType t;
+    e = hipGraphNodeGetType(nodes[i], &t);
+    if (e != hipSuccess) break;
+    counts[t == hipGraphNodeTypeKernel ? 0 : (t == hipGraphNodeTypeMemcpy ? 1 : 2)] += 1;
+  }
+  delete[] nodes;
+  if (e != hipSuccess) {
+    vg_set_error("vg_graph_node_counts: %s", hipGetErrorString(e));
+    return VG_ERR_ARG;
+  }
+  return VG_OK;
+}

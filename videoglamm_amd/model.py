@@ -392,7 +392,9 @@ class VideoGLaMMForCausalLM:
                 return out_ids, [self._segments(host)]
             logits = out
         elif self._fast_masks():
-            return out_ids, [self._segments(self._to_host(self.sam2.video_branch(sam, emb, hw, frame_feats=feats, as_masks=True)))]
+            host = self._to_host(self.sam2.video_branch(sam, emb, hw, frame_feats=feats, as_masks=True))
+            stage_mark(self.stages, "propagation")
+            return out_ids, [self._segments(host)]
         else:
             logits = self.sam2.video_branch(sam, emb, hw, frame_feats=feats)
         if self.capture is not None:

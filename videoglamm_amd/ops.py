@@ -70,6 +70,15 @@ def graph_capture(g):
                 gc.enable()
 
 
+def graph_node_counts(g):
+    """(kernel nodes, memcpy nodes, other nodes) of a torch.cuda.CUDAGraph created with keep_graph=True: launches per replay, read off the
+    captured hipGraph_t itself (vg_graph_node_counts)."""
+    import ctypes
+    counts = (ctypes.c_int64 * 3)()
+    _lib.check(_lib.load().vg_graph_node_counts(ctypes.c_void_p(int(g.raw_cuda_graph())), counts), "vg_graph_node_counts")
+    return tuple(int(c) for c in counts)
+
+
 def _f32(t):
     if t is None:
         return None

@@ -599,9 +599,10 @@ class SAM2:
                     d.copy_(f)
             st_emb.copy_(text_embeds)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True)      # (the hipGraph_t stays readable: graph_nodes() below)
             with ops.graph_capture(g):      # (thread-local capture mode, cyclic GC held off: ops.graph_capture)
                 out = self.video_branch(images, st_emb, video_hw, frame_feats=st_feats, as_masks=as_masks)
+            g.instantiate()
             ent = (g, st_feats, st_emb, out)
         graphs[key] = ent                       # (re-inserted last: most recently used)
         g, st_feats, st_emb, out = ent
@@ -611,6 +612,10 @@ class SAM2:
         st_emb.copy_(text_embeds)
         g.replay()
         return out.clone()
+
+    def video_graph_nodes(self):
+        """{(T, N, (H, W), as_masks): (kernel, memcpy, other) node counts} of the cached propagation graphs: launches per replayed clip."""
+        return {(k[0], k[1], k[2], k[4]): ops.graph_node_counts(ent[0]) for k, ent in self.__dict__.get("_video_graphs", {}).items()}
 
     def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None, as_masks=False):
         """VideoGLaMM framewise decode — R/model/VideoGLaMM.py:205-241,676-766.  One mask-decoder batch per frame
