@@ -356,6 +356,8 @@ def quality(cfg, args, model, step, device):
     union = (mb | m32b).sum(dim=(0, 2, 3)).double()
     iou = torch.where(union > 0, inter / union.clamp_min(1), torch.ones_like(union))
     q["mask_miou_vs_fp32"] = round(float(iou.mean()), 5)
+    bi, bu = (~mb & ~m32b).sum(dim=(0, 2, 3)).double(), (~mb | ~m32b).sum(dim=(0, 2, 3)).double()
+    q["background_miou_vs_fp32"] = round(float(torch.where(bu > 0, bi / bu.clamp_min(1), torch.ones_like(bu)).mean()), 5)      # the complement's IoU: the sensitive one when most pixels are on
     per_frame = (mb & m32b).sum(dim=(2, 3)).double() / (mb | m32b).sum(dim=(2, 3)).double().clamp_min(1)
     q["min_frame_iou_vs_fp32"] = round(float(per_frame.min()), 5)
     q["mask_fraction_fp32"] = round(float(m32b.float().mean()), 4)

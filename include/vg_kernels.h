@@ -71,6 +71,22 @@ int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, int64_t ldw, 
  * HF LlamaMLP act(gate_proj(x)) * up_proj(x) with the SwiGLU done in the epilogue (gate / up / act rounded to the
  * output dtype like the separate modules do).  M > 16 additionally needs 16-byte aligned C rows, no R / gamma / act. */
 
+/* Short-row contraction with a row-wise producer and a column-pair consumer in the same launch (bf16, K in {64, 128, 192, 256}, N % 64 == 0):
+ *   C = act(pro(A) @ W^T + bias) [axial RoPE] [+ R]
+ *   pro: LayerNorm over the K columns (ln_w / ln_b / ln_eps; statistics in fp32, result rounded to bf16 — vg_layernorm followed by vg_gemm), or
+ *        A + A2 with A2 [a2_rows, K] repeated over blocks of a2_rows rows (rounded to bf16 — vg_axpby followed by vg_gemm), or nothing (NULLs);
+ *   RoPE (rope_cos != NULL): vg_rope_axial_heads on the bf16-rounded product's first rope_cols columns (heads of rope_ch channels), rows
+ *        [rope_r0, rope_r1) of every block of rows_per_block rows, token = (row - rope_r0) % rope_grid; no activation / residual with it.
+ *   a_block_stride != 0: A is a strided [B, rows_per_block, K] view — row m at (m / rows_per_block) * a_block_stride + (m % rows_per_block) * lda.
+ * Replaces, per launch, the module sequences norm1 -> self_attn.{q,k,v}_proj -> apply_rotary_enc, norm2 -> cross_attn_image.q_proj -> rotary,
+ * (memory + memory_pos) -> cross_attn_image.k_proj -> rotary with num_k_exclude_rope, norm3 -> linear1 -> ReLU of
+ * R/model/segment_anything_2/sam2/modeling/memory_attention.py:60-99 + sam/transformer.py:289-327, and norm -> pwconv1 -> GELU of
+ * memory_encoder.py:96-118.  The fp32 parity mode runs the separate entry points. */
+int vg_gemm_rows(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* R, int64_t ldr,
+                 int64_t M, int N, int K, int act, const float* ln_w, const float* ln_b, float ln_eps, const void* A2, int64_t lda2,
+                 int a2_rows, const float* rope_cos, const float* rope_sin, int rope_cols, int rope_ch, int rows_per_block, int64_t a_block_stride,
+                 int rope_r0, int rope_r1, int rope_grid, int dtype, vg_stream_t stream);
+
 /* The same contraction with Hiera's window_partition / window_unpartition (backbones/utils.py:16-38,41-60, called from
  * hieradet.py:128-136,147-148) folded into it.  GEMM row m is the WINDOW-order row index (window (b,wy,wx), token (r,c)),
  * M = B*ceil(H/ws)*ceil(W/ws)*ws*ws including the zero padding rows the reference pads with.
@@ -228,10 +244,11 @@ int vg_activation(const void* x, void* y, int64_t n, int act, int in_dtype, int 
 int vg_swiglu(const void* gu, void* y, int64_t M, int F, int dtype, vg_stream_t stream);
 /* out = in converted */
 int vg_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, vg_stream_t stream);
-/* out[n,i] = cond[n] > 0 ? a[n,i] : (b ? b[i % b_period] : fill)   (fp32 cond)
+/* out[n,i] = cond[n] > 0 ? a[n,i] : (b ? b[i % b_period] : fill)   (fp32 cond); ld_out: elements between consecutive rows of out (0 = inner:
+ * contiguous) — the object pointers go straight into their rows of the memory bank.
  * R/model/segment_anything_2/sam2/modeling/sam2_base.py:355-364,390-401 */
 int vg_where_rows(const float* cond, const void* a, const void* b, void* out, int64_t rows,
-                  int64_t inner, int64_t b_period, float fill, int dtype, vg_stream_t stream);
+                  int64_t inner, int64_t b_period, float fill, int64_t ld_out, int dtype, vg_stream_t stream);
 /* mask fed to the memory encoder: out = (binarize ? (x>0) : sigmoid(x)) * scale + bias
  * R/model/segment_anything_2/sam2/modeling/sam2_base.py:684-693 */
 int vg_mask_for_mem(const float* x, void* out, int64_t n, int binarize, float scale, float bias,

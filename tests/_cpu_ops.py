@@ -44,6 +44,30 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     return y
 
 
+def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None):
+    """vg_gemm_rows as the separate statements it fuses (intermediates rounded to the storage dtype like the separate launches)."""
+    K, N = x.shape[-1], w.shape[0]
+    M = x.numel() // K
+    h = x
+    if ln is not None:
+        h = layernorm(x, ln[0], ln[1], ln[2])
+    elif add is not None:
+        h = (x.reshape(-1, add.shape[0], K).float() + add.float()).to(x.dtype).reshape(x.shape)
+    y = linear(h, w, bias, act, None, residual)
+    if rope is not None:
+        cos, sin, cols, ch, rpb, r0, r1, grid = rope
+        heads, B = cols // ch, M // rpb
+        yv = y.reshape(B, rpb, N).clone()
+        part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).contiguous()
+        rope_axial_(part, cos, sin, r1 - r0, grid)
+        yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
+        y = yv.reshape(*x.shape[:-1], N)
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out
+    return y
+
+
 def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, residual=None):
     if scatter:
         y = linear(x, w, bias, act, gamma)
@@ -152,14 +176,18 @@ def cast(x, dtype):
     return x.to(dtype)
 
 
-def where_rows(cond, a, b=None, fill=0.0):
+def where_rows(cond, a, b=None, fill=0.0, out=None):
     rows = cond.numel()
     a2 = a.reshape(rows, -1)
     if b is not None:
         other = b.reshape(-1).repeat(a2.shape[1] // b.numel()).to(a.dtype)[None, :].expand_as(a2)
     else:
         other = torch.full_like(a2, fill)
-    return torch.where(cond.reshape(rows, 1) > 0, a2, other).reshape(a.shape)
+    y = torch.where(cond.reshape(rows, 1) > 0, a2, other).reshape(a.shape)
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out
+    return y
 
 
 def mask_for_mem(x, binarize, scale, bias, out_dtype):

@@ -133,6 +133,7 @@ def _worker_rccl(port, q):
         got_ids, got_seg = run(full, ids_in, branch)
         res[tag + "_ids"] = got_ids == ref_ids
         res[tag + "_bitexact"] = bool(np.array_equal(_stack(got_seg), _stack(ref_seg)))
+        res[tag + "_pixel_agreement"] = float((_stack(got_seg) == _stack(ref_seg)).mean())
         res[tag + "_collectives"] = comm.collective_report()
     # the LLM-side sharding's collectives are only entered at world > 1: call their device-buffer branches directly
     send = torch.randn(5, 3, device=dev)
@@ -162,7 +163,10 @@ def test_rccl_device_buffer_branches_single_rank(cuda):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert r["backend"] == "nccl"
-    assert r["fw_ids"] and r["fw_bitexact"] and r["vid_ids"] and r["vid_bitexact"] and r["vid_unstreamed_bitexact"], r
+    # the streamed exchange runs Hiera in chunks of ceil(frames / stream_steps) frames, the single-process run in one batch: other GEMM tile routes,
+    # another fp32 summation order (tests/test_fullsize_gpu.py::test_sam2_large_batched_equals_serial_fp32) — masks agree to a handful of pixels;
+    # the single exchange after the last frame keeps the batch composition and is bit-exact
+    assert r["fw_ids"] and r["fw_bitexact"] and r["vid_ids"] and r["vid_pixel_agreement"] > 0.9999 and r["vid_unstreamed_bitexact"], r
     fw, vid, un = r["fw_collectives"], r["vid_collectives"], r["vid_unstreamed_collectives"]
     assert not any("gloo" in k for k in list(fw) + list(vid) + list(un)), (fw, vid, un)          # the device-buffer branch ran
     assert {"seg_all_gather", "mask_gather"} <= set(fw) and fw["seg_all_gather"]["bytes_received_per_rank"] == 6 * 256 * 4, fw

@@ -153,12 +153,13 @@ def test_host_graph_fused_two_way_cpu(cpu_ops, monkeypatch):
 
 
 def test_video_reference_order_of_operations_cpu(cpu_ops, monkeypatch):
-    """r04's reformulations of the video branch are algebra, not approximation: with every one of them switched OFF (v-projection applied to
-    the memory rows in front of the attention, the mask downsampler as im2col + GEMM + LayerNorm + GELU launches, separate q / k / v projections) the
+    """r04's / r05's reformulations of the video branch are algebra, not approximation: with every one of them switched OFF (v-projection applied to
+    the memory rows in front of the attention, the mask downsampler as im2col + GEMM + LayerNorm + GELU launches, separate q / k / v projections,
+    memories and pointers concatenated per frame in the reference's key order instead of living in the bank, separate W_v and W_out) the
     host graph is the reference's own order of operations — and the no-object clip (T = 9, N = 2, the reference's outputs) must come out the same,
     within the same 1e-3, as with them switched ON (the default, exercised by test_video_noobj_cpu / test_video_long_cpu)."""
     from videoglamm_amd import sam2
-    for name in ("_MEMATTN_LOWRANK", "_MEMENC_FUSED", "_SELFATTN_FUSED"):
+    for name in ("_MEMATTN_LOWRANK", "_MEMENC_FUSED", "_SELFATTN_FUSED", "_MEMBANK"):
         assert getattr(sam2, name) is True
         monkeypatch.setattr(sam2, name, False)
     run_noobj(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))

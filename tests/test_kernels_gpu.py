@@ -218,6 +218,76 @@ def test_gemm_small64_routing_and_batch(cuda):
     close(ops.bmm_nt(a.to(cuda), w.to(cuda)), ref.bmm_nt(a, w), **tol(torch.bfloat16, 128))
 
 
+ROWS = [  # (B, rows, N, K, prologue, rope (cols, ch, r0, r1, grid) | None, act, residual)
+    (2, 4096, 768, 256, "ln", (512, 256, 0, 4096, 4096), 0, False),     # norm1 -> q|k|v -> RoPE(q | k): memory self-attention
+    (2, 4096, 256, 256, "ln", (256, 256, 0, 4096, 4096), 0, False),     # norm2 -> q -> RoPE
+    (2, 3 * 1024 + 16, 1024, 64, "add", (1024, 256, 16, 3 * 1024 + 16, 1024), 0, False),   # (memory + pos) -> four layers' k -> RoPE, pointer rows first
+    (1, 4096, 2048, 256, "ln", None, 3, False),                         # norm3 -> linear1 -> ReLU
+    (1, 4096, 1024, 256, "ln", None, 1, False),                         # fuser: norm -> pwconv1 -> GELU
+    (3, 100, 256, 64, None, None, 0, True),                             # plain + residual, ragged rows (300 = 4 tiles + 44)
+    (1, 77, 64, 128, "ln", (64, 64, 5, 70, 13), 0, False),              # odd geometry: one N tile, K = 128, a token grid that wraps
+    (2, 130, 128, 192, "add", None, 0, True),                           # K = 192, A + A2 and a residual
+]
+
+
+@pytest.mark.parametrize("case", ROWS)
+def test_gemm_rows(cuda, case):
+    """vg_gemm_rows (bf16): LayerNorm / A + A2 in front of, axial RoPE behind a short-row GEMM, in one launch — against the fp32 statement of the
+    separate modules AND against the separate HIP launches it replaces (vg_layernorm / vg_axpby -> vg_gemm -> vg_rope_axial_heads), which it
+    follows rounding for rounding: at most a few bf16 steps apart where the fp32 summation order differs."""
+    from videoglamm_amd import ops
+    B, rows, N, K, pro, rope, act, res = case
+    dt = torch.bfloat16
+    x = rnd(B, rows, K, dtype=dt, seed=1)
+    w, bias = rnd(N, K, dtype=dt, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ln = (1.0 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5), 1e-5) if pro == "ln" else None
+    add = rnd(rows, K, dtype=dt, seed=6) if pro == "add" else None
+    r = rnd(B, rows, N, dtype=dt, seed=7) if res else None
+    rp = None
+    if rope is not None:
+        cols, ch, r0, r1, grid = rope
+        ang = rnd(grid, ch // 2, seed=8, scale=3.0)
+        rp = (ang.cos(), ang.sin(), cols, ch, rows, r0, r1, grid)
+    dev = lambda t: None if t is None else t.to(cuda)      # noqa: E731
+    tup = lambda t: None if t is None else tuple(dev(v) if torch.is_tensor(v) else v for v in t)      # noqa: E731
+    y = ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp))
+    want = ref.linear_rows(x, w, bias, act, r, ln=ln, add=add, rope=rp)
+    close(y, want, **tol(dt, K))
+    # the launches it replaces
+    h = dev(x)
+    if ln is not None:
+        h = ops.layernorm(h, dev(ln[0]), dev(ln[1]), ln[2])
+    elif add is not None:
+        h = ops.axpby(h, dev(add), 1.0, 1.0)
+    sep = ops.linear(h, dev(w), dev(bias), act, None, dev(r))
+    if rp is not None:
+        cols, ch, r0, r1, grid = rope
+        v = sep[:, r0:, :]                      # rope_axial_heads_ ropes the first n_rope rows of a (strided) view
+        ops.rope_axial_heads_(v, cols // ch, dev(rp[0]), dev(rp[1]), r1 - r0, grid)
+    d = (y.float() - sep.float()).abs()
+    step = sep.float().abs().clamp_min(1e-2) * 2.0 ** -7      # two bf16 rounding steps
+    assert float((d > step).float().mean()) < 1e-3, (float(d.max()), float((d > step).float().mean()))
+    # a strided [B, rows, K] view (the memory bank's valid rows inside a larger buffer) is addressed in place
+    big = torch.zeros(B, rows + 40, K, dtype=dt, device=cuda)
+    big[:, 24:24 + rows] = dev(x)
+    y2 = ops.linear_rows(big[:, 24:24 + rows], dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp))
+    assert torch.equal(y2, y)
+    out = torch.full((B, rows, N + 64), 7.0, dtype=dt, device=cuda)
+    ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out[..., 64:])
+    assert torch.equal(out[..., 64:], y) and float((out[..., :64] - 7.0).abs().max()) == 0.0
+
+
+def test_gemm_rows_fp32_composition(cuda):
+    """fp32 parity mode: linear_rows runs the separate entry points (no fused fp32 kernel) — same statement, fp32 tolerance."""
+    from videoglamm_amd import ops
+    x, w, bias = rnd(2, 100, 64, seed=1), rnd(128, 64, seed=2, scale=0.125), rnd(128, seed=3)
+    ang = rnd(16, 32, seed=8, scale=3.0)
+    rp = (ang.cos(), ang.sin(), 128, 64, 100, 4, 100, 16)
+    add = rnd(100, 64, seed=6)
+    y = ops.linear_rows(x.to(cuda), w.to(cuda), bias.to(cuda), add=add.to(cuda), rope=tuple(v.to(cuda) if torch.is_tensor(v) else v for v in rp))
+    close(y, ref.linear_rows(x, w, bias, add=add, rope=rp), **tol(torch.float32, 64))
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops
@@ -401,6 +471,11 @@ def test_pointwise(cuda, dtype):
     cond = torch.tensor([1.0, -1.0, 0.0, 2.0, -3.0, 5.0])
     close(ops.where_rows(cond.to(cuda), a.to(cuda), None, -1024.0), ref.where_rows(cond, a, None, -1024.0), rtol=0, atol=0)
     close(ops.where_rows(cond.to(cuda), a.to(cuda), b[0].to(cuda)), ref.where_rows(cond, a, b[0]), rtol=0, atol=0)
+    bank = torch.full((6, 5, 50, 32), 3.0, dtype=dtype, device=cuda)
+    dst = bank[:, 2]                                       # one strided row block per cond entry (the object pointers' rows of the memory bank)
+    ops.where_rows(cond.to(cuda), a.to(cuda), b[0].to(cuda), out=dst)
+    close(dst, ref.where_rows(cond, a, b[0]), rtol=0, atol=0)
+    assert float((bank[:, :2] - 3.0).abs().max()) == 0.0 and float((bank[:, 3:] - 3.0).abs().max()) == 0.0
     x = rnd(3, 40, 40, seed=5) * 4
     for binz in (0, 1):
         close(ops.mask_for_mem(x.to(cuda), binz, 20.0, -10.0, dtype), ref.mask_for_mem(x, binz, 20.0, -10.0, dtype), **tol(dtype))

@@ -29,6 +29,7 @@ def _sig(lib):
         "vg_quantize_fp8_rows": ([P, L, P, L, P, L, I, I, P], c_int),
         "vg_gemm_f8": ([P, L, P, P, L, P, P, L, P, P, L, L, L, L, I, I, P], c_int),
         "vg_gemm_route": ([L, L, L, I, I, I], c_int),
+        "vg_gemm_rows": ([P, L, P, L, P, L, P, P, L, L, I, I, I, P, P, F, P, L, I, P, P, I, I, I, L, I, I, I, I, P], c_int),
         "vg_gemm_window": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),
         "vg_attention_splitkv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P, L, I, P, P], c_int),
@@ -52,7 +53,7 @@ def _sig(lib):
         "vg_activation": ([P, P, L, I, I, I, P], c_int),
         "vg_swiglu": ([P, P, L, I, I, P], c_int),
         "vg_cast": ([P, P, L, I, I, P], c_int),
-        "vg_where_rows": ([P, P, P, P, L, L, L, F, I, P], c_int),
+        "vg_where_rows": ([P, P, P, P, L, L, L, F, L, I, P], c_int),
         "vg_mask_for_mem": ([P, P, L, I, F, F, I, P], c_int),
         "vg_threshold": ([P, P, L, P], c_int),
         "vg_rope_half": ([P, L, L, P, P, I, I, I, I, I, P], c_int),

@@ -103,21 +103,21 @@ extern "C" int vg_cast(const void* in, void* out, int64_t n, int in_dtype, int o
 }
 
 __global__ __launch_bounds__(256) void where_rows_kernel(const float* cond, const void* a, const void* b, void* out,
-                                                         int64_t rows, int64_t inner, int64_t bp, float fill, int dt) {
+                                                         int64_t rows, int64_t inner, int64_t bp, float fill, int dt, int64_t ld_out) {
   const int64_t n = rows * inner;
   PW_LOOP(i, n) {
     const int64_t r = i / inner, c = i - r * inner;
     float v;
     if (cond[r] > 0.f) v = ld_any(a, i, dt);
     else v = b ? ld_any(b, c % bp, dt) : fill;
-    st_any(out, i, dt, v);
+    st_any(out, r * ld_out + c, dt, v);
   }
 }
 extern "C" int vg_where_rows(const float* cond, const void* a, const void* b, void* out, int64_t rows, int64_t inner,
-                             int64_t b_period, float fill, int dtype, vg_stream_t stream) {
-  VG_CHECK(cond && a && out && rows >= 0 && inner > 0, VG_ERR_ARG, "vg_where_rows: bad args");
+                             int64_t b_period, float fill, int64_t ld_out, int dtype, vg_stream_t stream) {
+  VG_CHECK(cond && a && out && rows >= 0 && inner > 0 && (ld_out == 0 || ld_out >= inner), VG_ERR_ARG, "vg_where_rows: bad args");
   if (rows == 0) return VG_OK;
-  where_rows_kernel<<<pw_grid(rows * inner), 256, 0, (hipStream_t)stream>>>(cond, a, b, out, rows, inner, b ? b_period : 1, fill, dtype);
+  where_rows_kernel<<<pw_grid(rows * inner), 256, 0, (hipStream_t)stream>>>(cond, a, b, out, rows, inner, b ? b_period : 1, fill, dtype, ld_out ? ld_out : inner);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -164,6 +164,15 @@ def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=
             for a, b_ in ((0, M0), (M0, M)):
                 _linear(x2[a:b_], w, bias, act, gamma, None if r2 is None else r2[a:b_], out_dtype, y2[a:b_], glu)
             return y
+    if (out is not None and out.dim() == 3 and not out.is_contiguous() and out.stride(2) == 1 and x.dim() == 3 and x.is_contiguous()
+            and residual is None and not glu and out.shape[:2] == x.shape[:2]):
+        # [B, rows, N] rows of a larger buffer (the memory bank's slot of each object): one batched launch, batch stride = out.stride(0)
+        B, Mb = x.shape[0], x.shape[1]
+        assert out.dtype == odt and out.shape[2] == N and _dt(w) == _dt(x)
+        rc = lib.vg_gemm(_p(x), K, Mb * K, _p(w), w.stride(0), 0, _p(out), out.stride(1), out.stride(0), _p(_f32(bias)), _p(_f32(gamma)),
+                         None, 0, 0, Mb, N, K, B, _dt(x), _dt(out), act, 0, _stream())
+        _lib.check(rc, "vg_gemm(batched rows)")
+        return out
     ks = _splitk(M, N, K, x2.element_size()) if (not glu and (out is None or (out.is_contiguous() and out.dtype == odt))) else 0
     if ks:
         return _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, out)
@@ -180,6 +189,74 @@ def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=
     rc = lib.vg_gemm(_p(x2), lda, 0, _p(w), w.stride(0), 0, _p(o2), ldc, 0, _p(_f32(bias)), _p(_f32(gamma)),
                      _p(r2), ldr, 0, M, N, K, 1, _dt(x2), _dt(out), act, int(bool(glu)), _stream())
     _lib.check(rc, "vg_gemm")
+    return out
+
+
+def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None):
+    """y = act(pro(x) @ w^T + bias) [RoPE] [+ residual] on short rows, ONE launch in bf16 (vg_gemm_rows) — the fp32 parity mode (and any shape the
+    kernel does not take) runs the same arithmetic as the separate launches.
+    ln = (weight, bias, eps): LayerNorm over the last dim first;  add = a2 [rows2, K]: x + a2, a2 repeated over blocks of rows2 rows;
+    rope = (cos, sin, cols, ch, rows_per_block, r0, r1, grid): axial RoPE (rope_axial_heads_) on the first `cols` output columns, heads of `ch`
+    channels, rows [r0, r1) of every block of rows_per_block rows, token = (row - r0) % grid.  out: optional [.., N] destination (row stride free)."""
+    lib = _lib.load()
+    N, K = w.shape
+    sA = 0
+    if x.dim() == 3 and x.stride(2) == 1 and not x.is_contiguous() and x.dtype == torch.bfloat16:
+        # a strided [B, rows, K] view (the memory bank's valid rows): addressed in place by block stride
+        x2, M, lda, sA = x, x.shape[0] * x.shape[1], x.stride(1), x.stride(0)
+        assert rope is None or rope[4] == x.shape[1]
+    else:
+        x2, M, lda = _rows2d(x)
+    assert x2.shape[-1] == K and w.stride(1) == 1 and not (ln is not None and add is not None)
+    fused = x2.dtype == torch.bfloat16 and K in (64, 128, 192, 256) and N % 64 == 0 and (rope is None or (act == ACT_NONE and residual is None)) \
+        and (act == ACT_NONE or residual is None)
+    if not fused:
+        h = x
+        if ln is not None:
+            h = layernorm(x, ln[0], ln[1], ln[2])
+        elif add is not None:
+            h = axpby(x.reshape(-1, add.shape[0], K), add, 1.0, 1.0).view(x.shape)
+        y = _linear(h, w, bias, act, None, residual, None, out if rope is None else None)
+        if rope is not None:
+            cos, sin, cols, ch, rpb, r0, r1, grid = rope
+            heads, B = cols // ch, M // rpb
+            yv = y.view(B, rpb, N)
+            # (parity mode only: the strided head slices go through a contiguous copy — torch plumbing around vg_rope_axial)
+            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).contiguous().view(B * heads, r1 - r0, ch)
+            rope_axial_(part, cos, sin, r1 - r0, grid)
+            yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
+            if out is not None:
+                out.copy_(y.view(out.shape))
+                y = out
+        return y
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    o2, Mo, ldc = _rows2d(out)
+    assert Mo == M and out.dtype == x.dtype and out.shape[-1] == N
+    r2, ldr = None, 0
+    if residual is not None:
+        r2, Mr, ldr = _rows2d(residual)
+        assert Mr == M and r2.shape[1] == N and residual.dtype == x.dtype
+    lw = lb = a2 = None
+    eps, lda2, rows2 = 0.0, 0, 0
+    if ln is not None:
+        lw, lb, eps = _f32(ln[0]), _f32(ln[1]), float(ln[2])
+        assert lw.numel() == K and lb.numel() == K
+    if add is not None:
+        a2 = add
+        assert a2.dim() == 2 and a2.shape[1] == K and a2.stride(1) == 1 and a2.dtype == x.dtype and M % a2.shape[0] == 0
+        lda2, rows2 = a2.stride(0), a2.shape[0]
+    cs = sn = None
+    cols = ch = rpb = r0 = r1 = grid = 0
+    if rope is not None:
+        cs, sn, cols, ch, rpb, r0, r1, grid = rope
+        cs, sn = _f32(cs), _f32(sn)
+        assert M % rpb == 0 and cs.shape[1] * 2 == ch and cs.shape[0] >= grid and cs.is_contiguous() and sn.is_contiguous()
+    if sA:
+        rpb = x.shape[1]
+    rc = lib.vg_gemm_rows(_p(x2), lda, _p(w), w.stride(0), _p(o2), ldc, _p(_f32(bias)), _p(r2), ldr, M, N, K, act, _p(lw), _p(lb), eps,
+                          _p(a2), lda2, rows2, _p(cs), _p(sn), int(cols), int(ch), int(rpb), int(sA), int(r0), int(r1), int(grid), BF16, _stream())
+    _lib.check(rc, "vg_gemm_rows")
     return out
 
 
@@ -630,20 +707,26 @@ def cast(x, dtype):
     return out
 
 
-def where_rows(cond, a, b=None, fill=0.0):
-    """out[n,...] = cond[n] > 0 ? a[n,...] : (b broadcast | fill); cond fp32 [rows]."""
+def where_rows(cond, a, b=None, fill=0.0, out=None):
+    """out[n,...] = cond[n] > 0 ? a[n,...] : (b broadcast | fill); cond fp32 [rows].  out: optional destination whose rows (one per cond entry,
+    each `inner` contiguous elements) may be strided — a [rows, ...] view into a larger buffer."""
     lib = _lib.load()
     a = a.contiguous()
     cond = cond.contiguous().view(-1)
     rows = cond.numel()
     inner = a.numel() // rows
-    out = torch.empty_like(a)
+    ld_out = 0
+    if out is None:
+        out = torch.empty_like(a)
+    else:
+        assert out.dtype == a.dtype and out.shape[0] == rows and out.numel() == a.numel() and out[0].is_contiguous()
+        ld_out = out.stride(0) if rows > 1 else inner
     bp = 1
     if b is not None:
         b = b.contiguous()
         assert b.dtype == a.dtype
         bp = b.numel()
-    rc = lib.vg_where_rows(_p(_f32(cond)), _p(a), _p(b), _p(out), rows, inner, bp, float(fill), _dt(a), _stream())
+    rc = lib.vg_where_rows(_p(_f32(cond)), _p(a), _p(b), _p(out), rows, inner, bp, float(fill), ld_out, _dt(a), _stream())
     _lib.check(rc, "vg_where_rows")
     return out
 

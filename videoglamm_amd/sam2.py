@@ -17,6 +17,10 @@ NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
 _SELFATTN_FUSED = os.environ.get("VG_SELFATTN_FUSED", "1") == "1"     # memory self-attention: fused q|k|v projection + one RoPE launch (A/B knob)
 _MEMENC_FUSED = os.environ.get("VG_MEMENC_FUSED", "1") == "1"         # memory encoder: fused conv + LayerNorm2d + GELU stages (A/B knob)
 _MEMATTN_LOWRANK = os.environ.get("VG_MEMATTN_LOWRANK", "1") == "1"   # memory cross-attention: v-projection behind the attention (A/B knob)
+_MEMBANK = True      # r05: the propagation's memories and object pointers live in ONE preallocated bank per clip (no per-frame cat / copies) and the
+#                      memory attention runs on the fused short-row GEMMs (vg_gemm_rows); False = r04's per-frame assembly (tests switch it off together
+#                      with the flags above to run the reference's own order of operations)
+PTR_ROWS = 64        # 16 object pointers x 4 tokens of 64 channels (max_obj_ptrs_in_encoder, sam2_base.py:590-626)
 
 
 def _stack_views(ts):
@@ -445,10 +449,58 @@ class SAM2:
             out = self.lin(l + "linear2", self.lin(l + "linear1", t2, act=ops.ACT_RELU), residual=out)
         return self.ln(m + "norm", out)
 
+    def _merged_vo(self, name):
+        """(W_out W_v [256, 64], W_out b_v + b_out): the value and output projections of the low-rank memory cross-attention as ONE matrix —
+        ((P M) Wv^T + bv) Wo^T + bo = (P M) (Wo Wv)^T + (Wo bv + bo), exact in real arithmetic (product formed in fp32, rounded once)."""
+        def make():
+            wv, wo = self.P.sd[self.p + name + ".v_proj.weight"].float(), self.P.sd[self.p + name + ".out_proj.weight"].float()
+            return wo @ wv
+        def make_b():
+            wo = self.P.sd[self.p + name + ".out_proj.weight"].float()
+            return wo @ self.P.sd[self.p + name + ".v_proj.bias"].float() + self.P.sd[self.p + name + ".out_proj.bias"].float()
+        return self.P.const(("merged_vo", name), make), self.P.const(("merged_vo_b", name), make_b, torch.float32)
+
+    def memory_attention_bank(self, curr, bank, lo, hi, pos, nptr):
+        """MemoryAttention.forward (R/modeling/memory_attention.py:119-169,60-99) on the clip's memory bank (r05).
+        curr [N,HW,256]; bank [N,R,64]: rows [lo, hi) are this frame's memory — first nptr object-pointer tokens (no RoPE, no positional term:
+        num_k_exclude_rope), then whole 4096-token memories; pos [R,64]: the positional table aligned with the bank's rows (maskmem_pos +
+        maskmem_tpos_enc by age, zeros on the pointer rows).  Per layer: norm -> q|k|v -> RoPE as one launch, attention, out_proj + residual,
+        norm -> q -> RoPE as one launch, cross-attention on the un-projected memory (vg_attention_dv), W_out W_v + residual as one GEMM,
+        norm -> linear1 -> ReLU as one launch, linear2 + residual; the four layers' key projections of (memory + pos) + their RoPE are ONE
+        launch per frame.  bf16: vg_gemm_rows; the fp32 parity mode runs the same statements on the separate kernels (ops.linear_rows)."""
+        m = "memory_attention."
+        N, nq, C = curr.shape
+        Mv = hi - lo
+        side = int(math.sqrt(nq))
+        cos = self.P.const(("axial_cos", C, nq), lambda: _axial_cos_sin(C, side)[0], torch.float32)
+        sin = self.P.const(("axial_sin", C, nq), lambda: _axial_cos_sin(C, side)[1], torch.float32)
+        lnp = lambda n: (self.P.f32(self.p + n + ".weight"), self.P.f32(self.p + n + ".bias"), 1e-5)      # noqa: E731
+        out = ops.axpby(curr, self.vision_pos(), 1.0, 0.1)
+        mem = bank[:, lo:hi]
+        wk4, bk4 = self.P.fused([f"{self.p}{m}layers.{i}.cross_attn_image.k_proj" for i in range(4)])
+        k4 = ops.linear_rows(mem, wk4, bk4, add=pos[lo:hi], rope=(cos, sin, 4 * C, C, Mv, nptr, Mv, nq))          # [N, Mv, 4 C]
+        for i in range(4):
+            l = f"{m}layers.{i}."
+            sa = self.p + l + "self_attn"
+            wqkv, bqkv = self.P.fused([sa + ".q_proj", sa + ".k_proj", sa + ".v_proj"])
+            qkv = ops.linear_rows(out, wqkv, bqkv, ln=lnp(l + "norm1"), rope=(cos, sin, 2 * C, C, nq, 0, nq, nq))
+            o = ops.attention(qkv[..., :C].unsqueeze(2), qkv[..., C:2 * C].unsqueeze(2), qkv[..., 2 * C:].unsqueeze(2), C ** -0.5)
+            out = self.lin(l + "self_attn.out_proj", o.view(N, nq, C), residual=out)
+            ca = l + "cross_attn_image"
+            q = ops.linear_rows(out, self.P.w(self.p + ca + ".q_proj"), self.P.b(self.p + ca + ".q_proj"), ln=lnp(l + "norm2"),
+                                rope=(cos, sin, C, C, nq, 0, nq, nq))
+            pm = ops.attention_dv(q.view(N, nq, 1, C), k4[..., i * C:(i + 1) * C].unsqueeze(2), mem.unsqueeze(2), C ** -0.5)
+            wvo, bvo = self._merged_vo(ca)
+            out = ops.linear(pm.view(N, nq, mem.shape[-1]), wvo, bvo, residual=out)
+            h = ops.linear_rows(out, self.P.w(self.p + l + "linear1"), self.P.b(self.p + l + "linear1"), act=ops.ACT_RELU, ln=lnp(l + "norm3"))
+            out = self.lin(l + "linear2", h, residual=out)
+        return self.ln(m + "norm", out)
+
     # ------------------------------------------------------------------ S9 memory encoder
-    def memory_encoder(self, pix_feat, mask):
+    def memory_encoder(self, pix_feat, mask, out=None):
         """MemoryEncoder.forward(skip_mask_sigmoid=True) — R/modeling/memory_encoder.py:159-182,17-118.
-        pix_feat [N,es,es,256]; mask [N,S,S,1] (already scaled) -> features [N,es*es,64]."""
+        pix_feat [N,es,es,256]; mask [N,S,S,1] (already scaled) -> features [N,es*es,64] (written into `out`, a [N,es*es,64] view whose
+        object stride is free — the memory bank's slot — when given)."""
         e = "memory_encoder."
         N = pix_feat.shape[0]
         x, H = mask, self.S
@@ -468,18 +520,22 @@ class SAM2:
         for i in range(2):
             l = f"{e}fuser.layers.{i}."
             h = ops.dwconv(x, self.P.dw_w(self.p + l + "dwconv"), self.P.b(self.p + l + "dwconv"), 7)
-            h = self.lin(l + "pwconv1", self.ln(l + "norm", h, 1e-6), act=ops.ACT_GELU)
+            if _MEMBANK:       # norm -> pwconv1 -> GELU in one launch (bf16; the parity mode runs the separate kernels inside linear_rows)
+                h = ops.linear_rows(h, self.P.w(self.p + l + "pwconv1"), self.P.b(self.p + l + "pwconv1"), act=ops.ACT_GELU,
+                                    ln=(self.P.f32(self.p + l + "norm.weight"), self.P.f32(self.p + l + "norm.bias"), 1e-6))
+            else:
+                h = self.lin(l + "pwconv1", self.ln(l + "norm", h, 1e-6), act=ops.ACT_GELU)
             x = ops.linear(h, self.P.w(self.p + l + "pwconv2"), self.P.b(self.p + l + "pwconv2"), gamma=self.P.f32(self.p + l + "weight"), residual=x)
-        return self.lin(e + "out_proj", x).view(N, self.es * self.es, 64)
+        return self.lin(e + "out_proj", x.view(N, self.es * self.es, -1), out=out).view(N, self.es * self.es, 64)
 
     def maskmem_pos(self):
         return self.P.const(("maskmem_pos", self.es), lambda: _sine_pos(64, self.es, self.es))
 
     # ------------------------------------------------------------------ S6 SAM heads
-    def forward_sam_heads(self, pix_feat, high_res, text_inputs, multimask_output=True):
+    def forward_sam_heads(self, pix_feat, high_res, text_inputs, multimask_output=True, ptr_out=None):
         """SAM2Base._forward_sam_heads (points=None, masks=None) — R/modeling/sam2_base.py:251-411.
         pix_feat [N,HW,256]; returns low-res best mask fp32 [N,1,4es,4es] (NO_OBJ-filled), high-res [N,1,S,S],
-        obj_ptr [N,256], object score logits [N,1]."""
+        obj_ptr [N,256], object score logits [N,1].  ptr_out: optional [N, 4, 64] destination of the object pointers (their rows of the memory bank)."""
         N = pix_feat.shape[0]
         sparse = self.sparse_prompt(N, text_inputs, with_empty_point=True)
         masks, iou, toks, obj = self.mask_decoder(pix_feat, sparse, high_res, repeat_image=False)
@@ -487,23 +543,31 @@ class SAM2:
         low = ops.where_rows(obj, low, None, NO_OBJ_SCORE)
         high = ops.bilinear(low.view(N, 4 * self.es, 4 * self.es), self.S, self.S).view(N, 1, self.S, self.S)
         ptr = self.mlp("obj_ptr_proj", tok, 3)
-        ptr = ops.where_rows(obj, ptr, self.P.t(self.p + "no_obj_ptr").view(-1))
+        ptr = ops.where_rows(obj, ptr, self.P.t(self.p + "no_obj_ptr").view(-1), out=ptr_out)
         return dict(low=low, high=high, obj_ptr=ptr, obj_logits=obj, low_multi_pre_where=masks[:, 1:], ious=iou[:, 1:])
 
-    def encode_new_memory(self, feat_top, high_res_masks, is_mask_from_pts):
+    def encode_new_memory(self, feat_top, high_res_masks, is_mask_from_pts, out=None):
         """SAM2Base._encode_new_memory — R/modeling/sam2_base.py:666-704; features come back bf16-rounded the way
-        the predictor stores them (sam2_video_predictor.py:967,1011)."""
+        the predictor stores them (sam2_video_predictor.py:967,1011).  out: optional [N, es*es, 64] destination (a slot of the memory bank)."""
         N = high_res_masks.shape[0]
         m = ops.mask_for_mem(high_res_masks.view(N, self.S, self.S, 1), is_mask_from_pts, 20.0, -10.0, self.dtype)
-        mem = self.memory_encoder(feat_top.view(N, self.es, self.es, 256), m)
-        return ops.cast(ops.cast(mem, torch.bfloat16), self.dtype)
+        if self.dtype == torch.bfloat16:        # the model's activations ARE the predictor's storage format: the last GEMM writes the slot
+            return self.memory_encoder(feat_top.view(N, self.es, self.es, 256), m, out=out)
+        mem = ops.cast(ops.cast(self.memory_encoder(feat_top.view(N, self.es, self.es, 256), m), torch.bfloat16), self.dtype)
+        if out is not None:
+            out.copy_(mem)
+            return out
+        return mem
 
     # ------------------------------------------------------------------ S10 video branch / S11 framewise
-    def video_branch(self, images, text_embeds, video_hw, trace=None, frame_feats=None, as_masks=False):
+    def video_branch(self, images, text_embeds, video_hw, trace=None, frame_feats=None, as_masks=False, mem_override=None):
         """init_state_from_tensor -> add_new_text per object -> propagate_in_video for one clip
         (R/model/VideoGLaMM.py:834-877; R/sam2_video_predictor.py:108-180,415-495,520-636,674-827,921-1017;
         R/modeling/sam2_base.py:495-664,706-803).  images [T,3,S,S]; text_embeds [N,256].
         frame_feats: optional precomputed forward_image outputs per frame (frame-sharded Hiera).
+        mem_override (parity tests): {frame: [N, es*es, 64] memory} stored in the bank INSTEAD of the frame's own encoded memory (which is still
+        computed and traced) — the bank is bf16-rounded like the reference's, so two fp32 implementations that differ in summation order store
+        memories one rounding step apart in a few elements; teacher-forcing the bank separates that from an arithmetic difference.
         -> video-res logits fp32 [T,N,H,W]."""
         T, N = images.shape[0], text_embeds.shape[0]
         es, hw = self.es, self.es * self.es
@@ -511,6 +575,8 @@ class SAM2:
 
         if frame_feats is None:  # Hiera is frame-independent: batch it up front (the recurrence below only reads it)
             frame_feats = self.hiera_frames(images)
+        if _MEMBANK:
+            return self._video_branch_bank(T, text_embeds, video_hw, trace, frame_feats, as_masks, mem_override)
 
         def feats(t, bs):
             fpn = frame_feats[t]
@@ -535,6 +601,8 @@ class SAM2:
         cond = dict(mem=self.encode_new_memory(top0, high0, True), ptr=ptr0)
         if trace is not None:
             trace["maskmem"].append(cond["mem"])
+        if mem_override is not None and 0 in mem_override:
+            cond["mem"] = mem_override[0].to(cond["mem"])
         non_cond = {}
         lows = [low0]
         tpos = self.P.t(self.p + "maskmem_tpos_enc").view(7, 64)
@@ -567,9 +635,99 @@ class SAM2:
                 trace["obj_ptr"].append(o["obj_ptr"])
                 trace["maskmem"].append(non_cond[t]["mem"])
                 trace[f"obj_logits_{t}"] = o["obj_logits"]
+            if mem_override is not None and t in mem_override:
+                non_cond[t]["mem"] = mem_override[t].to(non_cond[t]["mem"])
             if trace is not None and t == 1:
                 trace["frame1_pix_feat_with_mem"] = pix
                 trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
+        low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
+        if trace is not None:
+            trace["low_res"] = low
+            trace["obj_ptr"] = torch.stack(trace["obj_ptr"])       # [T,N,256]; trace["maskmem"][t]: [N, es*es, 64] (bf16-rounded)
+        up = ops.bilinear_mask if as_masks else ops.bilinear       # as_masks=True: uint8 (logit > 0) in one pass
+        return up(low.view(T * N, 4 * es, 4 * es), H, W).view(T, N, H, W)
+
+    def _bank_pos(self, ages):
+        """[PTR_ROWS + 7 hw, 64] positional table aligned with the memory bank's rows for one age pattern: slot s holds maskmem_pos +
+        maskmem_tpos_enc[ages[s]] (sam2_base.py:566-580: t_pos = 0 for the conditioning frame -> entry 6, a frame t_rel behind -> entry
+        t_rel - 1), zeros on the pointer rows and on empty slots.  At most 12 patterns per clip length; built on first use (never inside a capture:
+        the eager pass in front of it fills the cache)."""
+        hw = self.es * self.es
+
+        def make():
+            tpos = self.P.t(self.p + "maskmem_tpos_enc").view(7, 64)
+            mpos = self.maskmem_pos()
+            tab = torch.zeros(PTR_ROWS + 7 * hw, 64, dtype=self.dtype, device=self.device)
+            for sl, a in enumerate(ages):
+                if a is not None:
+                    tab[PTR_ROWS + sl * hw:PTR_ROWS + (sl + 1) * hw] = ops.add(mpos, tpos[a])
+            return tab
+        return self.P.const(("bank_pos", self.es) + tuple(-1 if a is None else a for a in ages), make)
+
+    def _video_branch_bank(self, T, text_embeds, video_hw, trace, frame_feats, as_masks, mem_override):
+        """video_branch() on a preallocated memory bank (r05).  bank [N, PTR_ROWS + 7 hw, 64]: rows [PTR_ROWS - 4 (j + 1), PTR_ROWS - 4 j) hold
+        object pointer j (j = 0: the conditioning frame's, j = 1 + (t - 1) % 15: frame t's — a ring over the 15 most recent frames), rows
+        [PTR_ROWS + s hw, PTR_ROWS + (s + 1) hw) memory slot s (s = 0: the conditioning frame, s = 1 + (t - 1) % 6: frame t — a ring over the 6
+        most recent).  The valid rows of a frame are one contiguous range [lo, hi): the memory encoder's last GEMM and the pointer selection
+        write their rows in place, the attention kernels read the range through strides — no concatenation, no copies.  The keys' order inside
+        the softmax differs from the reference's (memories oldest-first, then pointers newest-first), which is a summation order, not a value."""
+        N = text_embeds.shape[0]
+        es, hw = self.es, self.es * self.es
+        H, W = video_hw
+        nptr_max = min(T, 16)                              # max_obj_ptrs_in_encoder = min(num_frames, 16)
+        bank = torch.empty(N, PTR_ROWS + 7 * hw, 64, dtype=self.dtype, device=self.device)
+        ptr_rows = lambda j: slice(PTR_ROWS - 4 * (j + 1), PTR_ROWS - 4 * j)        # noqa: E731
+        mem_rows = lambda sl: slice(PTR_ROWS + sl * hw, PTR_ROWS + (sl + 1) * hw)   # noqa: E731
+
+        def feats(t, bs):
+            fpn = frame_feats[t]
+            if bs > 1:
+                fpn = [f.expand(bs, -1, -1, -1).contiguous() for f in fpn]
+            return fpn
+
+        def store_memory(t, sl, top, high, from_pts):
+            mem = self.encode_new_memory(top, high, from_pts, out=bank[:, mem_rows(sl)])
+            if trace is not None:
+                trace["maskmem"].append(mem.clone())
+            if mem_override is not None and t in mem_override:
+                bank[:, mem_rows(sl)].copy_(mem_override[t])
+
+        no_mem = self.P.t(self.p + "no_mem_embed").view(-1)
+        # frame 0: objects added one at a time (batch 1 each), no memory encoder yet
+        fpn0 = feats(0, 1)
+        pix0 = ops.add(fpn0[2].view(1, hw, 256), no_mem)          # directly_add_no_mem_embed
+        outs0 = [self.forward_sam_heads(pix0, (fpn0[0], fpn0[1]), text_embeds[k:k + 1].unsqueeze(1), ptr_out=bank[k:k + 1, ptr_rows(0)])
+                 for k in range(N)]
+        low0 = torch.cat([o["low"] for o in outs0])
+        if trace is not None:
+            trace["frame0_low_multi_pre_where"] = torch.cat([o["low_multi_pre_where"] for o in outs0])
+            trace["frame0_obj_logits"] = torch.cat([o["obj_logits"] for o in outs0])
+            trace["obj_ptr"], trace["maskmem"] = [bank[:, ptr_rows(0)].reshape(N, 256).clone()], []
+        # preflight: consolidate + memory-encode frame 0 (binarised mask, is_mask_from_pts=True)
+        high0 = ops.bilinear(low0.view(N, 4 * es, 4 * es), self.S, self.S).view(N, 1, self.S, self.S)
+        top0 = fpn0[2].view(1, hw, 256).expand(N, -1, -1).contiguous() if N > 1 else fpn0[2].view(1, hw, 256)
+        store_memory(0, 0, top0, high0, True)
+        lows = [low0]
+        for t in range(1, T):
+            fpn = feats(t, N)
+            ages = [6] + [None] * 6                                   # slot -> entry of maskmem_tpos_enc
+            for tp in range(max(1, t - 6), t):
+                ages[1 + (tp - 1) % 6] = t - tp - 1
+            nmem = 1 + min(t - 1, 6)
+            nptr = 4 * (1 + min(t - 1, nptr_max - 1))
+            lo, hi = PTR_ROWS - nptr, PTR_ROWS + nmem * hw
+            top = fpn[2].view(N, hw, 256)
+            pix = self.memory_attention_bank(top, bank, lo, hi, self._bank_pos(ages), nptr)
+            # this frame's pointer replaces the oldest of the ring AFTER the attention has read it (stream order)
+            o = self.forward_sam_heads(pix, (fpn[0], fpn[1]), None, ptr_out=bank[:, ptr_rows(1 + (t - 1) % 15)])
+            lows.append(o["low"])
+            if trace is not None:
+                trace["obj_ptr"].append(bank[:, ptr_rows(1 + (t - 1) % 15)].reshape(N, 256).clone())
+                trace[f"obj_logits_{t}"] = o["obj_logits"]
+                if t == 1:
+                    trace["frame1_pix_feat_with_mem"] = pix
+                    trace["frame1_low_multi_pre_where"] = o["low_multi_pre_where"]
+            store_memory(t, 1 + (t - 1) % 6, top, o["high"], False)
         low = torch.stack(lows)                                                  # [T,N,1,4es,4es]
         if trace is not None:
             trace["low_res"] = low
