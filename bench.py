@@ -97,7 +97,7 @@ class GemmMeter:
     def kernel_of(M, N, K, glu, windowed):
         """the launcher's own routing (vg_gemm_route, videoglamm_amd/csrc/vg_gemm.hip): which tile kernel runs this shape"""
         from videoglamm_amd import _lib
-        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128", 5: "small64"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
+        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128", 5: "small64", 6: "p8n"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
 
     def __enter__(self):
         def timed(x, w, *a, **k):
@@ -772,6 +772,7 @@ def main():
         labels = {"glds": "gemm_tile_glds_kernel<bf16> (128x128 tile, 128-byte K steps)",
                   "k64b": "gemm_tile_k64b_kernel<bf16> (128x128 tile, 64-byte K steps: K*2 < 1024 B)",
                   "w128": "gemm_tile_p8_kernel<bf16> (256x256 tile, 8 waves of 128x64, phase-split K steps; r04: replaces gemm_tile_w128x8_kernel on the 256x256 route)",
+                  "p8n": "gemm_tile_p8n_kernel<bf16> (256x192 tile, the phase-split pipeline with the operand roles swapped; r05: shapes whose rounds x tile cost favour the narrow tile)",
                   "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)",
                   "small64": "gemm_small64_kernel<bf16> (64x64 tile, whole K <= 256 in one DMA burst: problems of < 256 128x128 tiles — memory attention, mask decoder)"}
         roofs = {k: roof(k, labels[k], key="gemm_" + k) for k in labels}

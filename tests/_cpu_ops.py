@@ -58,7 +58,7 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
         cos, sin, cols, ch, rpb, r0, r1, grid = rope
         heads, B = cols // ch, M // rpb
         yv = y.reshape(B, rpb, N).clone()
-        part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).contiguous()
+        part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone()
         rope_axial_(part, cos, sin, r1 - r0, grid)
         yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
         y = yv.reshape(*x.shape[:-1], N)

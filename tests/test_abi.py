@@ -63,8 +63,11 @@ def test_gemm_routing_rules():
     assert route(32768, 1728, 576, win=1) == 4             # ... its window-gathering form stays on the single-stage whole-line kernel
     assert route(131072, 1152, 288) == 2                   # Hiera stage 2 (K x 2 B = 576): 64-byte-step kernel
     assert route(524288, 432, 144) == 2                    # Hiera stage 1: 64-byte-step kernel
-    assert route(16384, 4608, 1152) == 3 and route(9232, 4096, 1024) == 3   # Hiera stage 4 fc1 and CLIP's fc1 (K = 1024): the 256x256 kernel
-    assert route(32768, 576, 2304) == 1                    # Hiera stage 3 fc2: N = 576 wastes a quarter of a 256-wide tile
+    assert route(65536, 2304, 576) == 3 and route(9232, 4096, 1024) == 3    # Hiera stage 3 fc1 and CLIP's fc1 (K = 1024): the 256x256 kernel
+    # r05: 256x192 tiles where whole rounds x tile width say so — N = 576 is three exact tiles (Hiera stage 3 fc2 / proj), Llama's q|k|v at
+    # M = 3361 two rounds of the narrow tile against two of the wide one, CLIP's fc2 one round of 222 narrow tiles against 148 wide ones
+    assert route(65536, 576, 2304) == 6 and route(65536, 576, 576) == 6 and route(3361, 6144, 4096) == 6 and route(9232, 1024, 4096) == 6
+    assert route(16384, 1152, 4608) == 6 and route(16384, 4608, 1152) == 3 and route(3361, 4096, 4096) == 3 and route(3361, 14336, 4096, glu=1) == 3
     assert lib.vg_gemm_route(1697, 4096, 4096, 0, 0, 0) == 1   # fp32 parity mode never takes the bf16-only kernels
     # split-K (ops.linear): under-filled grids with a long K only
     assert ops._splitk(213, 4096, 14336, 2) >= 2 and ops._splitk(2050, 1408, 6144, 2) == 2

@@ -272,9 +272,11 @@ def test_gemm_rows(cuda, case):
     big[:, 24:24 + rows] = dev(x)
     y2 = ops.linear_rows(big[:, 24:24 + rows], dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp))
     assert torch.equal(y2, y)
-    out = torch.full((B, rows, N + 64), 7.0, dtype=dt, device=cuda)
-    ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out[..., 64:])
-    assert torch.equal(out[..., 64:], y) and float((out[..., :64] - 7.0).abs().max()) == 0.0
+    out = torch.full((B * rows, N + 64), 7.0, dtype=dt, device=cuda)                   # a 2-D row-strided destination
+    ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out[:, 64:])
+    assert torch.equal(out[:, 64:], y.view(B * rows, N)) and float((out[:, :64] - 7.0).abs().max()) == 0.0
+    with pytest.raises(AssertionError):                                                 # a 3-D strided destination would be written through a copy: refused
+        ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out.view(B, rows, N + 64)[..., 64:])
 
 
 def test_gemm_rows_fp32_composition(cuda):
@@ -731,6 +733,85 @@ def _check_big_gemm(cuda, M, N, K, glu, routed=True):
     close(y, ref.linear(x, w, residual=res), rtol=2e-2, atol=2e-2)
     y32 = ops.linear(x.to(cuda), w.to(cuda), out_dtype=torch.float32)                          # fp32 output: no output rounding in the way
     close(y32, ref.linear(x, w, out_dtype=torch.float32), rtol=2e-3, atol=2e-3)
+
+
+NARROW = [  # (M, N, K): bf16 shapes launch_gemm routes to the 256x192-tile kernel (vg_gemm_route == 6)
+    (65536, 576, 2304),      # Hiera stage 3 fc2 (three exact column tiles; 768 tiles = 3 rounds)
+    (16384, 576, 576),       # ... its proj at a quarter of the rows (K = 9 steps: prologue / tail kinds back to back)
+    (3361, 6144, 4096),      # Llama q|k|v at the C2 prompt length: ragged M (13 x 256 + 33)
+    (9232, 1024, 4096),      # CLIP fc2: ragged N (5 x 192 + 64) and ragged M
+    (16384, 1160, 1152),     # N = 6 x 192 + 8: a last column tile with one 8-column group
+]
+
+
+@pytest.mark.parametrize("M,N,K", NARROW)
+def test_gemm_p8n(cuda, M, N, K):
+    """the 256x192-tile phase-split kernel against the fp32 statement: every epilogue family (bias + activation, LayerScale + residual, residual
+    alone, plain, fp32 output) on exact, ragged-M and ragged-N grids, long and minimal K."""
+    from videoglamm_amd import _lib, ops
+    assert _lib.load().vg_gemm_route(M, N, K, 1, 0, 0) == 6, "this shape must take the 256x192-tile kernel"
+    dtype = torch.bfloat16
+    x = rnd(M, K, dtype=dtype, seed=1)
+    w = rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, gamma, res = rnd(N, seed=3), 1.0 + 0.1 * rnd(N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    xd, wd = x.to(cuda), w.to(cuda)
+    close(ops.linear(xd, wd, bias.to(cuda), ops.ACT_GELU), ref.linear(x, w, bias, ref.ACT_GELU), rtol=2e-2, atol=2e-2)
+    close(ops.linear(xd, wd, bias.to(cuda), ops.ACT_NONE, gamma.to(cuda), res.to(cuda)), ref.linear(x, w, bias, ref.ACT_NONE, gamma, res), rtol=2e-2, atol=2e-2)
+    close(ops.linear(xd, wd, residual=res.to(cuda)), ref.linear(x, w, residual=res), rtol=2e-2, atol=2e-2)
+    close(ops.linear(xd, wd), ref.linear(x, w), rtol=2e-2, atol=2e-2)
+    close(ops.linear(xd, wd, bias.to(cuda), ops.ACT_SILU, None, res.to(cuda)), ref.linear(x, w, bias, ref.ACT_SILU, None, res), rtol=2e-2, atol=2e-2)   # run-time activation path
+    close(ops.linear(xd, wd, bias.to(cuda), out_dtype=torch.float32), ref.linear(x, w, bias, out_dtype=torch.float32), rtol=2e-3, atol=2e-3)
+    # a transposed / shifted tile would survive random data only by luck: one-hot rows pick single W columns
+    eye = torch.zeros(M, K, dtype=dtype)
+    idx = torch.arange(M) % K
+    eye[torch.arange(M), idx] = 1.0
+    y = ops.linear(eye.to(cuda), wd).float().cpu()
+    assert torch.equal(y, w.float().t()[idx])
+
+
+def _check_p8n(cuda, M, N, K):
+    from videoglamm_amd import ops
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=5)
+    close(ops.linear(x.to(cuda), w.to(cuda), bias.to(cuda), ops.ACT_GELU), ref.linear(x, w, bias, ref.ACT_GELU), rtol=2e-2, atol=2e-2)
+    close(ops.linear(x.to(cuda), w.to(cuda), residual=res.to(cuda)), ref.linear(x, w, residual=res), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_p8n_minimal_k_forced(cuda):
+    """K = 2 / 3 / 4 / 5 steps (the pipeline's PRELAST / LAST tails directly behind the prologue) and grids of a few tiles, which the shape rule never
+    sends to the 256x192 kernel: VG_GEMM_P8=3 forces it (read once per process: a child process runs it)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]\n"
+            "import test_kernels_gpu as t\n"
+            "from videoglamm_amd import _lib\n"
+            "lib = _lib.load(); assert lib.vg_init(0) > 0\n"
+            "dev = torch.device('cuda:0')\n"
+            "for s in ((4111, 1160, 128), (1000, 200, 192), (8192, 1152, 256), (777, 384, 320), (300, 192, 4096)):\n"
+            "    assert lib.vg_gemm_route(*s, 1, 0, 0) == 6\n"
+            "    t._check_p8n(dev, *s)\n"
+            "print('forced ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VG_GEMM_P8="3"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "forced ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_gemm_p8n_window_forms(cuda):
+    """Hiera stage 3's window-folded proj (N = 576: the 256x192 route) — rows scattered to image order + residual — and a gathered A on the same
+    kernel, against the unfolded statement."""
+    from videoglamm_amd import ops
+    B, H, W, ws, C, N = 16, 64, 64, 16, 576, 576
+    dtype = torch.bfloat16
+    x = rnd(B, H, W, C, dtype=dtype, seed=1)
+    w, bias = rnd(N, C, dtype=dtype, seed=2, scale=C ** -0.5), rnd(N, seed=3)
+    res = rnd(B, H, W, N, dtype=dtype, seed=4)
+    y = ops.linear_window(x.to(cuda), w.to(cuda), bias.to(cuda), B, H, W, ws, scatter=False)
+    close(y, ref.linear_window(x, w, bias, B, H, W, ws, scatter=False), rtol=2e-2, atol=2e-2)
+    xw = ref.window_partition(x, ws)
+    z = ops.linear_window(xw.to(cuda), w.to(cuda), bias.to(cuda), B, H, W, ws, scatter=True, residual=res.to(cuda))
+    close(z, ref.linear_window(xw, w, bias, B, H, W, ws, scatter=True, residual=res), rtol=2e-2, atol=2e-2)
 
 
 def test_gemm_tail_rows_split(cuda):

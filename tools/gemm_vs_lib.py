@@ -17,7 +17,8 @@ shapes = [("c2 llm qkv", 3361, 6144, 4096), ("c2 llm o", 3361, 4096, 4096), ("c2
           ("hiera s1 qkv", 1048576, 432, 144), ("hiera s1 fc1", 1048576, 576, 144), ("hiera s1 fc2", 1048576, 144, 576),
           ("hiera s2 qkv", 262144, 864, 288), ("hiera s2 fc1", 262144, 1152, 288), ("hiera s2 fc2", 262144, 288, 1152),
           ("hiera s3 qkv", 65536, 1728, 576), ("hiera s3 proj", 65536, 576, 576), ("hiera s3 fc1", 65536, 2304, 576), ("hiera s3 fc2", 65536, 576, 2304),
-          ("hiera s4 qkv", 16384, 3456, 1152), ("hiera s4 fc1", 16384, 4608, 1152), ("hiera s4 fc2", 16384, 1152, 4608),
+          ("hiera s4 qkv", 16384, 3456, 1152), ("hiera s4 proj", 16384, 1152, 1152), ("hiera s4 fc1", 16384, 4608, 1152), ("hiera s4 fc2", 16384, 1152, 4608),
+          ("clip proj", 9232, 1024, 1024), ("clip qkv", 9232, 3072, 1024), ("iv2 proj", 4100, 1408, 1408),
           ("square 8k", 8192, 8192, 8192)]
 if os.environ.get("VG_BENCH_SHAPES"):
     shapes = [s for s in shapes if any(t in s[0] for t in os.environ["VG_BENCH_SHAPES"].split(","))]
@@ -31,4 +32,6 @@ for name, M, N, K in shapes:
         ms = min(ms, t(lambda: ops.linear(a, w, out=out)))
         ml = min(ml, t(lambda: F.linear(a, w)))
     fl = 2 * M * N * K
-    print(f"{name:14s} M={M:8d} N={N:6d} K={K:6d}  ours {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s | lib {ml*1e3:8.1f} us {fl/ml/1e9:7.1f} TF/s  ratio {ml/ms:.2f}", flush=True)
+    from videoglamm_amd import _lib
+    name = f"{name} [r{_lib.load().vg_gemm_route(M, N, K, 1, 0, 0)}]"
+    print(f"{name:19s} M={M:8d} N={N:6d} K={K:6d}  ours {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s | lib {ml*1e3:8.1f} us {fl/ml/1e9:7.1f} TF/s  ratio {ml/ms:.2f}", flush=True)

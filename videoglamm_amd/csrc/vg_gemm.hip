@@ -960,7 +960,7 @@ static int env_knob(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-static int knob_p8() { static const int v = env_knob("VG_GEMM_P8", 1); return v; }    // 0: no 256x256 route (A/B), 2: every eligible bf16 shape
+static int knob_p8() { static const int v = env_knob("VG_GEMM_P8", 1); return v; }    // 0: no 256-row tile routes (A/B), 2 / 3: the 256x256 / 256x192 kernel on every eligible bf16 shape
 // small problems with a short K: fewer than 256 tiles of 128x128 (the chip is not filled), K = 64 / 128 / 192 / 256 bf16 -> gemm_small64_kernel
 static bool route_small64(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch) {
   if (es != 2 || a_op || wmode || !vec_out || M <= 16 || K % 64 != 0 || K > 256) return false;
@@ -994,6 +994,27 @@ static bool route_p8(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmod
   return t256 >= 128 && useful * fill >= 0.7;
 }
 
+// 256 x 192 tiles (vg_gemm_p8n.hip, r05) instead of 256 x 256 when whole rounds x tile cost say so: cost = rounds of 256 workgroups x
+// (0.87 | 1) — measured r05 (tools/lab/p8n_ab.sh, same box): a narrow tile costs 0.83-0.90 of a wide one at equal rounds (it stages 7/8 of the
+// bytes for 3/4 of the MFMAs).  N = 576 is three exact 192-tiles against 2.25 of three 256-tiles (Hiera stage 3 fc2 195 -> 162 us, proj
+// 86 -> 55), Llama's q|k|v at M = 3361 two rounds of the narrow tile against two of the wide one (189 -> 170 us; r04's 128x128 route: 213).  Without a valid 256-route for the shape (under-filled or badly quantised grids) the narrow tile is judged by the
+// same fill rule.
+static bool route_p8n(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch, bool p8_ok, int* nt_out, int* mt_out) {
+  const int nt = (int)((N + 191) / 192), mt = (int)((M + 255) / 256);
+  if (nt_out) { *nt_out = nt; *mt_out = mt; }
+  if (es != 2 || a_op || wmode || K % 64 != 0 || K < 128 || !vec_out) return false;
+  if (knob_p8() == 3) return true;       // 3: force the 256x192 kernel on every eligible shape (tests: minimal K, tiny grids)
+  if (knob_p8() != 1 || (route_small_k(K, es, a_op) && K * es < 1152)) return false;
+  const int64_t t192 = (int64_t)nt * mt * batch, t256 = (int64_t)((N + 255) / 256) * mt * batch;
+  if (t192 < 128) return false;
+  const int64_t r192 = (t192 + 255) / 256, r256 = (t256 + 255) / 256;
+  if (!p8_ok) {
+    const double useful = (double)M * N / ((double)mt * 256 * nt * 192), fill = (double)t192 / (double)(r192 * 256);
+    return useful * fill >= 0.7;
+  }
+  return (double)r192 * 0.87 < 0.97 * (double)r256;
+}
+
 template <typename T, typename TO>
 static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
   if (p.M <= 16) {
@@ -1019,8 +1040,10 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     int ntw, mtw;
     // (r04: a padding-free power-of-two window GATHER rides on the phase-split kernel — Hiera stage 3's windowed qkv; everything else windowed
     // stays on the 128x128 kernels)
-    const int wroute = (knob_p8() == 1 && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
+    const int wroute = ((knob_p8() == 1 || knob_p8() == 3) && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
     const bool big = route_p8(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, &ntw, &mtw) && vg_gemm_p8_eligible(p, batch);
+    int ntn, mtn;
+    const bool narrow = sizeof(T) == 2 && route_p8n(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, big, &ntn, &mtn) && vg_gemm_p8_eligible(p, batch);
     if constexpr (sizeof(T) == 2) {
       if (route_small64(p.M, p.N, p.K, 2, p.a_op, p.wmode, p.vec_out, batch) && !p.sa) {
         const int nseg = p.K / 64;
@@ -1034,6 +1057,15 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
         gemm_small64_kernel<TO><<<grids, 256, lds, st>>>(q);
         VG_LAUNCH_CHECK();
         return VG_OK;
+      }
+    }
+    if (narrow) {
+      if constexpr (sizeof(T) == 2) {
+        q.gn = pick_gn(mtn, ntn);
+        q.nbatch = batch;
+        static const int ncu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int64_t tot = (int64_t)ntn * mtn * batch;
+        return vg_gemm_p8n_launch(q, sizeof(TO) == 2, (int)(tot > ncu ? ncu : tot), st);
       }
     }
     if (big) {
@@ -1218,7 +1250,9 @@ extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int 
   if (M <= 16) return 0;
   const int es = in_dtype == VG_BF16 ? 2 : 4;
   if (route_small64(M, N, K, es, a_op, windowed, 1, 1)) return 5;
-  if (route_p8(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr)) return 3;
+  const bool p8ok = route_p8(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr);
+  if (route_p8n(M, N, K, es, a_op, windowed, 1, 1, p8ok, nullptr, nullptr)) return 6;
+  if (p8ok) return 3;
   if (route_s128(K, es, a_op)) return 4;
   if (route_small_k(K, es, a_op)) return 2;
   return 1;

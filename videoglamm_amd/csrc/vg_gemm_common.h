@@ -215,3 +215,5 @@ __device__ __forceinline__ bool epi_dispatch(int act, bool res, bool gam, F&& f)
 bool vg_gemm_p8_eligible(const GemmArgs& p, int batch);
 bool vg_gemm_p8_window_ok(int wmode, int wsh, int wH, int wW, int wws);
 int vg_gemm_p8_launch(const GemmArgs& q, int out_is_bf16, int wgs, hipStream_t st);
+// vg_gemm_p8n.hip: the same pipeline on 256 x 192 tiles (launch_gemm's route_p8n decides)
+int vg_gemm_p8n_launch(const GemmArgs& q, int out_is_bf16, int wgs, hipStream_t st);

@@ -180,6 +180,7 @@ def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=
         out = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
     o2, Mo, ldc = _rows2d(out)
     assert Mo == M and out.dtype == odt and out.shape[-1] == N, (tuple(out.shape), M, N, out.dtype, odt)      # (a wider / narrower `out` would be written with a wrong row stride)
+    assert o2.data_ptr() == out.data_ptr() and (o2.is_contiguous() or out.dim() == 2), "out must be contiguous or a 2-D row-strided view"
     r2, ldr = None, 0
     if residual is not None:
         assert residual.dtype == odt
@@ -222,7 +223,7 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
             heads, B = cols // ch, M // rpb
             yv = y.view(B, rpb, N)
             # (parity mode only: the strided head slices go through a contiguous copy — torch plumbing around vg_rope_axial)
-            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).contiguous().view(B * heads, r1 - r0, ch)
+            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone()
             rope_axial_(part, cos, sin, r1 - r0, grid)
             yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
             if out is not None:
@@ -232,6 +233,7 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
     o2, Mo, ldc = _rows2d(out)
+    assert o2.data_ptr() == out.data_ptr(), "out must be contiguous or a 2-D row-strided view (anything else would be written through a copy)"
     assert Mo == M and out.dtype == x.dtype and out.shape[-1] == N
     r2, ldr = None, 0
     if residual is not None:
