@@ -290,6 +290,24 @@ def test_gemm_rows_fp32_composition(cuda):
     close(y, ref.linear_rows(x, w, bias, add=add, rope=rp), **tol(torch.float32, 64))
 
 
+@pytest.mark.parametrize("hw", [(256, 256), (16, 16), (7, 9)])
+def test_multimask_select(cuda, hw):
+    """SAM2's mask selection (mask_decoder.py:257-295, sam2_base.py:378-389): mode 0 = token 0 unless its stability score falls under the
+    threshold, mode 1 = the best-IoU token of 1..3 (the many-workgroup copy kernel when the mask is a whole number of 16-byte groups)."""
+    from videoglamm_amd import ops
+    N, C = 5, 256
+    masks = rnd(N, 4, *hw, seed=1) * 3.0
+    masks[1, 0] = masks[1, 0].abs() + 1.0           # a stable token-0 mask: every pixel clear of +-delta
+    ious = rnd(N, 4, seed=2)
+    ious[2, 1:] = ious[2, 2]                       # ties: the first maximum wins
+    toks = rnd(N, 4, C, dtype=torch.bfloat16, seed=3)
+    for mode in (0, 1):
+        got = ops.multimask_select(masks.to(cuda), ious.to(cuda), toks.to(cuda), mode)
+        want = ref.multimask_select(masks, ious, toks, mode)
+        for g, w in zip(got, want):
+            assert torch.equal(g.cpu(), w), mode
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops
@@ -790,7 +808,7 @@ def test_gemm_p8n_minimal_k_forced(cuda):
             "from videoglamm_amd import _lib\n"
             "lib = _lib.load(); assert lib.vg_init(0) > 0\n"
             "dev = torch.device('cuda:0')\n"
-            "for s in ((4111, 1160, 128), (1000, 200, 192), (8192, 1152, 256), (777, 384, 320), (300, 192, 4096)):\n"
+            "for s in ((4111, 1160, 128), (4111, 1160, 192), (8192, 1152, 256), (777, 384, 320), (300, 192, 4096)):\n"
             "    assert lib.vg_gemm_route(*s, 1, 0, 0) == 6\n"
             "    t._check_p8n(dev, *s)\n"
             "print('forced ok')\n") % (os.path.dirname(here), here)

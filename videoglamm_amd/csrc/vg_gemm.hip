@@ -987,7 +987,7 @@ static bool route_p8(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmod
   // single-stage 128x128 one by 2...9 %; K = 1024 / 576 stay there)
   constexpr int smallk_min = 1152;     // r04: with the phase-split kernel also K = 576 (Hiera stage 3): C2 268.5 -> 266.7 ms same-box
   if (!w || es != 2 || (route_small_k(K, es, a_op) && K * es < smallk_min) || wmode || K % (128 / es) != 0 || !vec_out) return false;
-  if (w == 2) return true;       // 2: force the 256x256 kernel on every eligible shape
+  if (w == 2) return true;       // 2: force the 256x256 kernel on every eligible shape (4 = the shape rule, without the 256x192 tile)
   const int64_t t256 = (int64_t)ntw * mtw * batch;
   const double useful = (double)M * N / ((double)mtw * 256 * ntw * (a_op == 1 ? 128 : 256));
   const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
@@ -1004,7 +1004,7 @@ static bool route_p8n(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmo
   if (nt_out) { *nt_out = nt; *mt_out = mt; }
   if (es != 2 || a_op || wmode || K % 64 != 0 || K < 128 || !vec_out) return false;
   if (knob_p8() == 3) return true;       // 3: force the 256x192 kernel on every eligible shape (tests: minimal K, tiny grids)
-  if (knob_p8() != 1 || (route_small_k(K, es, a_op) && K * es < 1152)) return false;
+  if (knob_p8() != 1 || (route_small_k(K, es, a_op) && K * es < 1152)) return false;      // (4: the shape rule without the narrow tile — A/B)
   const int64_t t192 = (int64_t)nt * mt * batch, t256 = (int64_t)((N + 255) / 256) * mt * batch;
   if (t192 < 128) return false;
   const int64_t r192 = (t192 + 255) / 256, r256 = (t256 + 255) / 256;
@@ -1040,7 +1040,7 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
     int ntw, mtw;
     // (r04: a padding-free power-of-two window GATHER rides on the phase-split kernel — Hiera stage 3's windowed qkv; everything else windowed
     // stays on the 128x128 kernels)
-    const int wroute = ((knob_p8() == 1 || knob_p8() == 3) && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
+    const int wroute = ((knob_p8() == 1 || knob_p8() >= 3) && sizeof(T) == 2 && vg_gemm_p8_window_ok(p.wmode, p.wsh, p.wH, p.wW, p.wws)) ? 0 : p.wmode;
     const bool big = route_p8(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, &ntw, &mtw) && vg_gemm_p8_eligible(p, batch);
     int ntn, mtn;
     const bool narrow = sizeof(T) == 2 && route_p8n(p.M, p.N, p.K, (int)sizeof(T), p.a_op, wroute, p.vec_out, batch, big, &ntn, &mtn) && vg_gemm_p8_eligible(p, batch);

@@ -20,6 +20,7 @@ struct RowsArgs {
   int64_t a_block_stride;       // != 0: row m of A lives at block (m / rpb) * a_block_stride + (m % rpb) * lda (a strided [B, rows, K] view)
   const float* cs; const float* sn;
   int rope_cols, rope_ch, rpb, r0, r1, grid;
+  int ntile;                    // 64-column tiles per workgroup: the A tile is staged (and normalised) once and walks `ntile` W tiles
 };
 
 enum { PRO_NONE = 0, PRO_LN = 1, PRO_ADD = 2 };
@@ -33,27 +34,41 @@ __global__ __launch_bounds__(256) void gemm_rows64_kernel(RowsArgs a) {
   constexpr int KPC = 8, SEG = 64 * 128;          // one 64-element K segment of a 64-row operand tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-  const int bn = blockIdx.x, bm = blockIdx.y;
+  const int bm = blockIdx.y;
   const int M = p.M, N = p.N, nseg = p.K / 64;
   const T* A = (const T*)p.A;
   const T* W = (const T*)p.W;
+  // LDS: A tile | W tile | fp32 staging of the epilogue (separate: the A tile lives across the workgroup's W tiles)
+  char* smW = smem + nseg * SEG;
+  float* stg = (float*)(smem + 2 * nseg * SEG);
+  auto load_w = [&](int bn) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wave * 16 + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gn = bn * 64 + row;
+      gn = gn < N ? gn : N - 1;
+      const T* wsrc = W + (int64_t)gn * p.ldw + chunk * KPC;
+      char* dw = smW + wave * 16 * 128 + i * 1024;
+      for (int sg = 0; sg < nseg; ++sg)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + sg * 64),
+                                         (__attribute__((address_space(3))) void*)(dw + sg * SEG), 16, 0, 0);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = wave * 16 + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = bm * 64 + row, gn = bn * 64 + row;
+    int gm = bm * 64 + row;
     gm = gm < M ? gm : M - 1;
-    gn = gn < N ? gn : N - 1;
     const T* as = A + (a.a_block_stride ? (int64_t)(gm / a.rpb) * a.a_block_stride + (int64_t)(gm % a.rpb) * p.lda : (int64_t)gm * p.lda) + chunk * KPC;
-    const T* wsrc = W + (int64_t)gn * p.ldw + chunk * KPC;
     char* da = smem + wave * 16 * 128 + i * 1024;
-    for (int sg = 0; sg < nseg; ++sg) {
+    for (int sg = 0; sg < nseg; ++sg)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(as + sg * 64),
                                        (__attribute__((address_space(3))) void*)(da + sg * SEG), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + sg * 64),
-                                       (__attribute__((address_space(3))) void*)(da + (nseg + sg) * SEG), 16, 0, 0);
-    }
   }
+  const int bn0 = blockIdx.x * a.ntile;
+  load_w(bn0);
   // the prologue's own operands are requested while the tiles are in flight: thread (row, part) owns 16-byte chunks 2 part, 2 part + 1 of every
   // K segment of its row (the four threads of a row hit different LDS slots)
   const int prow = tid >> 2, part = tid & 3, pkey = (prow >> 1) & 7;
@@ -69,9 +84,6 @@ __global__ __launch_bounds__(256) void gemm_rows64_kernel(RowsArgs a) {
         for (int j = 0; j < 2; ++j) add2[sg][j] = *(const u32x4_t*)(a2 + sg * 64 + (2 * part + j) * KPC);
       }
   }
-  f32x16_t acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int ra = wm * 32 + l31, rb = wn * 32 + l31;
   const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -146,80 +158,101 @@ __global__ __launch_bounds__(256) void gemm_rows64_kernel(RowsArgs a) {
     }
     __syncthreads();
   }
-  for (int sg = 0; sg < nseg; ++sg) {
-    const char* sa = smem + sg * SEG + ra * 128;
-    const char* sb = smem + (nseg + sg) * SEG + rb * 128;
-    u32x4_t fa[4], fb[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = 2 * g + h;
-      fa[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
-      fb[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) MmaOp<T>::run(fa[g], fb[g], acc);
-  }
-  __syncthreads();   // the fp32 staging (4 waves x 32 rows x 36 floats) aliases the operand buffers
-
   TO* C = (TO*)p.C;
   const TO* R = (const TO*)p.R;
   constexpr int ES = 36;
-  float* ws = (float*)smem + wave * 32 * ES;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + l31] = acc[r];
-  vg_lds_barrier();
+  float* ws = stg + wave * 32 * ES;
   const int cg = lane & 3, rsub = lane >> 2;          // 4 column groups x 16 rows per pass
-  const int n0w = bn * 64 + wn * 32, m0w = bm * 64 + wm * 32;
-  const int n0 = n0w + cg * 8;
-  float bv[8], gv[8];
+  const int m0w = bm * 64 + wm * 32;
+  for (int jt = 0; jt < a.ntile; ++jt) {
+    const int bn = bn0 + jt;
+    if (bn * 64 >= N) break;                          // (workgroup-uniform)
+    f32x16_t acc;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = p.bias ? p.bias[n0 + e] : 0.f;
-    gv[e] = 1.f;
-  }
-  if constexpr (ROPE) {
-    if (n0 < a.rope_cols) {          // the lane's eight columns = four rotation pairs of one head (rope_cols, rope_ch multiples of 8)
-      const int hc = a.rope_ch >> 1, j0 = (n0 % a.rope_ch) >> 1;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int sg = 0; sg < nseg; ++sg) {
+      const char* sa = smem + sg * SEG + ra * 128;
+      const char* sb = smW + sg * SEG + rb * 128;
+      u32x4_t fa[4], fb[4];
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        float* rowp = ws + (ps * 16 + rsub) * ES + cg * 8;
-        const int r = (m0w + ps * 16 + rsub) % a.rpb;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(rowp[e] + bv[e]));      // the projection's bf16 output: what the separate RoPE launch reads
-        if (r >= a.r0 && r < a.r1) {
-          const int tok = (r - a.r0) % a.grid;
-          const f32x4_t c = *(const f32x4_t*)(a.cs + (int64_t)tok * hc + j0), sv = *(const f32x4_t*)(a.sn + (int64_t)tok * hc + j0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x0 = v[2 * e], x1 = v[2 * e + 1];
-            v[2 * e] = x0 * c[e] - x1 * sv[e];
-            v[2 * e + 1] = x0 * sv[e] + x1 * c[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rowp[e] = v[e];
+      for (int g = 0; g < 4; ++g) {
+        const int c = 2 * g + h;
+        fa[g] = *(const u32x4_t*)(sa + ((c ^ swa) << 4));
+        fb[g] = *(const u32x4_t*)(sb + ((c ^ swb) << 4));
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      for (int g = 0; g < 4; ++g) MmaOp<T>::run(fa[g], fb[g], acc);
+    }
+    __syncthreads();                                  // every wave has read this W tile: the next one may land under the epilogue
+    const bool more = jt + 1 < a.ntile && (bn + 1) * 64 < N;
+    if (more) load_w(bn + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + l31] = acc[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the staging slab is wave-private)
+    const int n0w = bn * 64 + wn * 32;
+    const int n0 = n0w + cg * 8;
+    float bv[8], gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[e] = p.bias ? p.bias[n0 + e] : 0.f;
+      gv[e] = 1.f;
+    }
+    if constexpr (ROPE) {
+      if (n0 < a.rope_cols) {          // the lane's eight columns = four rotation pairs of one head (rope_cols, rope_ch multiples of 8)
+        const int hc = a.rope_ch >> 1, j0 = (n0 % a.rope_ch) >> 1;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          float* rowp = ws + (ps * 16 + rsub) * ES + cg * 8;
+          const int r = (m0w + ps * 16 + rsub) % a.rpb;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(rowp[e] + bv[e]));      // the projection's bf16 output: what the separate RoPE launch reads
+          if (r >= a.r0 && r < a.r1) {
+            const int tok = (r - a.r0) % a.grid;
+            const f32x4_t c = *(const f32x4_t*)(a.cs + (int64_t)tok * hc + j0), sv = *(const f32x4_t*)(a.sn + (int64_t)tok * hc + j0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = v[2 * e], x1 = v[2 * e + 1];
+              v[2 * e] = x0 * c[e] - x1 * sv[e];
+              v[2 * e + 1] = x0 * sv[e] + x1 * c[e];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rowp[e] = v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      }
+    }
+    epi_dispatch(p.act, R != nullptr, false, [&](auto act, auto res, auto gam) {
+      epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16, false>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
+    });
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
-  epi_dispatch(p.act, R != nullptr, false, [&](auto act, auto res, auto gam) {
-    epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16, false>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
-  });
 }
 
 template <int PRO, bool ROPE>
 int launch_rows(const RowsArgs& a, hipStream_t st) {
   const int nseg = a.g.K / 64;
-  const int lds = nseg * 2 * 64 * 128 > 4 * 32 * 36 * 4 ? nseg * 2 * 64 * 128 : 4 * 32 * 36 * 4;
+  const int lds = nseg * 2 * 64 * 128 + 4 * 32 * 36 * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_rows64_kernel<PRO, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemm_rows64_kernel<PRO, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  dim3 grid(a.g.N / 64, (a.g.M + 63) / 64, 1);
-  gemm_rows64_kernel<PRO, ROPE><<<grid, 256, lds, st>>>(a);
+  // column tiles per workgroup: as many as keep every resident workgroup slot (1 per CU at K = 256, 4 at K = 64) busy — the A tile (and its LayerNorm) is then staged once per
+  // `ntile` outputs tiles instead of once per tile (measured r05, norm3 -> linear1 -> ReLU at M = 4096, N = 2048: 33.8 us with one tile each)
+  const int mt = (a.g.M + 63) / 64, nt = a.g.N / 64;
+  const int per_cu = 160 * 1024 / lds < 1 ? 1 : (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);      // resident workgroups per CU at this K
+  int ntile = (int)(((int64_t)mt * nt) / (256 * per_cu));
+  ntile = ntile < 1 ? 1 : (ntile > nt ? nt : (ntile > 16 ? 16 : ntile));
+  RowsArgs b = a;
+  b.ntile = ntile;
+  dim3 grid((nt + ntile - 1) / ntile, mt, 1);
+  gemm_rows64_kernel<PRO, ROPE><<<grid, 256, lds, st>>>(b);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -464,11 +464,42 @@ __global__ __launch_bounds__(256) void multimask_select_kernel(const float* __re
   }
 }
 
+// mode 1 (multimask_output=True: the best-IoU token, no stability pass — the SAM heads of the video branch): nothing to reduce, so the selected
+// mask is copied by many workgroups per object with 16-byte accesses (r05: one workgroup per object took 62 us for a 256 KB mask — a tracked
+// frame's slowest small kernel)
+__global__ __launch_bounds__(256) void multimask_best_kernel(const float* __restrict__ masks, const float* __restrict__ ious,
+                                                             const void* __restrict__ tokens, float* __restrict__ out_mask,
+                                                             float* __restrict__ out_iou, void* __restrict__ out_token,
+                                                             int* __restrict__ out_idx, int64_t HW, int C, int tok_dt) {
+  const int n = blockIdx.y;
+  const float* io = ious + n * 4;
+  int sel = 1;
+  for (int k = 2; k < 4; ++k) if (io[k] > io[sel]) sel = k;  // argmax, first max wins
+  const f32x4_t* src = (const f32x4_t*)(masks + ((int64_t)n * 4 + sel) * HW);
+  f32x4_t* dst = (f32x4_t*)(out_mask + (int64_t)n * HW);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    if (tokens && out_token)
+      for (int c = threadIdx.x; c < C; c += 256)
+        st_any(out_token, (int64_t)n * C + c, tok_dt, ld_any(tokens, ((int64_t)n * 4 + sel) * C + c, tok_dt));
+    if (threadIdx.x == 0) {
+      out_iou[n] = io[sel];
+      if (out_idx) out_idx[n] = sel;
+    }
+  }
+}
+
 extern "C" int vg_multimask_select(const float* masks, const float* ious, const void* tokens, float* out_mask,
                                    float* out_iou, void* out_token, int* out_idx, int N, int64_t HW, int C, float delta,
                                    float thresh, int mode, int token_dtype, vg_stream_t stream) {
   VG_CHECK(masks && ious && out_mask && out_iou && N >= 0 && HW > 0, VG_ERR_ARG, "vg_multimask_select: bad args");
   if (N == 0) return VG_OK;
+  if (mode == 1 && HW % 4 == 0 && ((uintptr_t)masks & 15) == 0 && ((uintptr_t)out_mask & 15) == 0) {
+    const int nb = (int)((HW / 4 + 255) / 256);
+    multimask_best_kernel<<<dim3(nb < 64 ? nb : 64, N), 256, 0, (hipStream_t)stream>>>(masks, ious, tokens, out_mask, out_iou, out_token, out_idx, HW, C, token_dtype);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   multimask_select_kernel<<<dim3(N), 256, 0, (hipStream_t)stream>>>(masks, ious, tokens, out_mask, out_iou, out_token, out_idx,
                                                                      HW, C, delta, thresh, mode, token_dtype);
   VG_LAUNCH_CHECK();
