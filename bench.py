@@ -504,6 +504,41 @@ def video_record(args, model, ops, inputs):
     return rec
 
 
+def mask_decoder_record(model, device, frames=64, objects=8, reps=3):
+    """The SAM2 mask decoder (S7 / S8: two-way transformer, upscaling, hypernetwork product, mask selection) at BASELINE config C4's size on ONE
+    GPU — 64 frames x 8 [SEG] objects = 512 (frame, object) instances — as a sub-record of the C2 line, where the stage is 32 instances and too
+    small to say anything.  HBM-bound by SURVEY.md section 8(d): per instance the reference streams the [4096, 256] keys through 2 blocks x 3
+    passes, the two high-resolution feature maps once, and writes 4 x 256^2 logits = 2 (3.1 + 4.2) + 0.26 M elements = 29.7 MB in bf16.
+    Timed with HIP events around SAM2.framewise_branch on precomputed Hiera features (mask upsampling to 1024^2 + threshold included, no D2H)."""
+    sam2 = model.sam2
+    g = torch.Generator().manual_seed(4321)
+    sam = torch.randn(frames, 3, sam2.S, sam2.S, generator=g).to(device)
+    emb = (torch.randn(objects, 256, generator=g) * 0.5).to(device=device, dtype=sam2.dtype)
+    feats = sam2.hiera_frames(sam)
+    del sam
+    hw = (1024, 1024)
+    sam2.framewise_branch(None, emb, hw, frame_feats=feats, frames=list(range(frames)), as_masks=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        masks, _ = sam2.framewise_branch(None, emb, hw, frame_feats=feats, frames=list(range(frames)), as_masks=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    inst = frames * objects
+    per_inst = (2 * (3.1e6 + 4.2e6) + 0.26e6) * 2.0
+    gbs = inst * per_inst / (ms * 1e-3) / 1e9
+    frac = float(masks.sum(dtype=torch.int64)) / masks.numel()
+    del feats, masks
+    torch.cuda.empty_cache()
+    return {"what": f"SAM2 mask decoder on {frames} frames x {objects} objects = {inst} instances (BASELINE config C4's clip on one GPU), framewise branch, "
+                    "precomputed Hiera features -> thresholded 1024^2 masks on the device",
+            "bound": "hbm", "instances": inst, "ms": round(ms, 2), "us_per_instance": round(1e3 * ms / inst, 2),
+            "algorithmic_bytes_per_instance": round(per_inst), "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "mask_fraction": round(frac, 4)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -831,6 +866,8 @@ def main():
                                       "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
     if world == 1 and not use_video and not args.tiny and not args.no_video_record:
         res["video_branch"] = video_record(args, model, ops, (images, context, sam, ids))
+    if world == 1 and not use_video and not args.tiny and not args.no_video_record:
+        res["roofline_mask_decoder_c4clip"] = mask_decoder_record(model, device)
     if world == 1 and not args.no_quality and not args.tiny:
         res["quality"] = quality(cfg, args, model, step, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:      # the CPU leg runs at N = 1 only
