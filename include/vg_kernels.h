@@ -87,6 +87,15 @@ int vg_gemm_rows(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
                  int a2_rows, const float* rope_cos, const float* rope_sin, int rope_cols, int rope_ch, int rows_per_block, int64_t a_block_stride,
                  int rope_r0, int rope_r1, int rope_grid, int dtype, vg_stream_t stream);
 
+/* A whole pre-norm MLP block on narrow rows in one launch (bf16; C in {144, 288}: Hiera stages 1 and 2; H % 32 == 0):
+ *   y = x + W2 @ gelu(W1 @ LayerNorm(x) + b1) + b2        W1: [H, C] contiguous rows, W2: [C, H] contiguous rows, exact-erf GELU
+ * — x = x + self.mlp(self.norm2(x)) of R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:160-168 (MLP: sam2_utils.py:108-132).
+ * The LayerNorm output and the hidden activation are rounded to bf16 like the separate launches' tensors; they never leave the CU.
+ * vg_mlp_rows_supported(C, H) != 0: this (C, H) has an instantiation; the fp32 parity mode runs vg_layernorm + vg_gemm x 2. */
+int vg_mlp_rows_supported(int C, int H);
+int vg_mlp_rows(const void* x, int64_t ldx, void* y, int64_t ldy, const float* ln_w, const float* ln_b, float eps, const void* w1,
+                const float* b1, const void* w2, const float* b2, int64_t M, int C, int H, int dtype, vg_stream_t stream);
+
 /* The same contraction with Hiera's window_partition / window_unpartition (backbones/utils.py:16-38,41-60, called from
  * hieradet.py:128-136,147-148) folded into it.  GEMM row m is the WINDOW-order row index (window (b,wy,wx), token (r,c)),
  * M = B*ceil(H/ws)*ceil(W/ws)*ws*ws including the zero padding rows the reference pads with.

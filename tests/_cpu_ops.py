@@ -58,7 +58,7 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
         cos, sin, cols, ch, rpb, r0, r1, grid = rope
         heads, B = cols // ch, M // rpb
         yv = y.reshape(B, rpb, N).clone()
-        part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone()
+        part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone(memory_format=torch.contiguous_format)
         rope_axial_(part, cos, sin, r1 - r0, grid)
         yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
         y = yv.reshape(*x.shape[:-1], N)
@@ -66,6 +66,11 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
         out.copy_(y.reshape(out.shape))
         return out
     return y
+
+
+def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
+    h = linear(layernorm(x, ln[0], ln[1], ln[2]), w1, b1, ACT_GELU)
+    return linear(h, w2, b2, ACT_NONE, None, x)
 
 
 def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, residual=None):

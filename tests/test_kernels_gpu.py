@@ -308,6 +308,41 @@ def test_multimask_select(cuda, hw):
             assert torch.equal(g.cpu(), w), mode
 
 
+@pytest.mark.parametrize("C,M", [(144, 4096 + 77), (288, 1024 + 5), (144, 100), (288, 128)])
+def test_mlp_rows(cuda, C, M):
+    """vg_mlp_rows (bf16): LayerNorm -> fc1 -> exact-erf GELU -> fc2 -> + x in one launch, against the fp32 statement and against the three
+    HIP launches it replaces (same roundings of the LayerNorm output and of the hidden activation: a few bf16 steps apart at most)."""
+    from videoglamm_amd import _lib, ops
+    assert _lib.load().vg_mlp_rows_supported(144, 576) == 1 and _lib.load().vg_mlp_rows_supported(576, 2304) == 0       # (288: instantiated, not routed)
+    dt = torch.bfloat16
+    H = 4 * C
+    x = rnd(M, C, dtype=dt, seed=1, scale=2.0) + 0.5
+    ln = (1.0 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), 1e-6)
+    w1, b1 = rnd(H, C, dtype=dt, seed=4, scale=C ** -0.5), rnd(H, seed=5)
+    w2, b2 = rnd(C, H, dtype=dt, seed=6, scale=H ** -0.5), rnd(C, seed=7)
+    d = lambda t: t.to(cuda)      # noqa: E731
+    lnd = (d(ln[0]), d(ln[1]), ln[2])
+    y = ops.mlp_rows(d(x), lnd, d(w1), d(b1), d(w2), d(b2), force=True)
+    close(y, ref.mlp_rows(x, ln, w1, b1, w2, b2), **tol(dt, H))
+    h = ops.linear(ops.layernorm(d(x), lnd[0], lnd[1], lnd[2]), d(w1), d(b1), ops.ACT_GELU)
+    sep = ops.linear(h, d(w2), d(b2), residual=d(x))
+    dd = (y.float() - sep.float()).abs()
+    step = sep.float().abs().clamp_min(1e-2) * 2.0 ** -7
+    assert float((dd > step).float().mean()) < 1e-3, (float(dd.max()), float((dd > step).float().mean()))
+    # a row-strided input view (a channel slice of a wider tensor)
+    wide = torch.zeros(M, C + 16, dtype=dt, device=cuda)
+    wide[:, 8:8 + C] = d(x)
+    assert torch.equal(ops.mlp_rows(wide[:, 8:8 + C], lnd, d(w1), d(b1), d(w2), d(b2), force=True), y)
+    # one-hot probe of the column / hidden bookkeeping: W1 = W2^T = scaled identity blocks -> y = x + gelu(LN(x)[:, perm]) summed back
+    # (a swapped fragment order would move whole 4-column groups)
+    eye1 = torch.zeros(H, C, dtype=dt)
+    eye1[torch.arange(H), torch.arange(H) % C] = 1.0
+    eye2 = torch.zeros(C, H, dtype=dt)
+    eye2[torch.arange(H) % C, torch.arange(H)] = 0.25
+    y2 = ops.mlp_rows(d(x), lnd, d(eye1), d(b1 * 0), d(eye2), d(b2 * 0), force=True)
+    close(y2, ref.mlp_rows(x, ln, eye1, b1 * 0, eye2, b2 * 0), **tol(dt, 4))
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops

@@ -29,6 +29,8 @@ def _sig(lib):
         "vg_quantize_fp8_rows": ([P, L, P, L, P, L, I, I, P], c_int),
         "vg_gemm_f8": ([P, L, P, P, L, P, P, L, P, P, L, L, L, L, I, I, P], c_int),
         "vg_gemm_route": ([L, L, L, I, I, I], c_int),
+        "vg_mlp_rows_supported": ([I, I], c_int),
+        "vg_mlp_rows": ([P, L, P, L, P, P, F, P, P, P, P, L, I, I, I, P], c_int),
         "vg_gemm_rows": ([P, L, P, L, P, L, P, P, L, L, I, I, I, P, P, F, P, L, I, P, P, I, I, I, L, I, I, I, I, P], c_int),
         "vg_gemm_window": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),

@@ -223,7 +223,7 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
             heads, B = cols // ch, M // rpb
             yv = y.view(B, rpb, N)
             # (parity mode only: the strided head slices go through a contiguous copy — torch plumbing around vg_rope_axial)
-            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone()
+            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone(memory_format=torch.contiguous_format)
             rope_axial_(part, cos, sin, r1 - r0, grid)
             yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
             if out is not None:
@@ -259,6 +259,25 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
     rc = lib.vg_gemm_rows(_p(x2), lda, _p(w), w.stride(0), _p(o2), ldc, _p(_f32(bias)), _p(r2), ldr, M, N, K, act, _p(lw), _p(lb), eps,
                           _p(a2), lda2, rows2, _p(cs), _p(sn), int(cols), int(ch), int(rpb), int(sA), int(r0), int(r1), int(grid), BF16, _stream())
     _lib.check(rc, "vg_gemm_rows")
+    return out
+
+
+def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
+    """y = x + w2 @ gelu(w1 @ LayerNorm(x) + b1) + b2 — a pre-norm MLP block (Hiera's x + mlp(norm2(x))); ONE launch at the narrow bf16 width
+    vg_mlp_rows is routed for (C = 144), the separate launches otherwise (wider rows, the fp32 parity mode).  ln = (weight, bias, eps).
+    force: run the fused kernel on any width it has an instantiation for (C = 288: correct, measured slower than the three launches)."""
+    lib = _lib.load()
+    C, H = x.shape[-1], w1.shape[0]
+    ok = lib.vg_mlp_rows_supported(C, H) or (force and C in (144, 288) and H % 32 == 0)
+    if not (x.dtype == torch.bfloat16 and ok and w1.shape == (H, C) and w2.shape == (C, H)
+            and w1.is_contiguous() and w2.is_contiguous()):
+        h = _linear(layernorm(x, ln[0], ln[1], ln[2]), w1, b1, ACT_GELU)
+        return _linear(h, w2, b2, ACT_NONE, None, x)
+    x2, M, ldx = _rows2d(x)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    rc = lib.vg_mlp_rows(_p(x2), ldx, _p(out), C, _p(_f32(ln[0])), _p(_f32(ln[1])), float(ln[2]), _p(w1), _p(_f32(b1)), _p(w2), _p(_f32(b2)),
+                         M, C, H, BF16, _stream())
+    _lib.check(rc, "vg_mlp_rows")
     return out
 
 

@@ -180,8 +180,10 @@ class SAM2:
                                   scatter=True, residual=shortcut)
         else:
             x = self.lin(p + "attn.proj", o, residual=shortcut.view(B, Hs * Ws, do)).view(B, Hs, Ws, do)
-        hmid = self.lin(p + "mlp.layers.0", self.ln(p + "norm2", x, 1e-6), act=ops.ACT_GELU)
-        return self.lin(p + "mlp.layers.1", hmid, residual=x)
+        # x + mlp(norm2(x)): one launch at the widths of stages 1 and 2 (vg_mlp_rows; bf16), three launches otherwise (ops.mlp_rows falls back)
+        return ops.mlp_rows(x, (self.P.f32(self.p + p + "norm2.weight"), self.P.f32(self.p + p + "norm2.bias"), 1e-6),
+                            self.P.w(self.p + p + "mlp.layers.0"), self.P.b(self.p + p + "mlp.layers.0"),
+                            self.P.w(self.p + p + "mlp.layers.1"), self.P.b(self.p + p + "mlp.layers.1"))
 
     def forward_image(self, img, out=None):
         """SAM2Base.forward_image (Hiera + FpnNeck scalp=1 + conv_s0/s1) — R/modeling/sam2_base.py:465-477,
