@@ -311,7 +311,7 @@ def meter_decode_gemv(model, ops, reps=3):
         return None
     return rec[0][2], [1e3 * a.elapsed_time(b) for a, b, _ in rec]
 
-PMC_TAG = "r04_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
+PMC_TAG = "r05_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
 
 
 def quality(cfg, args, model, step, device):
@@ -341,7 +341,7 @@ def quality(cfg, args, model, step, device):
     sd = {k: v.float() for k, v in sd.items()}
     cfg32 = dict(cfg, forced_tokens={i: t for i, t in enumerate(ids[n_prompt:])})
     cfg32["llm"] = {k: v for k, v in cfg["llm"].items() if k not in ("decode_weights", "prefill_gemm")}
-    m32 = VideoGLaMMForCausalLM(sd, cfg32, torch_dtype=torch.float32, device=device)
+    m32 = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg32, torch_dtype=torch.float32, device=device))
     del sd
     images, context, sam, pids = make_inputs(cfg, args, 1, device)
     cap32 = m32.capture = {}
@@ -597,7 +597,7 @@ def main():
     cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
     t0 = time.time()
     sd = synth.device_state_dict(synth.manifest(cfg), device, torch.bfloat16)
-    model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=device, comm=comm)
+    model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=device, comm=comm))
     images, context, sam, ids = make_inputs(cfg, args, world, device)
     T = sam.shape[0]
     use_video = args.branch == "video"

@@ -36,7 +36,7 @@ def test_e2e_fp8_llm_path_vs_bf16(cuda, branch):
     S = 208 * te + ids.shape[1] - te
 
     def run(c):
-        m = VideoGLaMMForCausalLM(sd, c, torch_dtype=torch.bfloat16, device=cuda)
+        m = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, c, torch_dtype=torch.bfloat16, device=cuda))
         m.capture = {}
         out_ids, segs = m.inference([images], [context], [sam], ids, [(256, 256)], [hw], max_new_tokens=G, use_sam2_video_branch=branch)
         dec = m.P._decoder

@@ -36,7 +36,7 @@ def check(device, case):
     images, context = torch.randn(te, 3, 224, 224, generator=g), torch.randn(te, 3, 336, 336, generator=g)
     sam = torch.randn(T, 3, S, S, generator=g)
     ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, 76, (5,), generator=g)])
-    m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device)
+    m = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device=device))
     out_ids, segs = m.inference([images.to(device)], [context.to(device)], [sam.to(device)], ids[None], [(S, S)], [hw], max_new_tokens=6,
                                 use_sam2_video_branch=branch)
     ref_ids, ref_logits = _oracle(pipeline, sd, cfg, images, context, sam, out_ids[0], ids.numel(), hw, branch)

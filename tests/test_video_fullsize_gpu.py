@@ -13,6 +13,8 @@ import torch
 
 from oracle import sam2 as osam, seeded
 
+from videoglamm_amd import synth  # noqa: E402  (harness helpers: synthetic weights, the forced-[SEG] token hook)
+
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -115,7 +117,7 @@ def _build(bench, args, cuda, llm_extra=None):
         cfg["llm"] = dict(cfg["llm"], **llm_extra)
     cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
     sd = synth.device_state_dict(synth.manifest(cfg), cuda, torch.bfloat16)
-    model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=cuda)
+    model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=cuda))
     del sd
     images, context, sam, ids = bench.make_inputs(cfg, args, 1, cuda)
 
@@ -178,7 +180,7 @@ def test_c4_64_frames_8_objects_fp8_llm_path(cuda):
     torch.cuda.empty_cache()
     args16 = _bench_args(["--frames", "64", "--objects", "8"])[1]
     cfgb, mb, _, _, _ = _build(bench, args16, cuda)
-    mb.cfg["forced_tokens"] = {i: t for i, t in enumerate(gen)}                 # the bf16 LLM path teacher-forced to the fp8 run's ids
+    synth.install_forced_tokens(mb, {i: t for i, t in enumerate(gen)})                 # the bf16 LLM path teacher-forced to the fp8 run's ids
     idsb, mbf, eb, _ = run(mb, sam)
     assert idsb == ids64
     iou = (mbf & m64).sum(dim=(0, 2, 3)).double() / (mbf | m64).sum(dim=(0, 2, 3)).double().clamp_min(1)

@@ -13,6 +13,8 @@ import sys
 import pytest
 import torch
 
+from videoglamm_amd import synth  # noqa: E402  (harness helpers: synthetic weights, the forced-[SEG] token hook)
+
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +39,7 @@ def _build(bench, args, cuda, llm_extra=None):
         cfg["llm"] = dict(cfg["llm"], **llm_extra)
     cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
     sd = synth.device_state_dict(synth.manifest(cfg), cuda, torch.bfloat16)
-    model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=cuda)
+    model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=cuda))
     del sd
     images, context, sam, ids = bench.make_inputs(cfg, args, 1, cuda)
 
@@ -74,7 +76,7 @@ def test_c4_shape_fp8_llm_path_vs_bf16(cuda):
     del model, cap
     torch.cuda.empty_cache()
     cfg8, model8, _, _ = _build(bench, args, cuda, llm_extra=dict(prefill_gemm="fp8", decode_weights="fp8"))
-    model8.cfg["forced_tokens"] = {i: t for i, t in enumerate(gen)}            # teacher-forced to the bf16 run's ids
+    synth.install_forced_tokens(model8, {i: t for i, t in enumerate(gen)})            # teacher-forced to the bf16 run's ids
     cap8 = model8.capture = {}
     images, context, sam, ids2 = bench.make_inputs(cfg8, args, 1, cuda)
     out8, _ = model8.inference([images], [context], [sam], ids2, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=args.max_new_tokens)

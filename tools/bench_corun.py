@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 cfg = synth.videoglamm_llama3_8b()
 sd = synth.device_state_dict(synth.manifest(cfg), dev, torch.bfloat16)
-model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev)
+model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev))
 images, context, sam, ids = bench.make_inputs(cfg, args, 1, dev)
 visual = torch.zeros(208 * args.te, cfg["llm"]["hidden"], dtype=torch.bfloat16, device=dev)
 generate(model.P, model.cfg, model.towers, images, context, ids[0].cpu(), 2, visual=visual)      # prefill + graph capture

@@ -1,6 +1,6 @@
 """Decode-loop microbenchmark: Llama-3-8B (synthetic weights), prefill of S random embeddings, then G graph-replayed
 decode steps; the 16 GB of weights stream from HBM every token (no MALL flattery as in a single-matrix loop).
-usage: python tools/bench_decode.py [S=1697] [G=32]      env: VG_DECODE_FUSED=0/1, VG_DEC_BPC"""
+usage: python tools/bench_decode.py [S=1697] [G=32]      env: VG_DECODE_FUSED=0/1"""
 import os
 import sys
 import time

@@ -21,7 +21,7 @@ torch.set_grad_enabled(False)
 cfg = synth.videoglamm_llama3_8b()
 cfg["forced_tokens"] = {8: cfg["seg_token_idx"]}
 sd = synth.device_state_dict(synth.manifest(cfg), dev, torch.bfloat16)
-model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev)
+model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev))
 images, context, sam, ids = bench.make_inputs(cfg, args, 1, dev)
 
 
@@ -51,7 +51,7 @@ t_iv2, _ = timed(lambda: model.towers.iv2(images.view(images.shape[0] // 4, 4, *
 t_clip, _ = timed(lambda: model.towers.clip(context))
 t_gen0, _ = timed(lambda: generate(model.P, model.cfg, model.towers, images, context, ids[0].cpu(), 0, visual=visual))
 t_gen, (out_ids, emb) = timed(lambda: generate(model.P, model.cfg, model.towers, images, context, ids[0].cpu(), args.max_new_tokens,
-                                                visual=visual, forced_tokens=cfg["forced_tokens"]))
+                                                visual=visual, token_hook=synth.forced_tokens_hook(cfg["forced_tokens"])))
 t_hiera, feats = timed(lambda: model.sam2.hiera_frames(sam, None))
 t_fw, _ = timed(lambda: ops.threshold(model.sam2.framewise_branch(sam, emb, (args.src, args.src), frame_feats=feats)[0]).cpu())
 print(f"towers.encode {t_enc:7.2f} ms  (iv2 {t_iv2:.2f}, clip {t_clip:.2f})")

@@ -49,7 +49,7 @@ for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
     if ids16 is not None:
         c["forced_tokens"] = {i: t for i, t in enumerate(ids16)}
     sd = sd16 if dt == torch.bfloat16 else {k: v.float() for k, v in sd16.items()}
-    m = VideoGLaMMForCausalLM(sd, c, torch_dtype=dt, device=dev)
+    m = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, c, torch_dtype=dt, device=dev))
     cap = m.capture = {}
     out_ids, _ = m.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=32)
     if ids16 is None:

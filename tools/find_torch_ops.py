@@ -22,7 +22,7 @@ torch.set_grad_enabled(False)
 cfg = synth.videoglamm_llama3_8b()
 cfg["forced_tokens"] = {8: cfg["seg_token_idx"]} if args.objects == 1 else {4 + 3 * i: cfg["seg_token_idx"] for i in range(args.objects)}
 sd = synth.device_state_dict(synth.manifest(cfg), dev, torch.bfloat16)
-model = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev)
+model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev))
 images, context, sam, ids = bench.make_inputs(cfg, args, 1, dev)
 step = lambda: model.inference([images], [context], [sam], ids, [(1024, 1024)], [(args.src, args.src)], max_new_tokens=args.max_new_tokens,  # noqa: E731
                                use_sam2_video_branch=branch == "video")

@@ -24,7 +24,7 @@ images, context = torch.randn(te, 3, 224, 224, generator=g).to(dev), torch.randn
 sam = torch.randn(T, 3, S, S, generator=g).to(dev)
 ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, cfg["llm"]["vocab"] - 2, (30,), generator=g)])[None]
 forced = {3 + 4 * i: seg for i in range(objects)}
-base = VideoGLaMMForCausalLM(sd, dict(cfg, forced_tokens=forced), torch_dtype=torch.bfloat16, device=dev)
+base = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, dict(cfg, forced_tokens=forced), torch_dtype=torch.bfloat16, device=dev))
 out_ids, segs = base.inference([images], [context], [sam], ids, [(S, S)], [(src, src)], max_new_tokens=new)
 emitted = out_ids[0, ids.shape[1]:].tolist()
 ref = np.stack([np.stack([segs[0][t][k] for k in sorted(segs[0][t])]) for t in sorted(segs[0])])
@@ -32,7 +32,7 @@ del base
 for name, llm in (("fp8 decode weights", dict(cfg["llm"], decode_weights="fp8")), ("fp8 prefill + decode weights", dict(cfg["llm"], decode_weights="fp8", prefill_gemm="fp8"))):
     sd["_"] = None
     sd.pop("_")
-    m = VideoGLaMMForCausalLM(sd, dict(cfg, llm=llm, forced_tokens={i: t for i, t in enumerate(emitted)}), torch_dtype=torch.bfloat16, device=dev)
+    m = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, dict(cfg, llm=llm, forced_tokens={i: t for i, t in enumerate(emitted)}), torch_dtype=torch.bfloat16, device=dev))
     if hasattr(m.P, "_decoder"):
         del m.P._decoder
     o2, s2 = m.inference([images], [context], [sam], ids, [(S, S)], [(src, src)], max_new_tokens=new)

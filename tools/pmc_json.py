@@ -11,9 +11,10 @@ import sys
 CLASSES = [
     ("gemm_glds", r"gemm_tile_glds_kernel<unsigned short"),
     ("gemm_k64b", r"gemm_tile_k64b_kernel<unsigned short|gemm_tile_ring64_kernel<unsigned short"),
-    ("gemm_w128", r"gemm_tile_w128x8_kernel<unsigned short|gemm_tile_p8_kernel<unsigned short"),      # the 256x256 route: r04 the phase-split kernel
+    ("gemm_w128", r"gemm_tile_p8_kernel<unsigned short"),      # the 256x256 route (label kept from the kernel it replaced in r04)
+    ("gemm_p8n", r"gemm_tile_p8n_kernel<unsigned short"),      # r05: the 256x192 route
     ("gemm_s128", r"gemm_tile_s128_kernel<unsigned short"),
-    ("gemm_mlp", r"hiera_mlp_kernel"),
+    ("mlp_rows", r"mlp_rows_kernel"),
     ("decode_gemv_glu", r"decode_gemv_fast_kernel<unsigned short, unsigned short, true"),
     ("attn_d64", r"attn_kernel<unsigned short, 64,"),
     ("attn_d96", r"attn_kernel<unsigned short, 96,"),
@@ -42,7 +43,7 @@ def main():
         f = sum(fetch[n][0] * fetch[n][1] for n in names) / nf
         nw = sum(write[n][0] for n in names if n in write)
         w = sum(write[n][0] * write[n][1] for n in names if n in write) / max(nw, 1)
-        out = {"round": 4, "workload": workload, "command": command, "fetch_correction": 2.0, "kernel": key, "kernel_names": sorted(n[:120] for n in names),
+        out = {"round": 5, "workload": workload, "command": command, "fetch_correction": 2.0, "kernel": key, "kernel_names": sorted(n[:120] for n in names),
                "dispatches": nf, "FETCH_SIZE_KB_avg_per_dispatch": round(f, 1), "WRITE_SIZE_KB_avg_per_dispatch": round(w, 1),
                "traffic_bytes_per_launch": round((2.0 * f + w) * 1000.0)}
         with open(os.path.join(outdir, f"{tag}_pmc_{key}.json"), "w") as fh:

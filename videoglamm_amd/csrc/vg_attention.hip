@@ -1018,11 +1018,11 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   hipStream_t st = (hipStream_t)stream;
   // (measured: a 1-wave workgroup for <= 32 query rows is SLOWER — 50 vs 31 us per decode launch — because the
   // K/V tile staging, not the MFMA work, dominates a few-row block and 64 threads stage 4x slower than 256)
-  // long bf16 sequences (LLM prefill, Hiera's global blocks): 8 waves = 256 query rows share every staged K/V tile (VG_ATTN_NW8, A/B knob)
+  // long bf16 sequences (LLM prefill, Hiera's global blocks): 8 waves = 256 query rows share every staged K/V tile
   // measured r02: +5 % on Hiera's global blocks (4096^2, d = 72), -6 % on the causal LLM prefill (coarser diagonal), -12 % at S = 1025
-  static const int nw8 = getenv("VG_ATTN_NW8") ? atoi(getenv("VG_ATTN_NW8")) : 1;
-  // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD (VG_ATTN_KS2, A/B knob)
-  static const int ks2 = getenv("VG_ATTN_KS2") ? atoi(getenv("VG_ATTN_KS2")) : 1;
+  constexpr int nw8 = 1;
+  // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD
+  constexpr int ks2 = 1;
   int rc;
   if (DV != D) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);

@@ -322,11 +322,9 @@ static int launch_decode_gemv(DecGemvArgs p, hipStream_t st) {
   constexpr int KPC = 16 / sizeof(T);
   static int bpc = -1;
   if (bpc < 0) {
-    // max workgroups per CU the row pairs are spread over (tuning knob).  2 = what is resident (these kernels take 254 VGPRs): with 4 the q|k|v
+    // max workgroups per CU the row pairs are spread over (measured constant).  2 = what is resident (these kernels take 254 VGPRs): with 4 the q|k|v
     // projection ran 768 workgroups in one and a half rounds (r03: 3.23 -> 3.205 ms per token on C2)
-    const char* e = getenv("VG_DEC_BPC");
-    bpc = e ? atoi(e) : 2;
-    if (bpc < 1) bpc = 1;
+    bpc = 2;
   }
   const int npair = GLU ? p.N : (p.N + 1) / 2;
   const int maxw = 256 * bpc * 4;
@@ -361,9 +359,7 @@ template <typename TO, bool GLU>
 static int launch_decode_gemv_w8(DecGemvArgs p, hipStream_t st) {
   static int bpc = -1;
   if (bpc < 0) {
-    const char* e = getenv("VG_DEC_BPC");
-    bpc = e ? atoi(e) : 4;
-    if (bpc < 1) bpc = 1;
+    bpc = 4;
   }
   const int npair = GLU ? p.N : (p.N + 1) / 2;
   const int maxw = 256 * bpc * 4;
@@ -1066,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void decode_layer_kernel(DecLayerArgs q) {
 }
 
 static int dec_role_blocks(int npair, int* ppw_out) {     // launch_decode_gemv's split
-  static const int bpc = [] { const char* e = getenv("VG_DEC_BPC"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+  constexpr int bpc = 2;
   const int maxw = 256 * bpc * 4;
   int ppw = (npair + maxw - 1) / maxw;
   for (int c = ppw; c <= 2 * ppw; ++c)

@@ -301,8 +301,7 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
   TO* yo = (TO*)y;
   const unsigned pgrid = 256 * 8;   // persistent cap of the register-resident path: 8 workgroups per CU
   if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2) {
-    static const bool short_rows = !getenv("VG_NORM_SHORT") || atoi(getenv("VG_NORM_SHORT")) != 0;
-    if (short_rows && vec && rows >= 1024 && (((uintptr_t)w | (uintptr_t)b) % 16 == 0)) {
+    if (vec && rows >= 1024 && (((uintptr_t)w | (uintptr_t)b) % 16 == 0)) {
       // tower / LLM-prefill widths with a few thousand rows: norm_kernel's per-workgroup prologue (64 weight / bias registers per lane, loaded
       // before the first row) outweighs the 4 rows a workgroup then normalises — 23 MB in 42 us at InternVideo2's 4100 x 1408 (r02 trace)
       const bf16_t* xs = (const bf16_t*)x;
@@ -312,7 +311,7 @@ static void launch_norm_t(const void* x, int64_t ldx, const float* w, const floa
       if (C == 4096) return launch_norm_short<RMS, 64, 8>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
       if (C == 3072) return launch_norm_short<RMS, 64, 6>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);
     }
-    if (short_rows && vec && rows >= 4096 && (((uintptr_t)w | (uintptr_t)b) % 16 == 0)) {      // Hiera's LayerNorm widths, every lane loaded
+    if (vec && rows >= 4096 && (((uintptr_t)w | (uintptr_t)b) % 16 == 0)) {      // Hiera's LayerNorm widths, every lane loaded
       const bf16_t* xs = (const bf16_t*)x;
       bf16_t* ys = (bf16_t*)y;
       if (C == 576) return launch_norm_short<RMS, 8, 9>(xs, ldx, w, b, ys, ldy, rows, C, eps, st);

@@ -101,6 +101,9 @@ class VideoGLaMMForCausalLM:
         # diagnostics only: when set to a dict, inference() leaves the fp32 mask logits ("logits", device), the [SEG] embeddings
         # ("emb") and the model's own per-step argmaxes ("argmax") in it (bench.py's self-check, tests)
         self.capture = None
+        # optional callable (step, emitted id) -> replacement id | None, applied after the lm_head + argmax of every decode step (vlm.generate):
+        # teacher forcing in the parity tests, synth.install_forced_tokens for synthetic-weight runs.  None = plain greedy decoding.
+        self.token_hook = None
         # diagnostics only: when set to a list, the stages of inference() append (name, host time) after a device sync
         # (bench.py's per-stage replicated / sharded split; meaningful with VG_HIERA_START=serial)
         self.stages = None
@@ -249,7 +252,7 @@ class VideoGLaMMForCausalLM:
         ctx = context_images[0] if context_images is not None else None
         out_ids, emb = generate(self.P, self._live_cfg(), self.towers, images[0].to(self.device), None if ctx is None else ctx.to(self.device),
                                 input_ids[0].cpu(), max_new_tokens, self._eos(),
-                                forced_tokens=self.cfg.get("forced_tokens"), after_prefill=after_prefill, comm=self.comm,
+                                token_hook=self.token_hook, after_prefill=after_prefill, comm=self.comm,
                                 trace=self.capture, stages=self.stages)
         if self.capture is not None:
             self.capture["emb"] = emb

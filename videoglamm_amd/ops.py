@@ -127,7 +127,7 @@ def _linear_splitk(lib, x, x2, M, lda, w, bias, act, gamma, residual, odt, ks, o
 
 
 import os as _os
-_TAILSPLIT = _os.environ.get("VG_GEMM_TAILSPLIT", "1") != "0"
+_TAILSPLIT = True
 
 
 def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=None, out=None, glu=False):
@@ -346,7 +346,7 @@ def _causal_code(causal, window):
     return int(window) if window else 1
 
 
-_SPLIT_WG_D256 = int(_os.environ.get("VG_ATTN_SPLIT_WG_D256", "256"))   # workgroups the KV split aims for at head dim 256: one 8-wave workgroup per CU (measured r02: 256 beats 384 / 512 / 1024 by 1.2-2.5x, the fp32 partials are the cost)
+_SPLIT_WG_D256 = 256   # workgroups the KV split aims for at head dim 256: one 8-wave workgroup per CU (measured r02: 256 beats 384 / 512 / 1024 by 1.2-2.5x, the fp32 partials are the cost)
 
 
 def attention(q, k, v, scale, causal=False, window=0):

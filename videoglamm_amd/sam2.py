@@ -14,9 +14,10 @@ import torch
 from . import ops
 
 NO_OBJ_SCORE = -1024.0  # R/modeling/sam2_base.py:17
-_SELFATTN_FUSED = os.environ.get("VG_SELFATTN_FUSED", "1") == "1"     # memory self-attention: fused q|k|v projection + one RoPE launch (A/B knob)
-_MEMENC_FUSED = os.environ.get("VG_MEMENC_FUSED", "1") == "1"         # memory encoder: fused conv + LayerNorm2d + GELU stages (A/B knob)
-_MEMATTN_LOWRANK = os.environ.get("VG_MEMATTN_LOWRANK", "1") == "1"   # memory cross-attention: v-projection behind the attention (A/B knob)
+_SELFATTN_FUSED = True     # memory self-attention: fused q|k|v projection + one RoPE launch
+_MEMENC_FUSED = True       # memory encoder: fused conv + LayerNorm2d + GELU stages
+_MEMATTN_LOWRANK = True    # memory cross-attention: v-projection behind the attention
+# (module flags, not environment knobs: tests/test_host_sam2.py switches them off together to run the reference's own order of operations)
 _MEMBANK = True      # r05: the propagation's memories and object pointers live in ONE preallocated bank per clip (no per-frame cat / copies) and the
 #                      memory attention runs on the fused short-row GEMMs (vg_gemm_rows); False = r04's per-frame assembly (tests switch it off together
 #                      with the flags above to run the reference's own order of operations)
@@ -86,8 +87,7 @@ class SAM2:
         # frames batched per Hiera launch group (r02, 32-frame clip: 16 frames 145.8 ms, 8 frames 156.2, 4 frames 171.8: bigger
         # batches fill the tails of the 128-tile grids) and per framewise mask-decoder launch group (its GEMMs are M = 4096 rows
         # per (frame, object): the more pairs per launch the better)
-        self.frame_chunk = int(os.environ.get("VG_FRAME_CHUNK", "16"))
-        self.decode_chunk = int(os.environ.get("VG_DECODE_CHUNK", "128"))
+        self.frame_chunk, self.decode_chunk = 16, 128
 
     def hiera_frames(self, images, frames=None):
         """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""

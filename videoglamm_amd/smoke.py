@@ -32,7 +32,7 @@ def run():
     images, context = torch.randn(te, 3, 224, 224, generator=g), torch.randn(te, 3, 336, 336, generator=g)
     sam = torch.randn(T, 3, S, S, generator=g)
     ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, 76, (6,), generator=g)])
-    m = VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device="cuda:0")
+    m = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.float32, device="cuda:0"))
     for branch in (False, True):
         out_ids, segs = m.inference([images.cuda()], [context.cuda()], [sam.cuda()], ids[None], [(S, S)], [hw], max_new_tokens=5,
                                     use_sam2_video_branch=branch)

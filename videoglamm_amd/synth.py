@@ -269,3 +269,20 @@ def device_state_dict(man, device, dtype, seed=0):
     if k in sd:
         sd[k] = torch.full_like(sd[k], 4.0)  # random-init SAM2 otherwise predicts "no object" everywhere
     return sd
+
+
+# ---- decode-time token hook for synthetic weights ------------------------------------------------------
+def forced_tokens_hook(mapping):
+    """{decode step: token id} -> a VideoGLaMMForCausalLM.token_hook: random-init weights never emit [SEG], so benchmarks and whole-workload
+    tests replace the emitted token at fixed steps (after the full lm_head + argmax: no work is skipped) — and parity tests teacher-force a
+    second model to the first one's ids the same way.  None / {} -> None (plain greedy decoding)."""
+    if not mapping:
+        return None
+    table = {int(k): int(v) for k, v in mapping.items()}
+    return lambda step, tok: table.get(step)
+
+
+def install_forced_tokens(model, mapping=None):
+    """model.token_hook = forced_tokens_hook(mapping); mapping defaults to the harness's cfg["forced_tokens"] entry.  Returns the model."""
+    model.token_hook = forced_tokens_hook(model.cfg.get("forced_tokens") if mapping is None else mapping)
+    return model

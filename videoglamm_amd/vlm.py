@@ -432,12 +432,13 @@ def stage_mark(stages, name):
 
 
 def generate(params, cfg, towers, images, context_images, input_ids, max_new_tokens, eos_token_id=None, visual=None,
-             forced_tokens=None, after_prefill=None, comm=None, trace=None, stages=None):
+             token_hook=None, after_prefill=None, comm=None, trace=None, stages=None):
     """Steps A–D of VideoGLaMM_SAM2.inference_* (R/model/VideoGLaMM.py:609-655 / 781-831) with encode-once +
     KV-cache scheduling.  The hidden state the reference gathers for a [SEG] at output position p is the
     final-norm state of position p-1 = the row that produced the token, captured here as it is
-    emitted.  forced_tokens {step: id} overrides the emitted token at given steps AFTER the full lm_head+argmax
-    has been computed (synthetic-weight benchmarks need a [SEG] at a known position; no work is skipped).
+    emitted.  token_hook(step, token_id) -> token_id | None: called with every emitted token AFTER the full lm_head + argmax (the place of a
+    logits processor in HF generate()); a returned id replaces the token (teacher forcing in tests; synth.forced_tokens_hook for the synthetic-weight
+    benchmark, whose random weights never emit [SEG] — no work is skipped).
     trace: optional dict; trace["argmax"] receives the model's own argmax of every step (before any forcing).
     eos_token_id: one id or several (HF generate() stops on any id of generation_config.eos_token_id).
     input_ids: host int64 [L] -> (output_ids host int64 [L+G], pred_embeddings device [N,256])."""
@@ -471,9 +472,11 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
         nxt = int(dec.tok_dev[0])
         if trace is not None:
             trace.setdefault("argmax", []).append(nxt)
-        if forced_tokens and step in forced_tokens:
-            nxt = int(forced_tokens[step])
-            dec.tok_dev.fill_(nxt)
+        if token_hook is not None:
+            repl = token_hook(step, nxt)
+            if repl is not None and int(repl) != nxt:
+                nxt = int(repl)
+                dec.tok_dev.fill_(nxt)
         ids.append(nxt)
         if nxt in eos or step == max_new_tokens - 1:
             break
