@@ -230,6 +230,10 @@ int vg_rmsnorm(const void* x, int64_t ldx, const float* w, void* y, int64_t ldy,
 int vg_twoway_image_update(const void* xpe, const void* x, const void* u2, const float* c2, const void* w2t, const float* bo,
                            const float* ln_w, const float* ln_b, float eps, const void* pe, void* x_out, void* xpe_out,
                            int N, int x_instances, int P, int nt, int TP, int dtype, vg_stream_t stream);
+/* Token-side layout of the fused two-way path: gather = 0: x [N, nt, 128] -> out [N, 8, TP, 128], row (h, t) = head h's 16 channels of token t,
+ * zeros elsewhere (the per-head products of Attention.forward, sam/transformer.py:236-260, as ONE small GEMM on block-diagonal rows);
+ * gather = 1: the inverse read — x [N, 8, TP, 128] -> out [N, nt, 128], channel c of token t from row (c / 16, t).  bf16 / fp32. */
+int vg_heads_blockdiag(const void* x, void* out, int N, int nt, int TP, int gather, int dtype, vg_stream_t stream);
 
 /* Output upscaling + hypernetwork product of the mask decoder, fused (r04): MaskDecoder.predict_masks
  * (R/model/segment_anything_2/sam2/modeling/sam/mask_decoder.py:225-245): ConvTranspose2d(256 -> 64, k2 s2) + feat_s1 -> LayerNorm2d -> GELU ->

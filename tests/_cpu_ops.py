@@ -68,6 +68,18 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
     return y
 
 
+def heads_blockdiag(x, TP):
+    N, nt = x.shape[0], x.shape[1]
+    bd = torch.zeros(N, 8, TP, 8, 16, dtype=x.dtype, device=x.device)
+    torch.diagonal(bd, dim1=1, dim2=3)[:, :nt].copy_(x.view(N, nt, 8, 16).permute(0, 1, 3, 2))
+    return bd.view(N * 8 * TP, 128)
+
+
+def heads_blockdiag_gather(full, N, nt, TP):
+    o_full = full.view(N, 8, TP, 8, 16)
+    return torch.diagonal(o_full, dim1=1, dim2=3)[:, :nt].permute(0, 1, 3, 2).reshape(N, nt, 128)
+
+
 def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
     h = linear(layernorm(x, ln[0], ln[1], ln[2]), w1, b1, ACT_GELU)
     return linear(h, w2, b2, ACT_NONE, None, x)

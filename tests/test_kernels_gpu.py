@@ -343,6 +343,19 @@ def test_mlp_rows(cuda, C, M):
     close(y2, ref.mlp_rows(x, ln, eye1, b1 * 0, eye2, b2 * 0), **tol(dt, 4))
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_heads_blockdiag(cuda, dtype):
+    """the token side's per-head block-diagonal layout and its inverse read (vg_heads_blockdiag), against the torch.diagonal statement"""
+    from videoglamm_amd import ops
+    for N, nt, TP in ((3, 9, 16), (1, 7, 8), (5, 8, 8), (2, 16, 16)):
+        x = rnd(N, nt, 128, dtype=dtype, seed=N + nt)
+        bd = ops.heads_blockdiag(x.to(cuda), TP)
+        assert torch.equal(bd.cpu(), ref.heads_blockdiag(x, TP))
+        full = rnd(N * 8 * TP, 128, dtype=dtype, seed=7)
+        assert torch.equal(ops.heads_blockdiag_gather(full.to(cuda), N, nt, TP).cpu(), ref.heads_blockdiag_gather(full, N, nt, TP))
+        assert torch.equal(ops.heads_blockdiag_gather(bd, N, nt, TP).cpu(), x)
+
+
 def test_gemm_transpose_detect(cuda):
     """A = I against an asymmetric W catches a swapped C layout (guide §3)."""
     from videoglamm_amd import ops
@@ -436,6 +449,26 @@ def test_attention_dv(cuda, dtype, B, Sq, Skv, D, DV):
         wv, bv = rnd(D, DV, seed=4, scale=DV ** -0.5), rnd(D, seed=5)
         full = ops.attention(q.to(cuda), k.to(cuda), ops.linear(v.to(cuda), wv.to(cuda), bv.to(cuda)), D ** -0.5)
         close(ops.linear(o, wv.to(cuda), bv.to(cuda)), full.cpu(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_dv_every_tail(cuda, dtype):
+    """the fp32 DV instantiation once mis-scored a key when Skv % 32 was in [28, 31] (worked around by the padded-V route in
+    ops.attention_dv; the generic V fetch reads a clamped last row since).  Sweep EVERY residue of the sequence end inside a 64-key tile — the
+    video branch reaches Skv = 4 P + n x 4096 with P = 1 ... 16 pointers, i.e. residues 4, 8, ..., 60, 0 — in both dtypes, with and without
+    the KV split (Skv < 512: one split; >= 512: several), with a large value on the LAST key so that a dropped or duplicated tail key shows."""
+    from videoglamm_amd import ops
+    D, DV, Sq = 256, 64, 192
+    q = rnd(1, Sq, 1, D, dtype=dtype, seed=1)
+    for base in (64, 1024):
+        for r in range(64):
+            Skv = base + r
+            k, v = rnd(1, Skv, 1, D, dtype=dtype, seed=2 + r), rnd(1, Skv, 1, DV, dtype=dtype, seed=3 + r)
+            v[:, -1] += 8.0
+            k[:, -1] = q[:, 7] * 0.5                    # the last key matters to at least one query
+            o = ops.attention_dv(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5)
+            t = dict(rtol=1e-3, atol=3e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+            close(o, ref.attention(q, k, v, D ** -0.5), **t)
 
 
 @pytest.mark.parametrize("dtype", DT)

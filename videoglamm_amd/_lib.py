@@ -50,6 +50,7 @@ def _sig(lib):
         "vg_layernorm": ([P, L, P, P, P, L, L, I, F, I, I, P], c_int),
         "vg_mask_upscale": ([P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P], c_int),
         "vg_twoway_image_update": ([P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P], c_int),
+        "vg_heads_blockdiag": ([P, P, I, I, I, I, I, P], c_int),
         "vg_rmsnorm": ([P, L, P, P, L, L, I, F, I, I, P], c_int),
         "vg_axpby": ([P, P, P, L, F, F, L, I, I, I, P], c_int),
         "vg_activation": ([P, P, L, I, I, I, P], c_int),

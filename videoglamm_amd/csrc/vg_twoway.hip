@@ -456,3 +456,40 @@ extern "C" int vg_mask_upscale(const void* x, const void* w0, const float* b0, c
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// ---- token-side layout helpers of the fused two-way path (r05): the per-head block-diagonal form the small GEMMs work on
+// (videoglamm_amd/sam2.py:_heads_bd) and its inverse, one launch each (torch.zeros + a strided copy / a strided copy + reshape before)
+namespace {
+__global__ __launch_bounds__(256) void heads_bd_kernel(const void* x, void* out, int64_t n, int nt, int TP, int dt) {
+  // out [N, 8, TP, 128]: row (h, t) holds head h's 16 channels of token t (x [N, nt, 128]), zeros elsewhere
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i & 127);
+    int64_t r = i >> 7;
+    const int t = (int)(r % TP); r /= TP;
+    const int h = (int)(r & 7);
+    const int64_t nn = r >> 3;
+    const float v = ((c >> 4) == h && t < nt) ? ld_any(x, (nn * nt + t) * 128 + c, dt) : 0.f;
+    st_any(out, i, dt, v);
+  }
+}
+__global__ __launch_bounds__(256) void heads_bd_gather_kernel(const void* full, void* out, int64_t n, int nt, int TP, int dt) {
+  // out [N, nt, 128]: channel c of token t = full [N, 8, TP, 128] at row (c / 16, t), channel c
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i & 127);
+    const int64_t r = i >> 7;
+    const int t = (int)(r % nt);
+    const int64_t nn = r / nt;
+    st_any(out, i, dt, ld_any(full, ((nn * 8 + (c >> 4)) * TP + t) * 128 + c, dt));
+  }
+}
+}  // namespace
+
+extern "C" int vg_heads_blockdiag(const void* x, void* out, int N, int nt, int TP, int gather, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && out && N > 0 && nt > 0 && nt <= TP && (dtype == VG_BF16 || dtype == VG_F32), VG_ERR_ARG, "vg_heads_blockdiag: bad args");
+  const int64_t n = gather ? (int64_t)N * nt * 128 : (int64_t)N * 8 * TP * 128;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (gather) heads_bd_gather_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, n, nt, TP, dtype);
+  else heads_bd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, n, nt, TP, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -281,6 +281,25 @@ def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
     return out
 
 
+def heads_blockdiag(x, TP):
+    """[N, nt, 128] -> block-diagonal [N * 8 * TP, 128]: row (h, t) holds head h's 16 channels of token t, zeros elsewhere (vg_heads_blockdiag)."""
+    x = x.contiguous()
+    N, nt, C = x.shape
+    assert C == 128 and nt <= TP
+    out = torch.empty(N * 8 * TP, 128, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().vg_heads_blockdiag(_p(x), _p(out), N, nt, TP, 0, _dt(x), _stream()), "vg_heads_blockdiag")
+    return out
+
+
+def heads_blockdiag_gather(full, N, nt, TP):
+    """the inverse read: full [N * 8 * TP, 128] (rows (h, t)) -> [N, nt, 128], head h's channels of token t from row (h, t)."""
+    full = full.contiguous()
+    assert full.numel() == N * 8 * TP * 128
+    out = torch.empty(N, nt, 128, dtype=full.dtype, device=full.device)
+    _lib.check(_lib.load().vg_heads_blockdiag(_p(full), _p(out), N, nt, TP, 1, _dt(full), _stream()), "vg_heads_blockdiag")
+    return out
+
+
 _ZROWS = {}
 
 

@@ -122,12 +122,12 @@ class SAM2:
     def ln(self, name, x, eps=1e-5, **kw):
         return ops.layernorm(x, self.P.f32(self.p + name + ".weight"), self.P.f32(self.p + name + ".bias"), eps, **kw)
 
-    def mlp(self, name, x, n, act=ops.ACT_RELU, sigmoid_output=False, out_dtype=None):
-        """R/modeling/sam2_utils.py:108-132."""
+    def mlp(self, name, x, n, act=ops.ACT_RELU, sigmoid_output=False, out_dtype=None, out=None):
+        """R/modeling/sam2_utils.py:108-132.  out: optional destination of the last layer (a row-strided 2-D view)."""
         for i in range(n):
             last = i == n - 1
             x = self.lin(f"{name}.layers.{i}", x, act=(ops.ACT_SIGMOID if (last and sigmoid_output) else (ops.ACT_NONE if last else act)),
-                         out_dtype=out_dtype if last else None)
+                         out_dtype=out_dtype if last else None, out=out if last else None)
         return x
 
     # ------------------------------------------------------------------ S1 Hiera + FPN
@@ -235,6 +235,15 @@ class SAM2:
 
     def sparse_prompt(self, n, text_embeds, with_empty_point):
         """PromptEncoder.forward sparse part — prompt_encoder.py:143-189 (+ sam2_base.py:310-313 padding points)."""
+        if with_empty_point and text_embeds is None:
+            # the tracked frames' prompt (two padding points, no text) is a constant of the model: made once per object count, and mask_decoder
+            # recognises it (its token tensor is then a constant too — no per-frame cat / copy)
+            def make():
+                nap = self.P.t(self.p + "sam_prompt_encoder.not_a_point_embed.weight")
+                return nap.view(1, 1, 256).expand(n, 2, 256).contiguous()
+            t = self.P.const(("sparse_empty", n), make)
+            self.__dict__.setdefault("_const_sparse", set()).add(t.data_ptr())
+            return t
         parts = []
         if with_empty_point:
             nap = self.P.t(self.p + "sam_prompt_encoder.not_a_point_embed.weight")
@@ -286,11 +295,8 @@ class SAM2:
     #                    GEMMs, the per-head softmax, the residual, LayerNorm and the + pe of the next pass in one kernel.
     # The k / v / q projections of the 4096 image rows (5 x 4096 x 256 x 128 MACs per block) are gone; the token side keeps the library's small GEMMs.
     def _heads_bd(self, x, TP):
-        """[N, nt, 128] -> block-diagonal [N * 8 * TP, 128]: row (h, t) holds head h's 16 channels of token t, zeros elsewhere."""
-        N, nt = x.shape[0], x.shape[1]
-        bd = torch.zeros(N, 8, TP, 8, 16, dtype=x.dtype, device=x.device)
-        torch.diagonal(bd, dim1=1, dim2=3)[:, :nt].copy_(x.view(N, nt, 8, 16).permute(0, 1, 3, 2))
-        return bd.view(N * 8 * TP, 128)
+        """[N, nt, 128] -> block-diagonal [N * 8 * TP, 128]: row (h, t) holds head h's 16 channels of token t, zeros elsewhere (one launch)."""
+        return ops.heads_blockdiag(x, TP)
 
     def _tw_const(self, name, kind):
         w = lambda n: self.P.sd[self.p + name + n + ".weight"].float()      # noqa: E731
@@ -312,8 +318,8 @@ class SAM2:
         # instance i attends image i % Bi: one attention call per group of Bi instances (Bi = N after the first block: a single call)
         zn = [ops.attention(U[g], xpe.view(Bi, P, 1, 256), x.view(Bi, P, 1, 256), 1.0) for g in range(N // Bi)]     # softmax-weighted means of the image rows
         zn = zn[0] if len(zn) == 1 else torch.cat(zn, dim=0)
-        o_full = self.lin(name + ".v_proj", zn.view(N * NC, 256)).view(N, 8, TP, 8, 16)            # (+ bv: the weights of a (h, t) sum to one)
-        o = torch.diagonal(o_full, dim1=1, dim2=3)[:, :nt].permute(0, 1, 3, 2).reshape(N, nt, 128)  # head h's channels of row (h, t)
+        o_full = self.lin(name + ".v_proj", zn.view(N * NC, 256))                                   # (+ bv: the weights of a (h, t) sum to one)
+        o = ops.heads_blockdiag_gather(o_full, N, nt, TP)                                           # head h's channels of row (h, t)
         return self.lin(name + ".out_proj", o, residual=queries)
 
     def _i2t_fused(self, name, norm, queries, query_pe, xpe, x, pe, TP):
@@ -361,9 +367,10 @@ class SAM2:
         d = "sam_mask_decoder."
         N, es, Bi = sparse.shape[0], self.es, image_embed.shape[0]
         assert N % Bi == 0 and (repeat_image or Bi > 1 or N == 1)
-        out_tokens = torch.cat([self.P.t(self.p + d + "obj_score_token.weight"), self.P.t(self.p + d + "iou_token.weight"),
-                                self.P.t(self.p + d + "mask_tokens.weight")], dim=0)
-        tokens = torch.cat([out_tokens.unsqueeze(0).expand(N, -1, -1), sparse], dim=1).contiguous()
+        out_tokens = self.P.const("mask_decoder_out_tokens", lambda: torch.cat([self.P.t(self.p + d + "obj_score_token.weight"), self.P.t(self.p + d + "iou_token.weight"),
+                                                                                 self.P.t(self.p + d + "mask_tokens.weight")], dim=0))
+        mk_tokens = lambda: torch.cat([out_tokens.unsqueeze(0).expand(N, -1, -1), sparse], dim=1).contiguous()      # noqa: E731
+        tokens = self.P.const(("mask_decoder_tokens_empty", N), mk_tokens) if sparse.data_ptr() in self.__dict__.get("_const_sparse", ()) else mk_tokens()
         no_mask = self.P.t(self.p + "sam_prompt_encoder.no_mask_embed.weight").view(-1)
         src = ops.add(image_embed, no_mask).view(Bi, es * es, 256)  # dense prompt = no_mask_embed broadcast (prompt_encoder.py:183-187)
         # the fused image side needs the bf16 kernels (vg_twoway_image_update, head-dim-256 attention); fp32 parity mode keeps the reference's order
@@ -376,7 +383,10 @@ class SAM2:
             hs, src = self._two_way(src, tokens)
         iou_tok, mask_toks = hs[:, 1, :], hs[:, 2:6, :]
         s0, s1 = high_res            # [Bi, ...]: ops.add broadcasts them over the instance groups (instance i -> image i % Bi)
-        hyper = torch.stack([self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :].contiguous(), 3) for i in range(4)], dim=1)
+        nhy = self.P.w(self.p + f"{d}output_hypernetworks_mlps.0.layers.2").shape[0]
+        hyper = torch.empty(N, 4, nhy, dtype=hs.dtype, device=hs.device)
+        for i in range(4):       # (row-strided views in and out: no per-token copies, no stack)
+            self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :], 3, out=hyper[:, i, :])
         if fused:
             # r04: upscaling + hypernetwork product in one kernel (the two [N, 16384, 64] / [N, 65536, 32] intermediates never exist)
             masks = ops.mask_upscale(src, self.P.convT_w(self.p + d + "output_upscaling.0"), self.P.b(self.p + d + "output_upscaling.0"), s1.view(Bi, 4 * es * es, 64),
@@ -392,8 +402,8 @@ class SAM2:
             up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.3"), N, 2 * es, 2 * es, 32)
             up = ops.activation(ops.add(up, s0), ops.ACT_GELU)                       # [N,4es,4es,32]
             masks = ops.bmm_nt(hyper, up.view(N, 16 * es * es, 32), out_dtype=torch.float32).view(N, 4, 4 * es, 4 * es)
-        iou = self.mlp(d + "iou_prediction_head", iou_tok.contiguous(), 3, sigmoid_output=True, out_dtype=torch.float32)
-        obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :].contiguous(), 3, out_dtype=torch.float32)
+        iou = self.mlp(d + "iou_prediction_head", iou_tok, 3, sigmoid_output=True, out_dtype=torch.float32)
+        obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :], 3, out_dtype=torch.float32)
         return masks, iou, mask_toks.contiguous(), obj
 
     # ------------------------------------------------------------------ S5 memory attention
