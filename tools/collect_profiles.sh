@@ -18,7 +18,7 @@ db() { find "$1" -name '*.db' | head -1; }
 has() { [ $ONLY = all ] || [ $ONLY = $1 ]; }
 
 ONLY=${2:-all}
-BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality --no-roofline"
+BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-quality --no-roofline --no-video-record"
 PASSES=4
 if has kt || has mfma; then
 for MODE in overlapped serial; do
@@ -47,11 +47,11 @@ python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 tail -c 900 $O/${TAG}_bench.json
 fi
 if has pmc; then
-CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality"
+CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality --no-video-record"
 for C in FETCH_SIZE WRITE_SIZE; do
   c=$(echo $C | tr A-Z a-z | cut -d_ -f1)
   rm -rf $O/${TAG}_pmc_$c
-  rocprofv3 --pmc $C --kernel-trace -d $O/${TAG}_pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality > $O/${TAG}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $O/${TAG}_pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-quality --no-video-record > $O/${TAG}_pmc_$c.log 2>&1
   python $R/tools/prof_summary.py "$(db $O/${TAG}_pmc_$c)" 2 > $O/${TAG}_pmc_$c.txt
   grep -A8 '^PMC' $O/${TAG}_pmc_$c.txt | cut -c1-160
 done
@@ -62,10 +62,10 @@ fi
 [ $ONLY = all ] || exit 0
 
 python $R/bench.py --branch video --no-cpu-baseline > $O/${TAG}_bench_video.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --frames 8 --te 8 --src 512 --no-cpu-baseline > $O/${TAG}_bench_c1.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --llm phi3-mini --no-cpu-baseline > $O/${TAG}_bench_phi3.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 8 --te 8 --src 512 --no-cpu-baseline --no-video-record > $O/${TAG}_bench_c1.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --llm phi3-mini --no-cpu-baseline --no-video-record > $O/${TAG}_bench_phi3.json 2>> $O/${TAG}_bench.err
 # BASELINE config C4's clip on ONE GPU (64 frames, 8 [SEG] objects = 512 mask-decoder instances), bf16 and the fp8 LLM path, framewise and video branch
-python $R/bench.py --frames 64 --objects 8 --no-cpu-baseline --no-quality > $O/${TAG}_bench_c4clip.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --frames 64 --objects 8 --prefill fp8 --decode-weights fp8 --no-cpu-baseline --no-quality > $O/${TAG}_bench_c4clip_fp8.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 64 --objects 8 --no-cpu-baseline --no-quality --no-video-record > $O/${TAG}_bench_c4clip.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --frames 64 --objects 8 --prefill fp8 --decode-weights fp8 --no-cpu-baseline --no-quality --no-video-record > $O/${TAG}_bench_c4clip_fp8.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --frames 64 --objects 8 --branch video --no-cpu-baseline --no-quality --steps 2 > $O/${TAG}_bench_c4clip_video.json 2>> $O/${TAG}_bench.err
 cut -c1-140 $O/${TAG}_bench_video.json $O/${TAG}_bench_c1.json $O/${TAG}_bench_phi3.json $O/${TAG}_bench_c4clip.json $O/${TAG}_bench_c4clip_fp8.json $O/${TAG}_bench_c4clip_video.json

@@ -258,13 +258,15 @@ class VideoGLaMMForCausalLM:
             self.capture["emb"] = emb
         return out_ids.unsqueeze(0), emb
 
-    def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens, all_frames=False):
+    def _text_and_hiera(self, images, context_images, sam, input_ids, max_new_tokens, all_frames=False, static_feats=False):
         """LLM side + Hiera features of this rank's frames, Hiera on the side stream (see _hiera_async)."""
         frames = self.comm.my_frames(sam.shape[0]) if self.comm is not None else None
+        # single-GPU graph-replayed propagation: Hiera writes the clip's features into the replay's own input buffers (SAM2.video_static_feats)
+        bufs = self.sam2.video_static_feats(sam.shape[0]) if (static_feats and frames is None and not all_frames) else None
         box = {}
 
         def start():
-            box["feats"], box["join"] = self._hiera_async(sam, frames, all_frames)
+            box["feats"], box["join"] = self._hiera_async(sam, frames, all_frames, bufs)
 
         # Hiera goes to the side stream FIRST: it then shares the chip with the towers / LLM prefill (big-K, MFMA-bound
         # GEMMs that leave HBM idle, where Hiera's small-K GEMMs, norms and window shuffles are bandwidth-hungry) and is
@@ -273,7 +275,7 @@ class VideoGLaMMForCausalLM:
         mode = os.environ.get("VG_HIERA_START", "first")
         if mode == "serial":      # no overlap (per-kernel timing runs: bench.py's instrumented step)
             stage_mark(self.stages, "begin")
-            feats = self.comm.hiera_all_frames(self.sam2, sam) if all_frames else self.sam2.hiera_frames(sam, frames)
+            feats = self.comm.hiera_all_frames(self.sam2, sam) if all_frames else self.sam2.hiera_frames(sam, frames, bufs=bufs)
             stage_mark(self.stages, "hiera_fpn")
             out_ids, emb = self._text_side(images, context_images, input_ids, max_new_tokens)
             return out_ids, emb, feats
@@ -314,13 +316,13 @@ class VideoGLaMMForCausalLM:
         torch.cuda.current_stream(masks.device).synchronize()
         return out
 
-    def _hiera_async(self, sam, frames=None, all_frames=False):
+    def _hiera_async(self, sam, frames=None, all_frames=False, bufs=None):
         """Hiera + FPN of the SAM frames on a side HIP stream.  It depends only on the pixels, not on the LLM, and it is
         MFMA/LDS-bound while the LLM decode loop is an HBM-bound GEMV chain: the two overlap on the chip.  Returns
         (features per frame, join) — call join() on the consuming stream before reading the features."""
         # all_frames (multi-GPU video branch, r04): the rank's frames go through Hiera in chunks and every finished chunk is all-gathered right away
         # (FrameSharder.hiera_all_frames) — the object ranks' features arrive while the later chunks and the LLM side still run
-        run = (lambda: self.comm.hiera_all_frames(self.sam2, sam)) if all_frames else (lambda: self.sam2.hiera_frames(sam, frames))
+        run = (lambda: self.comm.hiera_all_frames(self.sam2, sam)) if all_frames else (lambda: self.sam2.hiera_frames(sam, frames, bufs=bufs))
         if self.device.type != "cuda":
             return run(), (lambda: None)
         if getattr(self, "_side", None) is None:
@@ -370,7 +372,8 @@ class VideoGLaMMForCausalLM:
         # one exchange of the whole clip after the last frame (default), or — FrameSharder(stream_features=True) — streamed chunk by chunk on a
         # communicator of their own while Hiera still runs
         streamed = self.comm is not None and self.comm.stream_features
-        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens, all_frames=streamed)
+        graphed = self.comm is None and self.device.type == "cuda" and os.environ.get("VG_VIDEO_GRAPH", "1") == "1"
+        out_ids, emb, feats = self._text_and_hiera(images, context_images, sam, input_ids, max_new_tokens, all_frames=streamed, static_feats=graphed)
         if emb.shape[0] == 0:
             return out_ids, [{}]
         hw = tuple(original_size_list[0])

@@ -89,15 +89,26 @@ class SAM2:
         # per (frame, object): the more pairs per launch the better)
         self.frame_chunk, self.decode_chunk = 16, 128
 
-    def hiera_frames(self, images, frames=None):
-        """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views."""
+    def video_static_feats(self, n):
+        """persistent per-level buffers [n, h, w, c] the graph-replayed propagation reads (video_branch_graphed): handed to hiera_frames as `bufs`,
+        Hiera's last kernels write the clip's features straight into them — the replay then has nothing to copy (r05: 96 staging copies = 268 MB
+        per 32-frame clip before)."""
+        st = self.__dict__.setdefault("_video_static", {})
+        if n not in st:
+            st[n] = [torch.empty((n,) + shp, dtype=self.dtype, device=self.device) for shp in self.level_shapes()]
+        return st[n]
+
+    def hiera_frames(self, images, frames=None, bufs=None):
+        """forward_image over many frames in chunks -> list (per frame) of [1,h,w,c] level views.  bufs: optional per-level [len(frames), h, w, c]
+        destinations (video_static_feats)."""
         frames = list(range(images.shape[0])) if frames is None else frames
         out = {}
         # ONE buffer per level for all requested frames: the chunks' last kernels write straight into their rows, so consecutive frames stay
         # consecutive views across chunk borders and the consumers' batches (_stack_views) never copy (r03: a 32-pair mask-decoder batch over two
         # 16-frame chunks cat 268 MB of FPN levels per C2 clip)
         n = len(frames)
-        bufs = [torch.empty((n,) + shp, dtype=self.dtype, device=self.device) for shp in self.level_shapes()]
+        if bufs is None:
+            bufs = [torch.empty((n,) + shp, dtype=self.dtype, device=self.device) for shp in self.level_shapes()]
         for c0 in range(0, n, self.frame_chunk):
             fr = frames[c0:c0 + self.frame_chunk]
             fpn = self.forward_image(images[fr[0]:fr[-1] + 1] if fr == list(range(fr[0], fr[-1] + 1)) else images[fr],
@@ -762,11 +773,16 @@ class SAM2:
             while len(graphs) >= 4:
                 graphs.pop(next(iter(graphs)))
             self.video_branch(images, text_embeds, video_hw, frame_feats=frame_feats, as_masks=as_masks)      # eager once: lazy weight packing, kernel attributes
-            st_feats = {t: [torch.empty_like(f) for f in frame_feats[t]] for t in range(T)}
+            # static inputs of the graph: the persistent feature buffers themselves when the caller's features already live there
+            # (model.inference_video_branch hands them to Hiera), private copies otherwise
+            static = self.__dict__.get("_video_static", {}).get(T)
+            in_place = static is not None and all(frame_feats[t][lv].data_ptr() == static[lv][t:t + 1].data_ptr() for t in range(T) for lv in range(3))
+            st_feats = {t: ([static[lv][t:t + 1] for lv in range(3)] if in_place else [torch.empty_like(f) for f in frame_feats[t]]) for t in range(T)}
             st_emb = torch.empty_like(text_embeds)
             for t in range(T):
                 for d, f in zip(st_feats[t], frame_feats[t]):
-                    d.copy_(f)
+                    if d.data_ptr() != f.data_ptr():
+                        d.copy_(f)
             st_emb.copy_(text_embeds)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph(keep_graph=True)      # (the hipGraph_t stays readable: graph_nodes() below)
@@ -778,7 +794,8 @@ class SAM2:
         g, st_feats, st_emb, out = ent
         for t in range(T):
             for d, f in zip(st_feats[t], frame_feats[t]):
-                d.copy_(f)
+                if d.data_ptr() != f.data_ptr():       # (features Hiera wrote into the graph's own buffers need no staging)
+                    d.copy_(f)
         st_emb.copy_(text_embeds)
         g.replay()
         return out.clone()
