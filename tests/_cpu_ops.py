@@ -44,7 +44,7 @@ def linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=N
     return y
 
 
-def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None):
+def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None, force_fused=False):
     """vg_gemm_rows as the separate statements it fuses (intermediates rounded to the storage dtype like the separate launches)."""
     K, N = x.shape[-1], w.shape[0]
     M = x.numel() // K

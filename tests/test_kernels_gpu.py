@@ -250,7 +250,7 @@ def test_gemm_rows(cuda, case):
         rp = (ang.cos(), ang.sin(), cols, ch, rows, r0, r1, grid)
     dev = lambda t: None if t is None else t.to(cuda)      # noqa: E731
     tup = lambda t: None if t is None else tuple(dev(v) if torch.is_tensor(v) else v for v in t)      # noqa: E731
-    y = ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp))
+    y = ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), force_fused=True)
     want = ref.linear_rows(x, w, bias, act, r, ln=ln, add=add, rope=rp)
     close(y, want, **tol(dt, K))
     # the launches it replaces
@@ -270,13 +270,33 @@ def test_gemm_rows(cuda, case):
     # a strided [B, rows, K] view (the memory bank's valid rows inside a larger buffer) is addressed in place
     big = torch.zeros(B, rows + 40, K, dtype=dt, device=cuda)
     big[:, 24:24 + rows] = dev(x)
-    y2 = ops.linear_rows(big[:, 24:24 + rows], dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp))
+    y2 = ops.linear_rows(big[:, 24:24 + rows], dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), force_fused=True)
     assert torch.equal(y2, y)
     out = torch.full((B * rows, N + 64), 7.0, dtype=dt, device=cuda)                   # a 2-D row-strided destination
-    ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out[:, 64:])
+    ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out[:, 64:], force_fused=True)
     assert torch.equal(out[:, 64:], y.view(B * rows, N)) and float((out[:, :64] - 7.0).abs().max()) == 0.0
     with pytest.raises(AssertionError):                                                 # a 3-D strided destination would be written through a copy: refused
-        ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out.view(B, rows, N + 64)[..., 64:])
+        ops.linear_rows(dev(x), dev(w), dev(bias), act, dev(r), ln=tup(ln), add=dev(add), rope=tup(rp), out=out.view(B, rows, N + 64)[..., 64:], force_fused=True)
+
+
+def test_gemm_rows_large_m_route(cuda):
+    """above ~2048 tiles of 64 x 64 ops.linear_rows sends the LayerNorm forms through the separate launches (vg_layernorm -> vg_gemm ->
+    vg_rope_axial_heads: measured faster there) — same values as the fused kernel up to bf16 rounding steps."""
+    from videoglamm_amd import ops
+    dt = torch.bfloat16
+    x = rnd(8, 1024, 256, dtype=dt, seed=1).to(cuda)
+    w, bias = rnd(768, 256, dtype=dt, seed=2, scale=1 / 16).to(cuda), rnd(768, seed=3).to(cuda)
+    ln = ((1.0 + 0.1 * rnd(256, seed=4)).to(cuda), (0.1 * rnd(256, seed=5)).to(cuda), 1e-5)
+    ang = rnd(1024, 128, seed=8, scale=3.0)
+    rp = (ang.cos().to(cuda), ang.sin().to(cuda), 512, 256, 1024, 0, 1024, 1024)
+    w2 = rnd(2048, 256, dtype=dt, seed=6, scale=1 / 16).to(cuda)
+    for kw in (dict(rope=rp), dict(act=ops.ACT_RELU)):
+        ww = w if "rope" in kw else w2
+        bb = bias if "rope" in kw else None
+        a = ops.linear_rows(x, ww, bb, ln=ln, force_fused=True, **kw)
+        b = ops.linear_rows(x.repeat(5, 1, 1), ww, bb, ln=ln, **kw)[:8]          # 40 x 1024 rows: past the tile rule -> separate launches
+        d = (a.float() - b.float()).abs()
+        assert float((d > b.float().abs().clamp_min(1e-2) * 2.0 ** -7).float().mean()) < 1e-3
 
 
 def test_gemm_rows_fp32_composition(cuda):

@@ -193,9 +193,9 @@ def _linear(x, w, bias=None, act=ACT_NONE, gamma=None, residual=None, out_dtype=
     return out
 
 
-def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None):
-    """y = act(pro(x) @ w^T + bias) [RoPE] [+ residual] on short rows, ONE launch in bf16 (vg_gemm_rows) — the fp32 parity mode (and any shape the
-    kernel does not take) runs the same arithmetic as the separate launches.
+def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None, add=None, rope=None, force_fused=False):
+    """y = act(pro(x) @ w^T + bias) [RoPE] [+ residual] on short rows, ONE launch in bf16 (vg_gemm_rows) while the problem is small — the fp32 parity
+    mode, shapes the kernel does not take and large row counts (see below; force_fused overrides) run the same arithmetic as the separate launches.
     ln = (weight, bias, eps): LayerNorm over the last dim first;  add = a2 [rows2, K]: x + a2, a2 repeated over blocks of rows2 rows;
     rope = (cos, sin, cols, ch, rows_per_block, r0, r1, grid): axial RoPE (rope_axial_heads_) on the first `cols` output columns, heads of `ch`
     channels, rows [r0, r1) of every block of rows_per_block rows, token = (row - r0) % grid.  out: optional [.., N] destination (row stride free)."""
@@ -211,6 +211,13 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
     assert x2.shape[-1] == K and w.stride(1) == 1 and not (ln is not None and add is not None)
     fused = x2.dtype == torch.bfloat16 and K in (64, 128, 192, 256) and N % 64 == 0 and (rope is None or (act == ACT_NONE and residual is None)) \
         and (act == ACT_NONE or residual is None)
+    if fused and ln is not None and not force_fused:
+        # the 64 x 64-tile kernel pays while the problem is small (every workgroup re-stages W, and the LayerNorm is redone per column group): measured
+        # r05 (tools/lab/rows_bench.py, K = 256): norm -> linear -> ReLU at M = 4096: N = 1024 17.9 us fused / 25.5 separate, N = 2048 29.0 / 25.2;
+        # M = 32768 (8 objects), N = 2048: 158 / 69; with the RoPE epilogue the separate path has a third launch: M = 8192, N = 768 24.6 / 33.7,
+        # M = 32768: 80.5 / 48.5.  (The A + A2 prologue of the memory keys replaces nine launches and always pays.)
+        tiles = -(-M // 64) * (N // 64)
+        fused = tiles <= 2048 if rope is not None else tiles < 2048
     if not fused:
         h = x
         if ln is not None:
@@ -222,10 +229,13 @@ def linear_rows(x, w, bias=None, act=ACT_NONE, residual=None, out=None, ln=None,
             cos, sin, cols, ch, rpb, r0, r1, grid = rope
             heads, B = cols // ch, M // rpb
             yv = y.view(B, rpb, N)
-            # (parity mode only: the strided head slices go through a contiguous copy — torch plumbing around vg_rope_axial)
-            part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone(memory_format=torch.contiguous_format)
-            rope_axial_(part, cos, sin, r1 - r0, grid)
-            yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
+            if y.dtype == torch.bfloat16 and r0 == 0:
+                rope_axial_heads_(yv, heads, cos, sin, r1, grid)        # (the first r1 rows of every block, strided heads: one launch)
+            else:
+                # (parity mode only: the strided head slices go through a contiguous copy — torch plumbing around vg_rope_axial)
+                part = yv[:, r0:r1, :cols].reshape(B, r1 - r0, heads, ch).permute(0, 2, 1, 3).reshape(B * heads, r1 - r0, ch).clone(memory_format=torch.contiguous_format)
+                rope_axial_(part, cos, sin, r1 - r0, grid)
+                yv[:, r0:r1, :cols] = part.view(B, heads, r1 - r0, ch).permute(0, 2, 1, 3).reshape(B, r1 - r0, cols)
             if out is not None:
                 out.copy_(y.view(out.shape))
                 y = out
