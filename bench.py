@@ -424,7 +424,7 @@ def cpu_baseline(cfg, args):
     T, G, L = args.frames, args.max_new_tokens, c["num_layers"]
     t_vision = T * t_sam + args.te * t_clip + args.te * t_iv2
     t_llm = (G + 1) * L * t_layer                     # G + 1 full re-forwards of the sequence, L layers each
-    return dict(value=round(T / (t_vision + t_llm), 5), unit="frames/sec", cores=cores, kind="port",
+    return dict(value=round(T / (t_vision + t_llm), 5), unit="frames/sec", cores=cores, kind="port", method="extrapolated from timed per-module samples (not a timed clip)",
                 sample=f"fp32 oracle at full architecture size: 1 frame through Hiera-L+FPN+mask decoder ({t_sam:.1f}s), 1 frame through CLIP-L/336 "
                        f"({t_clip:.1f}s), InternVideo2-1B chunk/4 ({t_iv2:.1f}s), 1 of {L} LLM layers on the {S_llm}-row prompt ({t_layer:.2f}s); clip time "
                        f"= {T} x SAM + {args.te} x (CLIP + IV2) + {G + 1} re-forwards x {L} layers (the oracle restates generate(use_cache=False)) "

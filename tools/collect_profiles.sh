@@ -34,6 +34,7 @@ for MODE in overlapped serial; do
   { echo "# $CMD   (C2 framewise, 1 x MI355X; $PASSES passes of the hot path, all in the '$MODE' stream configuration: 1 warm-up + 3 timed; per-pass columns = totals / $PASSES)"
     echo "# bench line of the traced run:"; grep '^{"metric' $O/${TAG}_kt_$MODE.log; echo
     python $R/tools/prof_summary.py "$(db $O/${TAG}_kt_$MODE)" $PASSES; } > $O/${TAG}_kt_$MODE.txt
+  [ $MODE = serial ] && python $R/tools/decode_timeline.py "$(db $O/${TAG}_kt_$MODE)" > $O/${TAG}_decode_timeline.txt 2>&1
   (cd $R/tools && python kt_json.py "$(db $O/${TAG}_kt_$MODE)" $O/${TAG}_kt_$MODE.json $PASSES $MODE "$CMD  (+ a --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace pass of the same command for mfma_busy_frac); tools/collect_profiles.sh" $MF)
   rm -rf $O/${TAG}_kt_$MODE $O/${TAG}_mfma_$MODE
 done
@@ -69,3 +70,11 @@ python $R/bench.py --frames 64 --objects 8 --no-cpu-baseline --no-quality --no-v
 python $R/bench.py --frames 64 --objects 8 --prefill fp8 --decode-weights fp8 --no-cpu-baseline --no-quality --no-video-record > $O/${TAG}_bench_c4clip_fp8.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --frames 64 --objects 8 --branch video --no-cpu-baseline --no-quality --steps 2 > $O/${TAG}_bench_c4clip_video.json 2>> $O/${TAG}_bench.err
 cut -c1-140 $O/${TAG}_bench_video.json $O/${TAG}_bench_c1.json $O/${TAG}_bench_phi3.json $O/${TAG}_bench_c4clip.json $O/${TAG}_bench_c4clip_fp8.json $O/${TAG}_bench_c4clip_video.json
+# r05: the video branch (kernel trace of the C2 clip and of C4's clip on it, one tracked frame kernel by kernel), the mask decoder at C4's clip size, GEMMs against the vendor library
+P=${TAG%_c2}
+VIDEO_ARGS="" bash $R/tools/lab/video_kt.sh ${TAG}_video_kt > /dev/null 2>&1
+PASSES=3 VIDEO_ARGS="--frames 64 --objects 8 --steps 2" bash $R/tools/lab/video_kt.sh ${P}_c4clip_video_kt > /dev/null 2>&1
+bash $R/tools/lab/video_frame_seq.sh ${P}_video_frame_seq 1 > /dev/null 2>&1
+bash $R/tools/lab/maskdec_kt.sh ${P}_maskdec_kt > /dev/null 2>&1
+(cd $R && python tools/gemm_vs_lib.py > $O/${P}_gemm_vs_lib.log 2>&1)
+ls $O | grep "^${P}" | tr '\n' ' '

@@ -1,10 +1,11 @@
 """Summarise a rocprofv3 rocpd database: per-kernel time (and PMC counters when present).
-usage: python tools/prof_summary.py <results.db> [steps]"""
+usage: python tools/prof_summary.py <results.db> [steps] [rows]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+nrows = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 cur = db.cursor()
 rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc"))
 import re
@@ -16,7 +17,7 @@ tot = sum(r[2] for r in rows)
 print(f"total kernel time {tot:.2f} ms over {steps:g} step(s) = {tot / steps:.2f} ms/step"
       + (f"   (+ {sum(r[2] for r in init):.1f} ms of model-build kernels — synthetic weight RNG / scaling, {sum(r[1] for r in init)} launches, once per process — not in the table)" if init else ""))
 print(f"{'ms/step':>10} {'launches/step':>14} {'avg us':>10}  kernel")
-for r in rows[:30]:
+for r in rows[:nrows]:
     print(f"{r[2] / steps:10.2f} {r[1] / steps:14.1f} {r[3]:10.1f}  {r[0][:110]}")
 try:
     pm = list(cur.execute("select k.name, p.counter_name, count(*), sum(p.counter_value), avg(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
