@@ -84,6 +84,9 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #ifndef VG_ATTN_VTR
 #define VG_ATTN_VTR 1
 #endif
+#ifndef VG_ATTN_DB
+#define VG_ATTN_DB 1
+#endif
 #ifndef VG_ATTN_MINW
 #define VG_ATTN_MINW 2
 #endif
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   // Row stride: the 16 lanes of a transpose read touch 4 rows x 4 column quads of 8 bytes; rows must land 8 banks apart
   constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
   constexpr int RSV = DP * ES + (DP == 128 ? 32 : 16);
+  // DB (key-split kernel with 64-wide values, vg_attention_dv): TWO K / V tile buffers — a wave writes tile t + 1 into the other buffer as soon as
+  // it is done multiplying tile t, so the loop has one barrier per tile instead of two and the staging writes of the early waves run under the MFMAs
+  // of the late ones (K 33 KB + V^T 8 KB per buffer: 148 KB with the Q tile; the head-dim-256 values of the self-attention form do not fit twice)
+  constexpr bool DB = VG_ATTN_DB && sizeof(T) == 2 && KS == 2 && DVP <= 64;
   char* Qs = smem;
   char* Ks = Qs + BQ * RS;
   char* Vs = Ks + BKV * RS;
@@ -289,18 +296,15 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
 #pragma unroll
     for (int g = 0; g < NG; ++g) qreg[g] = *(const u32x4_t*)(qrow + g * 32);
   }
-  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV) {
-    if (!PF) fetch(kv0);
-    __syncthreads();
-    stage();
-    __syncthreads();
-    if (PF && kv0 + BKV < kv_end) fetch(kv0 + BKV);
-
-    f32x16_t s[NKT];
+  static_assert(!DB || (PF && QREG), "the double-buffered loop prefetches and keeps Q in registers");
+  // (r05, measured and dropped: running the kh = 1 waves half an iteration behind their SIMD partners — softmax / PV of tile t - 1 beside the partner's
+  // QK^T of tile t, V^T tiles in a ring of three — changed nothing: 131 vs 126 us on the C2 shape, 3 spilled registers; tools/lab/attn_db_ab.sh)
+  constexpr bool PIPE = sizeof(T) == 2 && (DP <= 128 || DVP <= 64);
+  f32x16_t s[NKT];
+  auto qk_tile = [&]() {
     // PIPE (bf16, head dim <= 128): the K / Q fragments of k-group g + 1 are requested before the MFMAs of group g issue, and the
     // sub-tiles' independent accumulators alternate — left to itself the compiler emits read, wait, MFMA per fragment (measured r02:
     // every MFMA of the loop then pays a full LDS round trip); head dim 256 has no registers to spare for the second fragment set
-    constexpr bool PIPE = sizeof(T) == 2 && (DP <= 128 || DVP <= 64);
     if constexpr (PIPE) {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
@@ -339,6 +343,8 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       }
     }
 
+  };
+  auto smpv_tile = [&](const int kv0, const char* Vt) {
     // softmax in the exp2 domain: t = s * (scale * log2 e), so every score costs one fma + one v_exp_f32; m_i and the
     // partials keep natural-log units (m = max(t) / log2 e) for the split-KV merge.  The mask arithmetic only runs on
     // tiles that need it (sequence end, causal diagonal, window edges): the inner loop is VALU-bound, not MFMA-bound.
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
       // VTR: lane i of a 16-lane group hands ds_read_b64_tr_b16 the 8-byte piece (key row i >> 2, column quad i & 3) of a 4-key x 16-column
       // block and receives column i of it = 4 keys of ONE head-dim column (tools/lab/tr_probe.hip); the MFMA A operand of 16-key step t wants
       // the keys whose P values this lane's accumulator registers hold: 16 t + 4 h + {0..3} and 16 t + 8 + 4 h + {0..3} -> two reads
-      const char* vtr = Vs + (4 * h + ((lane & 15) >> 2)) * RSV + ((((lane >> 4) & 1) * 16 + 4 * (lane & 3)) << 1);
+      const char* vtr = Vt + (4 * h + ((lane & 15) >> 2)) * RSV + ((((lane >> 4) & 1) * 16 + 4 * (lane & 3)) << 1);
       auto vread = [&](int t, int dt) -> u32x4_t {
         if constexpr (VTR) {
           typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
           return v;
         } else {
           const int d = dt * 32 + l31;
-          return *(const u32x4_t*)(Vs + d * 128 + ((((kh * NKT + (t >> 1)) * 4 + (t & 1) * 2 + h) ^ ((d >> 1) & 7)) << 4));
+          return *(const u32x4_t*)(Vt + d * 128 + ((((kh * NKT + (t >> 1)) * 4 + (t & 1) * 2 + h) ^ ((d >> 1) & 7)) << 4));
         }
       };
 #pragma unroll
@@ -446,13 +452,46 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
     } else {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        const char* vs = Vs + kt * 32 * RSVF;
+        const char* vs = Vt + kt * 32 * RSVF;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          if constexpr (sizeof(T) == 2) pv_step_bf16t(Vs, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
+          if constexpr (sizeof(T) == 2) pv_step_bf16t(Vt, dt * 32 + l31, kh * NKT + kt, h, s[kt], o[dt]);
           else pv_step_f32<RSVF>(vs, dt * 32 + l31, h, s[kt], o[dt]);
         }
       }
+    }
+  };
+  char* const Kb0 = Qs + BQ * RS;
+  char* const Vb0 = Kb0 + (DB ? 2 : 1) * BKV * RS;
+  constexpr int VBY = DVP * 128;
+  if constexpr (DB) {
+    Vs = Vb0;
+    if (kv_begin < kv_end) {
+      stage();
+      __syncthreads();
+      if (kv_begin + BKV < kv_end) fetch(kv_begin + BKV);
+    }
+  }
+  int ti = 0;                                   // tile index of the walk (DB: K / V buffer ti & 1)
+  for (int kv0 = kv_begin; kv0 < kv_end; kv0 += BKV, ++ti) {
+    if constexpr (!DB) {
+      if (!PF) fetch(kv0);
+      __syncthreads();
+      stage();
+      __syncthreads();
+      if (PF && kv0 + BKV < kv_end) fetch(kv0 + BKV);
+      qk_tile();
+      smpv_tile(kv0, Vs);
+    } else {
+      qk_tile();
+      smpv_tile(kv0, Vb0 + (ti & 1) * VBY);
+      if (kv0 + BKV < kv_end) {                 // tile t + 1 (in registers since the last barrier) goes to the buffers nobody reads any more
+        Ks = Kb0 + ((ti + 1) & 1) * (BKV * RS);
+        Vs = Vb0 + ((ti + 1) & 1) * VBY;
+        stage();
+      }
+      __syncthreads();
+      if (kv0 + 2 * BKV < kv_end) fetch(kv0 + 2 * BKV);
     }
   }
 
@@ -543,7 +582,9 @@ static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RSV = DP * (int)sizeof(T) + (DP == 128 ? 32 : 16);
   constexpr int vbytes = VTR ? BKV * RSV : (sizeof(T) == 2 ? DVP * 128 : BKV * RSVF);   // bf16, head dim 256: transposed V image, DP rows of 64 keys
   constexpr int BQ = NW / KS * 32;
-  constexpr int lds = (BQ + BKV) * RS + vbytes;
+  constexpr bool DB = VG_ATTN_DB && sizeof(T) == 2 && KS == 2 && DVP <= 64;
+  constexpr int lds = (BQ + BKV) * RS + vbytes + (DB ? BKV * RS + vbytes : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(KS == 1 || lds >= (NW / KS) * (DVP / 32 * 16 + 2) * 64 * 4, "the key-half merge reuses the tile buffers");
   static bool attr_set = false;
   if (!attr_set) {
