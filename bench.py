@@ -97,7 +97,7 @@ class GemmMeter:
     def kernel_of(M, N, K, glu, windowed):
         """the launcher's own routing (vg_gemm_route, videoglamm_amd/csrc/vg_gemm.hip): which tile kernel runs this shape"""
         from videoglamm_amd import _lib
-        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128", 5: "small64", 6: "p8n"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
+        return {1: "glds", 2: "k64b", 3: "w128", 4: "s128", 5: "small64", 6: "p8n", 7: "rr"}[_lib.load().vg_gemm_route(int(M), int(N), int(K), 1, 1 if glu else 0, 1 if windowed else 0)]
 
     def __enter__(self):
         def timed(x, w, *a, **k):
@@ -784,7 +784,7 @@ def main():
                  "launches": n, "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                  "algorithmic_tflop_per_launch": round(flops / 1e12 / max(n, 1), 4),
                  "algorithmic_bytes_per_launch": round(nbytes / max(n, 1)), "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
-                 "kernel_ms_per_step": round(ms, 2),
+                 "kernel_ms_per_step": round(ms, 2), "hbm_frac": round(nbytes / (ms * 1e-3) / 8e12, 4) if ms > 0 else 0.0,
                  "frac_serial": round(ach / peak, 4)}       # = frac: HIP events per launch in the serial-stream instrumented pass
             for mode in ("serial", "overlapped"):
                 t = trace_of(key, mode)
@@ -809,6 +809,7 @@ def main():
                   "w128": "gemm_tile_p8_kernel<bf16> (256x256 tile, 8 waves of 128x64, phase-split K steps; r04: replaces gemm_tile_w128x8_kernel on the 256x256 route)",
                   "p8n": "gemm_tile_p8n_kernel<bf16> (256x192 tile, the phase-split pipeline with the operand roles swapped; r05: shapes whose rounds x tile cost favour the narrow tile)",
                   "s128": "gemm_tile_s128_kernel<bf16> (128x128 tile, one 128-byte-row stage: 1024 <= K*2 <= 3072 B)",
+                  "rr": "gemm_rr_kernel<K / 16, resident | streamed W> (r05: K = 144 / 288 over >= 65536 rows — Hiera stages 1-2, FPN laterals: the wave's A rows in registers, W chunks in LDS, no tiles; HBM-bound at K = 144: see hbm_frac)",
                   "small64": "gemm_small64_kernel<bf16> (64x64 tile, whole K <= 256 in one DMA burst: problems of < 256 128x128 tiles — memory attention, mask decoder)"}
         roofs = {k: roof(k, labels[k], key="gemm_" + k) for k in labels}
         roofs = {"gemm_" + k: v for k, v in roofs.items() if v["launches"]}

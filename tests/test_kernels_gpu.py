@@ -687,6 +687,57 @@ def test_gemm_window(cuda, dtype, B, H, W, ws, K, N):
     close(z, ref.linear_window(r.to(dtype), w2, None, B, H, W, ws, scatter=True, residual=res), **tol(dtype, N))
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(65536 + 77, 432, 144, 0, False), (65536, 144, 144, 0, True), (66000, 288, 144, 0, False), (65600, 864, 144, 0, False),
+                                           (65536 + 300, 864, 288, 0, False), (65536, 288, 288, 0, True), (65537, 1152, 288, 1, False), (70000, 256, 288, 0, False),
+                                           (131072, 16, 144, 1, False), (65536 + 255, 48, 288, 0, True)])
+def test_gemm_rr(cuda, M, N, K, act, res):
+    """the row-register kernel (vg_gemm_rr.hip: K = 144 / 288 over >= 65536 rows — Hiera stages 1-2, FPN laterals): W resident (K = 144, N <= 512) and streamed,
+    ragged last panel, column blocks that end inside a 64-column chunk (N = 432, 144, 48, 16), GELU, residual; against fp32 matmul of the same bf16 operands,
+    and the strided-input form (lda > K)."""
+    from videoglamm_amd import ops
+    from videoglamm_amd import _lib
+    assert _lib.load().vg_gemm_route(M, N, K, ops.BF16, 0, 0) == 7, "the shape must take the row-register route"
+    g = torch.Generator(device=cuda).manual_seed(M + N)
+    x = (torch.randn(M, K + 16, device=cuda, generator=g) * 0.5).to(torch.bfloat16)[:, :K]          # rows with a stride: lda = K + 16
+    w = (torch.randn(N, K, device=cuda, generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=cuda, generator=g)
+    r = (torch.randn(M, N, device=cuda, generator=g)).to(torch.bfloat16) if res else None
+    y = ops.linear(x, w, b, act=act, residual=r)
+    z = x.float() @ w.float().t() + b
+    if act == 1:
+        z = torch.nn.functional.gelu(z)
+    if res:
+        z = z + r.float()
+    err = (y.float() - z).abs()
+    assert err.max().item() < 2e-2 + 8e-3 * z.abs().max().item(), err.max().item()
+    assert (err > 1e-2 + 4e-3 * z.abs()).float().mean().item() < 1e-5
+    # contiguous input: same numbers
+    assert torch.equal(y, ops.linear(x.contiguous(), w, b, act=act, residual=r))
+
+
+@pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 256, 256, 8, 144, 432), (4, 128, 128, 4, 288, 864), (3, 160, 144, 8, 144, 144), (5, 120, 128, 7, 288, 288)])
+def test_gemm_rr_window(cuda, B, H, W, ws, K, N):
+    """window gather (A rows) and window scatter + residual (C / R rows) on the row-register kernel, power-of-two windows and a 7-token window that pads the
+    grid (padding rows read zeros and are dropped on the way back): equal to the two-kernel path bit for bit, close to the fp32 statement."""
+    from videoglamm_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(B * H + ws)
+    x = (torch.randn(B, H, W, K, device=cuda, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=cuda, generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=cuda, generator=g)
+    y = ops.linear_window(x, w, b, B, H, W, ws, scatter=False)
+    xp = ops.window_partition(x, ws)
+    assert torch.equal(y, ops.linear(xp, w, b))
+    z = xp.float() @ w.float().t() + b
+    assert (y.float() - z).abs().max().item() < 2e-2 + 8e-3 * z.abs().max().item()
+    w2 = (torch.randn(K, N, device=cuda, generator=g) * N ** -0.5).to(torch.bfloat16)
+    if N in (144, 288):
+        res = torch.randn(B, H, W, K, device=cuda, generator=g).to(torch.bfloat16)
+        o = ops.linear_window(y, w2, None, B, H, W, ws, scatter=True, residual=res)
+        zz = ops.window_unpartition((y.float() @ w2.float().t()), ws, B, H, W) + res.float() if hasattr(ops, "window_unpartition") else None
+        if zz is not None:
+            assert (o.float() - zz).abs().max().item() < 3e-2 + 8e-3 * zz.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Bw,wtok,H,D", [(64, 16, 4, 72), (8, 64, 2, 72), (6, 16, 2, 32), (16, 49, 4, 72), (24, 32, 1, 64),
                                          (5, 256, 8, 72), (3, 256, 2, 64), (2, 256, 3, 80), (33, 256, 8, 72)])

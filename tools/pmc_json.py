@@ -13,6 +13,7 @@ CLASSES = [
     ("gemm_k64b", r"gemm_tile_k64b_kernel<unsigned short|gemm_tile_ring64_kernel<unsigned short"),
     ("gemm_w128", r"gemm_tile_p8_kernel<unsigned short"),      # the 256x256 route (label kept from the kernel it replaced in r04)
     ("gemm_p8n", r"gemm_tile_p8n_kernel<unsigned short"),      # r05: the 256x192 route
+    ("gemm_rr", r"gemm_rr_kernel<"),                             # r05: the row-register short-K route
     ("gemm_s128", r"gemm_tile_s128_kernel<unsigned short"),
     ("mlp_rows", r"mlp_rows_kernel"),
     ("decode_gemv_glu", r"decode_gemv_fast_kernel<unsigned short, unsigned short, true"),

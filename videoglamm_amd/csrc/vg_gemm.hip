@@ -960,6 +960,7 @@ static int env_knob(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+static int knob_rr() { static const int v = env_knob("VG_GEMM_RR", 1); return v; }    // row-register kernel (K = 144 / 288): 0 off (A/B), 1 rule (M >= 65536 rows), 2 every eligible shape (tests)
 static int knob_p8() { static const int v = env_knob("VG_GEMM_P8", 1); return v; }    // 0: no 256-row tile routes (A/B), 2 / 3: the 256x256 / 256x192 kernel on every eligible bf16 shape
 // small problems with a short K: fewer than 256 tiles of 128x128 (the chip is not filled), K = 64 / 128 / 192 / 256 bf16 -> gemm_small64_kernel
 static bool route_small64(int64_t M, int64_t N, int64_t K, int es, int a_op, int wmode, int vec_out, int batch) {
@@ -1057,6 +1058,13 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
         gemm_small64_kernel<TO><<<grids, 256, lds, st>>>(q);
         VG_LAUNCH_CHECK();
         return VG_OK;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      // short K over very many rows (Hiera stages 1-2, the FPN laterals of those levels): A rows in registers, no tiles (vg_gemm_rr.hip)
+      if (knob_rr() && vg_gemm_rr_eligible(p, batch, sizeof(TO) == 2) && (knob_rr() == 2 || p.M >= 65536)) {
+        static const int ncu_rr = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        return vg_gemm_rr_launch(q, ncu_rr, st);
       }
     }
     if (narrow) {
@@ -1249,6 +1257,8 @@ extern "C" int vg_gemm_f8(const uint8_t* A8, int64_t lda, const float* a_scale, 
 extern "C" int vg_gemm_route(int64_t M, int64_t N, int64_t K, int in_dtype, int a_op, int windowed) {
   if (M <= 16) return 0;
   const int es = in_dtype == VG_BF16 ? 2 : 4;
+  // 7: the row-register kernel (bf16 output, no LayerScale, activation none | GELU assumed — what the path runs at K = 144 / 288)
+  if (es == 2 && !a_op && knob_rr() && (K == 144 || K == 288) && N % 16 == 0 && (knob_rr() == 2 || M >= 65536)) return 7;
   if (route_small64(M, N, K, es, a_op, windowed, 1, 1)) return 5;
   const bool p8ok = route_p8(M, N, K, es, a_op, windowed, 1, 1, nullptr, nullptr);
   if (route_p8n(M, N, K, es, a_op, windowed, 1, 1, p8ok, nullptr, nullptr)) return 6;

@@ -217,3 +217,6 @@ bool vg_gemm_p8_window_ok(int wmode, int wsh, int wH, int wW, int wws);
 int vg_gemm_p8_launch(const GemmArgs& q, int out_is_bf16, int wgs, hipStream_t st);
 // vg_gemm_p8n.hip: the same pipeline on 256 x 192 tiles (launch_gemm's route_p8n decides)
 int vg_gemm_p8n_launch(const GemmArgs& q, int out_is_bf16, int wgs, hipStream_t st);
+// vg_gemm_rr.hip: the row-register kernel for K = 144 / 288 over very many rows (A rows in registers, W chunks in LDS; launch_gemm's short-K route)
+bool vg_gemm_rr_eligible(const GemmArgs& p, int batch, bool out_is_bf16);
+int vg_gemm_rr_launch(const GemmArgs& q, int ncu, hipStream_t st);
