@@ -107,6 +107,16 @@ int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t ldw, void*
                    const float* gamma, const void* R, int64_t ldr, int N, int K, int in_dtype, int out_dtype, int act,
                    int mode, int B, int H, int Wd, int ws, const void* zero_row, vg_stream_t stream);
 
+/* y = act(LayerNorm_K(A rows) @ W^T + bias) — the norm1 -> q|k|v and norm2 -> fc1 pairs of Hiera's MultiScaleBlock at the widths of stages 1 and 2
+ * (R/model/segment_anything_2/sam2/modeling/backbones/hieradet.py:117-123, 160-166), the LayerNorm applied to the rows in registers.  Built for the
+ * row-register route only: bf16, K in {144, 288}, N a multiple of 16, >= 65536 rows, act none | GELU; VG_ERR_UNSUPPORTED otherwise (the caller then runs
+ * vg_layernorm + vg_gemm / vg_gemm_window).  window = 1: rows gathered from an image-order [B,H,W,K] tensor as vg_gemm_window's mode 1 (M is ignored;
+ * padding rows stay zero BEHIND the norm, as F.pad of the normalised tensor does); zero_row as in vg_gemm_window. */
+int vg_gemm_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+               const float* ln_w, const float* ln_b, float ln_eps, int64_t M, int N, int K, int act,
+               int window, int B, int H, int Wd, int ws, const void* zero_row, int dtype, vg_stream_t stream);
+
+
 /* ---- attention (flash-style, LDS-staged QK tiles, in-register online softmax) -------------------
  * O[b,i,h,:] = softmax_j(scale * Q[b,i,h,:]·K[b,j,g,:] (+causal mask)) @ V[b,j,g,:],  g = h / (Hq/Hkv)
  * causal = 1: key j visible to query i iff j <= i + (Skv - Sq).  causal = c >= 2: the same with a sliding window of c

@@ -80,6 +80,11 @@ def heads_blockdiag_gather(full, N, nt, TP):
     return torch.diagonal(o_full, dim1=1, dim2=3)[:, :nt].permute(0, 1, 3, 2).reshape(N, nt, 128)
 
 
+def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
+    xn = layernorm(x, ln[0], ln[1], ln[2])
+    return linear_window(xn, w, bias, *window, scatter=False, act=act) if window is not None else linear(xn, w, bias, act=act)
+
+
 def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
     h = linear(layernorm(x, ln[0], ln[1], ln[2]), w1, b1, ACT_GELU)
     return linear(h, w2, b2, ACT_NONE, None, x)

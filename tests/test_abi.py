@@ -61,8 +61,9 @@ def test_gemm_routing_rules():
     assert route(3361, 4096, 14336) == 3                   # C2 down
     assert route(32768, 1728, 576) == 3                    # Hiera stage 3 (K x 2 B = 1152): the phase-split 256x256 kernel since r04
     assert route(32768, 1728, 576, win=1) == 4             # ... its window-gathering form stays on the single-stage whole-line kernel
-    assert route(131072, 1152, 288) == 2                   # Hiera stage 2 (K x 2 B = 576): 64-byte-step kernel
-    assert route(524288, 432, 144) == 2                    # Hiera stage 1: 64-byte-step kernel
+    assert route(131072, 1152, 288) == 7 and route(524288, 432, 144) == 7     # Hiera stages 1 / 2 (K = 144 / 288, >= 65536 rows): the row-register kernel (r05)
+    assert route(32768, 1152, 288) == 2 and route(4096, 432, 144) == 2        # ... fewer rows: the 64-byte-step kernel
+    assert lib.vg_gemm_route(524288, 432, 144, 0, 0, 0) == 2                  # ... and fp32 always
     assert route(65536, 2304, 576) == 3 and route(9232, 4096, 1024) == 3    # Hiera stage 3 fc1 and CLIP's fc1 (K = 1024): the 256x256 kernel
     # r05: 256x192 tiles where whole rounds x tile width say so — N = 576 is three exact tiles (Hiera stage 3 fc2 / proj), Llama's q|k|v at
     # M = 3361 two rounds of the narrow tile against two of the wide one, CLIP's fc2 one round of 222 narrow tiles against 148 wide ones

@@ -715,6 +715,42 @@ def test_gemm_rr(cuda, M, N, K, act, res):
     assert torch.equal(y, ops.linear(x.contiguous(), w, b, act=act, residual=r))
 
 
+@pytest.mark.parametrize("M,N,K,act", [(65536 + 41, 432, 144, 0), (65536, 864, 288, 0), (70000, 1152, 288, 1), (65600, 288, 144, 1)])
+def test_gemm_ln(cuda, M, N, K, act):
+    """LayerNorm -> projection in one launch (vg_gemm_ln on the row-register kernel) against the two launches: the normalised rows are rounded to bf16 as
+    vg_layernorm's output is, so the results agree up to the summation order of the row statistics (a bf16 step on a handful of elements at most)."""
+    from videoglamm_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(M + K)
+    x = (torch.randn(M, K, device=cuda, generator=g) * 2.0 + 0.3).to(torch.bfloat16)
+    lw, lb = torch.randn(K, device=cuda, generator=g) * 0.2 + 1.0, torch.randn(K, device=cuda, generator=g) * 0.1
+    w = (torch.randn(N, K, device=cuda, generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=cuda, generator=g)
+    y = ops.linear_ln(x, (lw, lb, 1e-6), w, b, act=act)
+    r = ops.linear(ops.layernorm(x, lw, lb, 1e-6), w, b, act=act)
+    d = (y.float() - r.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-3 and d.max().item() <= 0.07, ((d > 0).float().mean().item(), d.max().item())
+    z = torch.nn.functional.layer_norm(x.float(), (K,), lw, lb, 1e-6) @ w.float().t() + b
+    if act == 1:
+        z = torch.nn.functional.gelu(z)
+    assert (y.float() - z).abs().max().item() < 4e-2 + 1e-2 * z.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 256, 256, 8, 144, 432), (4, 128, 128, 4, 288, 864), (5, 120, 128, 7, 288, 288)])
+def test_gemm_ln_window(cuda, B, H, W, ws, K, N):
+    """the same behind the window gather: padding rows (7-token windows on a 120 x 128 grid) are zero BEHIND the norm — their outputs are the bias"""
+    from videoglamm_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(B + ws)
+    x = (torch.randn(B, H, W, K, device=cuda, generator=g) * 1.5).to(torch.bfloat16)
+    lw, lb = torch.randn(K, device=cuda, generator=g) * 0.2 + 1.0, torch.randn(K, device=cuda, generator=g) * 0.1
+    w = (torch.randn(N, K, device=cuda, generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=cuda, generator=g)
+    y = ops.linear_ln(x, (lw, lb, 1e-6), w, b, window=(B, H, W, ws))
+    r = ops.linear_window(ops.layernorm(x, lw, lb, 1e-6), w, b, B, H, W, ws, scatter=False)
+    assert y.shape == r.shape
+    d = (y.float() - r.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-3 and d.max().item() <= 0.07, ((d > 0).float().mean().item(), d.max().item())
+
+
 @pytest.mark.parametrize("B,H,W,ws,K,N", [(2, 256, 256, 8, 144, 432), (4, 128, 128, 4, 288, 864), (3, 160, 144, 8, 144, 144), (5, 120, 128, 7, 288, 288)])
 def test_gemm_rr_window(cuda, B, H, W, ws, K, N):
     """window gather (A rows) and window scatter + residual (C / R rows) on the row-register kernel, power-of-two windows and a 7-token window that pads the

@@ -33,6 +33,7 @@ def _sig(lib):
         "vg_mlp_rows": ([P, L, P, L, P, P, F, P, P, P, P, L, I, I, I, P], c_int),
         "vg_gemm_rows": ([P, L, P, L, P, L, P, P, L, L, I, I, I, P, P, F, P, L, I, P, P, I, I, I, L, I, I, I, I, P], c_int),
         "vg_gemm_window": ([P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
+        "vg_gemm_ln": ([P, L, P, L, P, L, P, P, P, F, L, I, I, I, I, I, I, I, I, P, I, P], c_int),
         "vg_attention": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P], c_int),
         "vg_attention_splitkv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, I, P, L, I, P, P], c_int),
         "vg_attention_dv": ([P, P, P, P, I, I, I, I, I, I] + [L] * 12 + [F, I, P, L, I, P], c_int),

@@ -1105,6 +1105,9 @@ static int launch_gemm(const GemmArgs& p, int batch, hipStream_t st) {
 // vg_gemm_window passes its geometry to the shared body through this thread-local (the body is vg_gemm's)
 struct GemmWindow { int mode, H, W, ws; const void* zrow; };
 static thread_local GemmWindow g_window{0, 0, 0, 0, nullptr};
+// vg_gemm_ln: the LayerNorm of the A rows rides the same way
+struct GemmLn { const float* w; const float* b; float eps; bool on; };
+static thread_local GemmLn g_ln{nullptr, nullptr, 0.f, false};
 
 // ---- split-K for grids that leave most of the chip idle (few 128x128 tiles, long K): K slices on blockIdx.z, fp32 partials,
 // one pass that sums them and applies the usual epilogue
@@ -1298,6 +1301,12 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
     p.wsh = (a >= 0 && b >= 0 && c >= 0) ? (a | (b << 8) | (c << 16)) : -1;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (g_ln.on) {
+    p.ln_w = g_ln.w; p.ln_b = g_ln.b; p.ln_eps = g_ln.eps;
+    // only the row-register kernel normalises its rows: anything else is the caller's vg_layernorm + vg_gemm
+    VG_CHECK(in_dtype == VG_BF16 && out_dtype == VG_BF16 && knob_rr() && vg_gemm_rr_eligible(p, batch, true) && (knob_rr() == 2 || M >= 65536),
+             VG_ERR_UNSUPPORTED, "vg_gemm_ln: M=%d N=%d K=%d is not a row-register shape (bf16, K in {144, 288}, N %% 16 == 0, >= 65536 rows, no residual)", M, N, K);
+  }
   if (in_dtype == VG_BF16 && out_dtype == VG_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == VG_BF16 && out_dtype == VG_F32) return launch_gemm<bf16_t, float>(p, batch, st);
   if (in_dtype == VG_F32 && out_dtype == VG_F32) return launch_gemm<float, float>(p, batch, st);
@@ -1305,6 +1314,10 @@ extern "C" int vg_gemm(const void* A, int64_t lda, int64_t sA, const void* W, in
   vg_set_error("vg_gemm: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
   return VG_ERR_UNSUPPORTED;
 }
+
+extern "C" int vg_gemm_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                          const float* ln_w, const float* ln_b, float ln_eps, int64_t M, int N, int K, int act,
+                          int window, int B, int H, int Wd, int ws, const void* zero_row, int dtype, vg_stream_t stream);
 
 extern "C" int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
                               const float* gamma, const void* R, int64_t ldr, int N, int K, int in_dtype, int out_dtype, int act,
@@ -1317,5 +1330,22 @@ extern "C" int vg_gemm_window(const void* A, int64_t lda, const void* W, int64_t
   g_window = GemmWindow{mode, H, Wd, ws, zero_row};
   const int rc = vg_gemm(A, lda, 0, W, ldw, 0, C, ldc, 0, bias, gamma, R, ldr, 0, (int)M, N, K, 1, in_dtype, out_dtype, act, 0, stream);
   g_window.mode = 0;
+  return rc;
+}
+
+// y = act(LayerNorm_K(A) W^T + bias): the LayerNorm in front of Hiera's q|k|v and fc1 projections at the widths of stages 1 and 2 (hieradet.py:117-123,
+// 160-166), normalised in the registers of the row-register kernel (vg_gemm_rr.hip).  window = 1: the rows are gathered window by window from an image-order
+// tensor (vg_gemm_window's mode 1; M is then derived from B, H, Wd, ws and padding rows are zero BEHIND the norm, like window_partition's F.pad).
+extern "C" int vg_gemm_ln(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                          const float* ln_w, const float* ln_b, float ln_eps, int64_t M, int N, int K, int act,
+                          int window, int B, int H, int Wd, int ws, const void* zero_row, int dtype, vg_stream_t stream) {
+  VG_CHECK(ln_w && ln_b, VG_ERR_ARG, "vg_gemm_ln: LayerNorm weight / bias missing");
+  VG_CHECK(dtype == VG_BF16, VG_ERR_UNSUPPORTED, "vg_gemm_ln: bf16 only (dtype %d)", dtype);
+  g_ln = GemmLn{ln_w, ln_b, ln_eps, true};
+  int rc;
+  if (window) rc = vg_gemm_window(A, lda, W, ldw, C, ldc, bias, nullptr, nullptr, 0, N, K, dtype, dtype, act, 1, B, H, Wd, ws, zero_row, stream);
+  else if (M <= 0 || M >= (1ll << 31)) { vg_set_error("vg_gemm_ln: %lld rows", (long long)M); rc = VG_ERR_ARG; }
+  else rc = vg_gemm(A, lda, 0, W, ldw, 0, C, ldc, 0, bias, nullptr, nullptr, 0, 0, (int)M, N, K, 1, dtype, dtype, act, 0, stream);
+  g_ln.on = false;
   return rc;
 }

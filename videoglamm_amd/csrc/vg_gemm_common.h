@@ -24,6 +24,8 @@ struct GemmArgs {
   int ksplit, kchunk; float* part;
   int nbatch;   // persistent 256x256 kernel: batch count (tiles of all batch entries form one queue)
   int nt;       // output tiles leave with non-temporal (streaming) stores: large outputs whose rows are whole 64-byte sectors (launch_gemm)
+  // LayerNorm over K in front of the contraction (vg_gemm_ln; the row-register kernel only): A rows are normalised as they arrive in registers
+  const float* ln_w; const float* ln_b; float ln_eps;
 };
 
 // window-order row m -> image-order row, or -1 for a padding row (backbones/utils.py:16-38 window_partition).

@@ -19,7 +19,7 @@
 
 namespace {
 
-template <int KS, bool RESIDENT, int ACT, bool RES>
+template <int KS, bool RESIDENT, int ACT, bool RES, bool LNP>
 __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char rr_smem[];
   constexpr int K = KS * 16, RSW = K * 2 + 16, SLOT = 64 * RSW, PPR = K / 8;   // 16-byte pieces per W row
@@ -49,9 +49,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
   // waits out a full store round trip (measured: 25 us per 256-row panel instead of 6)
   float* bias_s = (float*)rr_smem;
   const int nbias = nch * 64;
-  char* slab = rr_smem + nbias * 4 + wave * 4096;         // wave-private: 32 rows x 64 bf16 of the chunk being stored (16-byte pieces XOR-swizzled by row)
-  char* slots = rr_smem + nbias * 4 + 8 * 4096;
+  float* ln_s = bias_s + nbias;                            // LNP: gamma[K] | beta[K]
+  constexpr int LNB = LNP ? 2 * K * 4 : 0;
+  char* slab = rr_smem + nbias * 4 + LNB + wave * 4096;   // wave-private: 32 rows x 64 bf16 of the chunk being stored (16-byte pieces XOR-swizzled by row)
+  char* slots = rr_smem + nbias * 4 + LNB + 8 * 4096;
   for (int i = tid; i < nbias; i += 512) bias_s[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
+  if constexpr (LNP) {
+    for (int i = tid; i < K; i += 512) { ln_s[i] = p.ln_w ? p.ln_w[i] : 1.f; ln_s[K + i] = p.ln_b ? p.ln_b[i] : 0.f; }
+  }
   const int npanel = (p.M + 255) >> 8;
   const int mine = ((int)blockIdx.x < npanel) ? (npanel - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // panels blockIdx.x, + gridDim.x, ...
   if (mine == 0) return;
@@ -69,6 +74,50 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
   }
 
   u32x4_t areg[KS];
+  bool avalid = false, nvalid = false;      // LNP: the lane's row holds data (a padding row of the window gather stays zero BEHIND the LayerNorm, as F.pad does)
+  // LayerNorm of the wave's 32 rows in place: lane (row, half) holds K / 2 of the row's values, its partner lane the rest; two-pass fp32 statistics and the
+  // bf16-rounded output of vg_layernorm (norm_short_kernel: same expressions)
+  auto ln_apply = [&](u32x4_t (&a)[KS], bool valid) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += __uint_as_float(a[j][e] << 16) + __uint_as_float(a[j][e] & 0xffff0000u);
+    sum += __shfl_xor(sum, 32, 64);
+    const float invK = 1.0f / (float)K, mean = sum * invK;
+    // (the packed rows are re-unpacked in every pass: left to itself the compiler keeps all K / 2 unpacked values of the lane alive across the three passes —
+    //  72 / 144 more registers, 150-330 of them spilled)
+    auto opaque = [&]() {
+#pragma unroll
+      for (int j = 0; j < KS; ++j) asm volatile("" : "+v"(a[j][0]), "+v"(a[j][1]), "+v"(a[j][2]), "+v"(a[j][3]));
+    };
+    opaque();
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = __uint_as_float(a[j][e] << 16) - mean, d1 = __uint_as_float(a[j][e] & 0xffff0000u) - mean;
+        q += d0 * d0 + d1 * d1;
+      }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * invK + p.ln_eps);
+    opaque();
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      asm volatile("" ::: "memory");          // gamma / beta are read here, per panel: hoisted out of the panel loop they are 2 K / 2 registers per lane (spills)
+      const int k = j * 16 + h * 8;
+      const f32x4_t w0 = *(const f32x4_t*)(ln_s + k), w1 = *(const f32x4_t*)(ln_s + k + 4);
+      const f32x4_t b0 = *(const f32x4_t*)(ln_s + K + k), b1 = *(const f32x4_t*)(ln_s + K + k + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float n0 = (__uint_as_float(a[j][e] << 16) - mean) * rstd, n1 = (__uint_as_float(a[j][e] & 0xffff0000u) - mean) * rstd;
+        const float g0 = e < 2 ? w0[2 * e] : w1[2 * e - 4], g1 = e < 2 ? w0[2 * e + 1] : w1[2 * e - 3];
+        const float c0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], c1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+        a[j][e] = valid ? f2bf2(n0 * g0 + c0, n1 * g1 + c1) : 0u;
+      }
+    }
+  };
   int64_t orow = -1;            // output (and residual) row of this lane's GEMM row; -1: nothing to store
   int64_t orow_s[4];            // output rows of the store layout: pass s writes rows 8 s + lane / 8 of the wave's 32, eight lanes per row
   auto aload = [&](int panel) {
@@ -78,6 +127,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     const bf16_t* ap = (const bf16_t*)p.A + (src >= 0 ? src : 0) * p.lda + h * 8;
 #pragma unroll
     for (int j = 0; j < KS; ++j) areg[j] = src >= 0 ? *(const u32x4_t*)(ap + j * 16) : zero4;
+    avalid = src >= 0;
   };
   auto out_row = [&](int panel) {
     const int m = panel * 256 + wave * 32 + l31;
@@ -156,10 +206,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
   };
 
-  // K = 144: the next panel's rows have their own registers and are requested at the TOP of the current panel — by the time they are needed every store that
+  // K = 144, W resident: the next panel's rows have their own registers and are requested at the TOP of the current panel — by the time they are needed every store that
   // was issued before them has long been acknowledged (vmcnt retires in order: a load behind fresh stores waits out their round trip).  K = 288 has no room
   // for a second set (72 registers): its rows are requested behind the last MFMA of the panel.
-  constexpr bool ADB = KS <= 9;
+  constexpr bool ADB = KS <= 9 && RESIDENT;       // (the streamed form at K = 144 has the W-chunk registers on top: a second row set spills)
   u32x4_t anext[ADB ? KS : 1];
   auto aload_next = [&](int panel) {
     const int m = panel * 256 + wave * 32 + l31;
@@ -168,6 +218,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     const bf16_t* ap = (const bf16_t*)p.A + (src >= 0 ? src : 0) * p.lda + h * 8;
 #pragma unroll
     for (int j = 0; j < (ADB ? KS : 1); ++j) anext[j] = src >= 0 ? *(const u32x4_t*)(ap + j * 16) : zero4;
+    nvalid = src >= 0;
   };
 
   // one 64-column chunk of the panel: MFMAs, then (STREAM) the next chunk's W goes to its slot and the one after is requested, then the epilogue
@@ -218,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     const int panel = (int)blockIdx.x + it * (int)gridDim.x;
     const int nextp = it + 1 < mine ? panel + (int)gridDim.x : -1;
     out_row(panel);
+    if constexpr (LNP) ln_apply(areg, avalid);
     if constexpr (ADB) {
       if (nextp >= 0) aload_next(nextp);
     }
@@ -235,6 +287,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
       if (nextp >= 0) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) areg[j] = anext[j];
+        avalid = nvalid;
       }
     }
   }
@@ -242,18 +295,22 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
 
 template <int KS, bool RESIDENT>
 static int rr_launch_v(const GemmArgs& q, int wgs, size_t lds, hipStream_t st) {
-#define VG_RR_GO(A, R)                                                                                                                       \
-  do {                                                                                                                                       \
-    static bool attr = false;                                                                                                                \
-    if (!attr) {                                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_rr_kernel<KS, RESIDENT, A, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
-      attr = true;                                                                                                                           \
-    }                                                                                                                                        \
-    gemm_rr_kernel<KS, RESIDENT, A, R><<<wgs, 512, lds, st>>>(q);                                                                            \
+#define VG_RR_GO(A, R, L)                                                                                                                       \
+  do {                                                                                                                                          \
+    static bool attr = false;                                                                                                                   \
+    if (!attr) {                                                                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_rr_kernel<KS, RESIDENT, A, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+      attr = true;                                                                                                                              \
+    }                                                                                                                                           \
+    gemm_rr_kernel<KS, RESIDENT, A, R, L><<<wgs, 512, lds, st>>>(q);                                                                            \
   } while (0)
-  if (q.R) VG_RR_GO(VG_ACT_NONE, true);
-  else if (q.act == VG_ACT_GELU) VG_RR_GO(VG_ACT_GELU, false);
-  else VG_RR_GO(VG_ACT_NONE, false);
+  const bool ln = q.ln_w || q.ln_b;
+  if (ln) {
+    if (q.act == VG_ACT_GELU) VG_RR_GO(VG_ACT_GELU, false, true);
+    else VG_RR_GO(VG_ACT_NONE, false, true);
+  } else if (q.R) VG_RR_GO(VG_ACT_NONE, true, false);
+  else if (q.act == VG_ACT_GELU) VG_RR_GO(VG_ACT_GELU, false, false);
+  else VG_RR_GO(VG_ACT_NONE, false, false);
 #undef VG_RR_GO
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -264,15 +321,15 @@ static int rr_launch_v(const GemmArgs& q, int wgs, size_t lds, hipStream_t st) {
 // K in {144, 288}, bf16 in and out, N a multiple of 16, 16-byte aligned C / R rows, act none | GELU (GELU without a residual), no LayerScale / fp8 scales / batch
 bool vg_gemm_rr_eligible(const GemmArgs& p, int batch, bool out_is_bf16) {
   return (p.K == 144 || p.K == 288) && out_is_bf16 && batch == 1 && !p.a_op && !p.sa && !p.gamma && p.vec_out && p.N % 16 == 0 && p.N >= 16 &&
-         (p.act == VG_ACT_NONE || (p.act == VG_ACT_GELU && !p.R)) && p.ksplit <= 1;
+         (p.act == VG_ACT_NONE || (p.act == VG_ACT_GELU && !p.R)) && p.ksplit <= 1 && !((p.ln_w || p.ln_b) && p.R);
 }
 
 int vg_gemm_rr_launch(const GemmArgs& q, int ncu, hipStream_t st) {
   const int npanel = (q.M + 255) / 256, wgs = npanel < ncu ? npanel : ncu, nch = (q.N + 63) / 64;
-  const int slot = 64 * (q.K * 2 + 16);
+  const size_t slot = 64 * (size_t)(q.K * 2 + 16), fixed = (size_t)nch * 256 + ((q.ln_w || q.ln_b) ? 8 * (size_t)q.K : 0) + 8 * 4096;   // bias | gamma, beta | slabs
   if (q.K == 144) {
-    if ((size_t)nch * (slot + 256) + 32768 <= 158 * 1024) return rr_launch_v<9, true>(q, wgs, (size_t)nch * (slot + 256) + 32768, st);
-    return rr_launch_v<9, false>(q, wgs, 2 * (size_t)slot + (size_t)nch * 256 + 32768, st);
+    if (fixed + nch * slot <= 158 * 1024) return rr_launch_v<9, true>(q, wgs, fixed + nch * slot, st);
+    return rr_launch_v<9, false>(q, wgs, fixed + 2 * slot, st);
   }
-  return rr_launch_v<18, false>(q, wgs, 2 * (size_t)slot + (size_t)nch * 256 + 32768, st);
+  return rr_launch_v<18, false>(q, wgs, fixed + 2 * slot, st);
 }

@@ -281,13 +281,39 @@ def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
     ok = lib.vg_mlp_rows_supported(C, H) or (force and C in (144, 288) and H % 32 == 0)
     if not (x.dtype == torch.bfloat16 and ok and w1.shape == (H, C) and w2.shape == (C, H)
             and w1.is_contiguous() and w2.is_contiguous()):
-        h = _linear(layernorm(x, ln[0], ln[1], ln[2]), w1, b1, ACT_GELU)
+        h = linear_ln(x, ln, w1, b1, ACT_GELU)          # (one launch at stage 2's width: vg_gemm_ln; norm + linear otherwise)
         return _linear(h, w2, b2, ACT_NONE, None, x)
     x2, M, ldx = _rows2d(x)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     rc = lib.vg_mlp_rows(_p(x2), ldx, _p(out), C, _p(_f32(ln[0])), _p(_f32(ln[1])), float(ln[2]), _p(w1), _p(_f32(b1)), _p(w2), _p(_f32(b2)),
                          M, C, H, BF16, _stream())
     _lib.check(rc, "vg_mlp_rows")
+    return out
+
+
+def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
+    """act(LayerNorm(x) @ w^T + bias); ln = (weight, bias, eps).  window = (B, H, W, ws): x is image-order [B,H,W,K] and the output window-order
+    [Bw, ws*ws, N] (window_partition behind the norm, as linear_window's gather).  ONE launch where the row-register kernel is built for the shape
+    (vg_gemm_ln: bf16, K = 144 / 288, >= 65536 rows — Hiera stages 1 and 2), the norm and the projection as two launches otherwise."""
+    lib = _lib.load()
+    N, K = w.shape
+    x2, M, lda = _rows2d(x)
+    if window is not None:
+        B, H, W, ws = window
+        Bw = B * (-(-H // ws)) * (-(-W // ws))
+        M = Bw * ws * ws
+    fused = (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == x.dtype and w.stride(1) == 1 and act in (ACT_NONE, ACT_GELU)
+             and lib.vg_gemm_route(M, N, K, BF16, 0, 1 if window is not None else 0) == 7)
+    if not fused:
+        xn = layernorm(x, ln[0], ln[1], ln[2])
+        return linear_window(xn, w, bias, *window, scatter=False, act=act) if window is not None else _linear(xn, w, bias, act)
+    out = torch.empty((Bw, ws * ws, N) if window is not None else x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    o2, _, ldc = _rows2d(out)
+    wa = window if window is not None else (0, 0, 0, 0)
+    rc = lib.vg_gemm_ln(_p(x2), lda, _p(w), w.stride(0), _p(o2), ldc, _p(_f32(bias)), _p(_f32(ln[0])), _p(_f32(ln[1])), float(ln[2]), M, N, K, act,
+                        1 if window is not None else 0, wa[0], wa[1], wa[2], wa[3],
+                        _p(_zero_row(K, x.dtype, x.device)) if window is not None else None, BF16, _stream())
+    _lib.check(rc, "vg_gemm_ln")
     return out
 
 

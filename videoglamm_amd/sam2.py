@@ -157,22 +157,26 @@ class SAM2:
         B, H, W, _ = x.shape
         do, nh = blk["dim_out"], blk["heads"]
         hd = do // nh
-        xn = self.ln(p + "norm1", x, 1e-6)
         shortcut = x
+        ws = blk["window"]
+        wq, bq = self.P.w(self.p + p + "attn.qkv"), self.P.b(self.p + p + "attn.qkv")
         if blk["dim"] != do:
+            xn = self.ln(p + "norm1", x, 1e-6)           # two consumers (the shortcut's projection and q|k|v): the norm is its own launch
             shortcut = self.lin(p + "proj", xn)
             if blk["q_stride"]:
                 shortcut = ops.pool2(shortcut, True)
-        ws = blk["window"]
-        if ws > 0:
             # window_partition rides in the qkv GEMM's A-row gather (padding rows read zeros, like the reference's F.pad)
-            qkv = ops.linear_window(xn, self.P.w(self.p + p + "attn.qkv"), self.P.b(self.p + p + "attn.qkv"), B, H, W, ws, scatter=False)
+            qkv = ops.linear_window(xn, wq, bq, B, H, W, ws, scatter=False) if ws > 0 else self.lin(p + "attn.qkv", xn.view(B, H * W, -1))
+        else:
+            # norm1 -> q|k|v (+ the window gather) as ONE launch at the widths of stages 1 / 2 (ops.linear_ln: vg_gemm_ln), two launches elsewhere
+            ln1 = (self.P.f32(self.p + p + "norm1.weight"), self.P.f32(self.p + p + "norm1.bias"), 1e-6)
+            qkv = ops.linear_ln(x, ln1, wq, bq, window=(B, H, W, ws)) if ws > 0 else ops.linear_ln(x.view(B, H * W, -1), ln1, wq, bq)
+        if ws > 0:
             h = w = ws
             Bw = qkv.shape[0]
-            qkv = qkv.view(Bw, h * w, 3, nh, hd)
         else:
             h, w, Bw = H, W, B
-            qkv = self.lin(p + "attn.qkv", xn.view(B, H * W, -1)).view(Bw, h * w, 3, nh, hd)
+        qkv = qkv.view(Bw, h * w, 3, nh, hd)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         if blk["q_stride"]:
             q = ops.pool2(q.reshape(Bw, h, w, do) if q.is_contiguous() else qkv.view(Bw, h, w, 3 * do)[..., :do], True)
