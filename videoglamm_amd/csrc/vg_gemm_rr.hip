@@ -12,9 +12,16 @@
 //   * W is the a-operand: 64-row chunks in LDS (row stride K * 2 + 16 bytes: conflict-free ds_read_b128).  RESIDENT: all of W fits (K = 144, N <= 512)
 //     and is staged once per workgroup — the panel loop then has NO barrier; STREAM: two chunk slots, chunk c + 1 is fetched into registers before
 //     and written to LDS behind the MFMAs of chunk c, one LDS-only barrier per chunk (W comes from L2: every workgroup of an XCD streams the same chunks);
-//   * D^T = W A^T: a lane owns ONE output row and 16 of a block's 32 columns; bias / GELU / residual in registers, v_permlane32_swap turns the
-//     (4 + 4)-column pieces of the two lane halves into 16-byte row pieces, stored directly (streaming stores for big outputs, vg_gemm_common.h).
+//   * D^T = W A^T: a lane owns ONE output row and 16 of a block's 32 columns; bias (from LDS) / GELU / residual in registers, v_permlane32_swap turns the
+//     (4 + 4)-column pieces of the two lane halves into 16-byte row pieces, a wave-private 4 KB slab turns those into whole 128-byte row segments
+//     (eight lanes per row, eight rows per store instruction; streaming stores for big outputs, vg_gemm_common.h);
+//   * optional LayerNorm over K of the rows as they sit in registers (vg_gemm_ln: norm1 -> q|k|v, norm2 -> fc1).
 // HBM traffic = A once + C once (+ R); per workgroup and panel the LDS carries one W read per wave.
+// Measured (tools/lab/rr_bench.py, us, this kernel | the tile kernels): stage-1 q|k|v 400 | 610, stage-1 -> 2 projection 210 | 369, FPN level 0 165 | 262 (5.1 TB/s:
+// the practical HBM rate of a read + write stream), stage-2 q|k|v 180 | 218, stage-2 projection + residual 128 | 162, stage-2 fc1 + GELU 321 | 331 (VALU-bound
+// on the exact-erf GELU: 105 us of it).  Ablations: without its stores the stage-1 q|k|v runs 156 us (W resident) — the first version's scattered 16-byte stores
+// cost 220 us; bias loads in the epilogue (global, behind the stores in the vmcnt queue) cost 6 %.  Tried and dropped: the second wave of each SIMD running its
+// epilogue one chunk late (beside its partner's MFMAs): no gain, as on the attention kernel.
 #include "vg_gemm_common.h"
 
 namespace {
@@ -197,11 +204,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-#ifdef RR_ABL_NOSTORE
-      if (orow_s[s4] >= 0 && n + 8 <= p.N && p.M < 0) epi_store16((bf16_t*)p.C + orow_s[s4] * p.ldc + n, d[s4], p.nt);
-#else
       if (orow_s[s4] >= 0 && n + 8 <= p.N) epi_store16((bf16_t*)p.C + orow_s[s4] * p.ldc + n, d[s4], p.nt);
-#endif
     }
     asm volatile("" ::: "memory");
   };
