@@ -129,7 +129,25 @@ class GemmMeter:
             p2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
             on_p8 = (p2(ws) and H % ws == 0 and W % ws == 0 and p2(H // ws) and p2(W // ws) and x.dtype == torch.bfloat16
                      and os.environ.get("VG_GEMM_P8", "1") != "0")
-            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, self.kernel_of(M, N, K, False, not on_p8), self.scope))
+            kern = self.kernel_of(M, N, K, False, not on_p8)
+            if x.dtype == torch.bfloat16 and self.kernel_of(M, N, K, False, True) == "rr":      # (the row-register route takes any window shape)
+                kern = "rr"
+            self.rec.append((2.0 * M * N * K, e0, e1, nbytes, kern, self.scope))
+            self.shapes.append((M, N, K))
+            return y
+        def timed_ln(x, ln, w, bias=None, act=0, window=None):            # LayerNorm -> projection (ops.linear_ln): one row-register launch where it is built;
+            N, K = w.shape                                                  # its two-launch form goes through the hooks above
+            M = x.numel() // x.shape[-1]
+            if window is not None:
+                B, H, W, ws = window
+                M = B * (-(-H // ws)) * (-(-W // ws)) * ws * ws
+            if not (x.dtype == torch.bfloat16 and self.kernel_of(M, N, K, False, window is not None) == "rr"):
+                return self.orig_ln(x, ln, w, bias, act, window)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig_ln(x, ln, w, bias, act, window)
+            e1.record()
+            self.rec.append((2.0 * M * N * K, e0, e1, (x.numel() + w.numel()) * x.element_size() + y.numel() * y.element_size(), "rr", self.scope))
             self.shapes.append((M, N, K))
             return y
         from videoglamm_amd import sam2 as _sam2
@@ -146,6 +164,8 @@ class GemmMeter:
         self.ops.linear = timed
         self.orig_window = self.ops.linear_window
         self.ops.linear_window = timed_window
+        self.orig_ln = self.ops.linear_ln
+        self.ops.linear_ln = timed_ln
         return self
 
     def __exit__(self, *exc):
@@ -153,6 +173,7 @@ class GemmMeter:
         _sam2.SAM2.mask_decoder = self.orig_md
         self.ops.linear = self.orig
         self.ops.linear_window = self.orig_window
+        self.ops.linear_ln = self.orig_ln
 
     def summary(self, kernel=None, scope=None):
         torch.cuda.synchronize()

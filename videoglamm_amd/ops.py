@@ -282,7 +282,7 @@ def mlp_rows(x, ln, w1, b1, w2, b2, force=False):
     if not (x.dtype == torch.bfloat16 and ok and w1.shape == (H, C) and w2.shape == (C, H)
             and w1.is_contiguous() and w2.is_contiguous()):
         h = linear_ln(x, ln, w1, b1, ACT_GELU)          # (one launch at stage 2's width: vg_gemm_ln; norm + linear otherwise)
-        return _linear(h, w2, b2, ACT_NONE, None, x)
+        return linear(h, w2, b2, residual=x)
     x2, M, ldx = _rows2d(x)
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     rc = lib.vg_mlp_rows(_p(x2), ldx, _p(out), C, _p(_f32(ln[0])), _p(_f32(ln[1])), float(ln[2]), _p(w1), _p(_f32(b1)), _p(w2), _p(_f32(b2)),
@@ -306,7 +306,7 @@ def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
              and lib.vg_gemm_route(M, N, K, BF16, 0, 1 if window is not None else 0) == 7)
     if not fused:
         xn = layernorm(x, ln[0], ln[1], ln[2])
-        return linear_window(xn, w, bias, *window, scatter=False, act=act) if window is not None else _linear(xn, w, bias, act)
+        return linear_window(xn, w, bias, *window, scatter=False, act=act) if window is not None else linear(xn, w, bias, act=act)
     out = torch.empty((Bw, ws * ws, N) if window is not None else x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
     o2, _, ldc = _rows2d(out)
     wa = window if window is not None else (0, 0, 0, 0)
