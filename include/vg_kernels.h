@@ -198,6 +198,30 @@ int vg_decode_attention(const void* qkv, void* k_cache, void* v_cache, const flo
                         void* out, int H, int Hkv, int D, int max_len, int window, float scale, const int* pos_dev,
                         float* workspace, int64_t ws_floats, int keys_per_wg, int dtype, vg_stream_t stream);
 
+/* r06 — the decode step with the RoPE in the projection and the attention as a wave-private flash pass (bf16, head_dim 128):
+ * vg_decode_qkv_rope: q|k|v projection of the new token (RMSNorm fused as in vg_decode_gemv) with rotate-half RoPE of the q and k heads and the
+ *   KV-cache append in the GEMV's epilogue: q_out [H*D] receives the rotated query heads, k_cache / v_cache ([max_len,Hkv,D]) row *pos_dev the
+ *   rotated key / the value row.  rope_cs: fp32 [2][D/2] = cos row | sin row of position *pos_dev (kept current by vg_decode_advance).
+ *   Replaces HF LlamaAttention.forward's q_proj / k_proj / v_proj + apply_rotary_pos_emb + cache update at q_len = 1
+ *   (R/model/videogpt_plus/model/language_model/llama3_1.py:40-108 via generate).
+ * vg_decode_attention2: softmax(q.K[lo..p]^T * scale).V[lo..p] for the pre-rotated q against caches that already hold row p; keys_per_wg 128 / 256.
+ *   The caches must hold FINITE values in every row (allocate them zero-filled): rows past p are masked, not skipped.  workspace: the
+ *   vg_decode_attention one (zero-filled once; the last Hkv words are self-resetting counters).
+ * vg_decode_advance: the decode loop's bookkeeping on the device.  tok / step given (both or neither) — k = *step; raw[k] = *tok; *tok = forced[k] >= 0 ?
+ *   forced[k] : *tok; hist[k] = *tok; *step = k + 1 — then *pos += inc (0 / 1); rope_cs given — rope_cs = rows *pos of cos / sin ([max_len, half_dim],
+ *   after the increment).  forced / hist / raw may be NULL.  What HF generate()'s loop does on the host between two forward calls (logits
+ *   processor, input_ids append, cache_position + 1). */
+int vg_decode_qkv_rope_supported(int H, int Hkv, int D, int K, int dtype);
+int vg_decode_qkv_rope(const void* x, const void* Wqkv, int64_t ldw, const float* norm_w, float eps, void* q_out, void* k_cache,
+                       void* v_cache, const float* rope_cs, const int* pos_dev, int H, int Hkv, int D, int K, int dtype,
+                       vg_stream_t stream);
+int vg_decode_attention2_supported(int H, int Hkv, int D, int dtype);
+int vg_decode_attention2(const void* q, const void* k_cache, const void* v_cache, void* out, int H, int Hkv, int D, int max_len,
+                         int window, float scale, const int* pos_dev, float* workspace, int64_t ws_floats, int keys_per_wg, int dtype,
+                         vg_stream_t stream);
+int vg_decode_advance(int64_t* tok, int* pos, int* step, const int64_t* forced, int n_forced, int64_t* hist, int64_t* raw, int cap,
+                      const float* cos, const float* sin, float* rope_cs, int half_dim, int inc, vg_stream_t stream);
+
 /* vg_decode_layer (r03): everything of a decoder layer behind the q|k|v projection as ONE launch — vg_decode_attention, then
  *   y_o = attn_out . Wo^T + resid (vg_decode_gemv), and when Wgu != NULL also act = SwiGLU(RMSNorm(y_o; norm_w, eps) . Wgu^T) and
  *   y = act . Wdown^T + y_o.  The GEMV workgroups request their weight rows before the row they multiply exists and wait for it on

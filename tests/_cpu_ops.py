@@ -312,6 +312,28 @@ def add_int_(p, v):
     return p
 
 
+def decode_advance_(pos_dev, inc, tok_dev=None, step_dev=None, forced=None, hist=None, raw=None, rope=None):
+    """vg_decode_advance as stated in include/vg_kernels.h"""
+    if tok_dev is not None:
+        k = int(step_dev[0])
+        t0 = int(tok_dev[0])
+        t = t0
+        if forced is not None and k < forced.numel() and int(forced[k]) >= 0:
+            t = int(forced[k])
+        if raw is not None and k < raw.numel():
+            raw[k] = t0
+        if hist is not None and k < hist.numel():
+            hist[k] = t
+        tok_dev[0] = t
+        step_dev[0] = k + 1
+    pos_dev += inc
+    if rope is not None:
+        cos, sin, rope_cs = rope
+        hd = cos.shape[1]
+        rope_cs[:hd] = cos[int(pos_dev[0])]
+        rope_cs[hd:] = sin[int(pos_dev[0])]
+
+
 def multimask_select(masks, ious, tokens, mode, delta=0.05, thresh=0.98):
     N = masks.shape[0]
     bi = torch.arange(N)

@@ -21,7 +21,7 @@ sd = synth.device_state_dict(man, dev, torch.bfloat16)
 P = Params(sd, dev, torch.bfloat16)
 llm = cfg["llm"]
 nbytes = sum(v.numel() * 2 for k, v in sd.items() if "embed_tokens" not in k)
-for fused in ("0", "1"):
+for fused in os.environ.get("BENCH_DECODE_FUSED", "0,1").split(","):
     os.environ["VG_DECODE_FUSED"] = fused
     dec = LlamaDecoder(P, llm, -(-(S + G + 2) // 1024) * 1024)
     x = (torch.randn(S, llm["hidden"], device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.02).to(torch.bfloat16)
@@ -35,12 +35,14 @@ for fused in ("0", "1"):
     toks = []
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    sync = os.environ.get("BENCH_DECODE_SYNC", "1") == "1"      # 1: read every token back before the next step (the r05 loop); 0: steps back to back
     for _ in range(G):
         dec.decode_step()
-        toks.append(int(dec.tok_dev[0]))
+        if sync:
+            toks.append(int(dec.tok_dev[0]))
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     ms = (t3 - t2) * 1e3 / G
-    print(f"fused={fused}: prefill S={S} {1e3 * (t1 - t0):.1f} ms; decode {ms:.3f} ms/token "
+    print(f"fused={fused} rope_path={dec.rope_path} kpw2={dec.kpw2} sync={int(sync)}: prefill S={S} {1e3 * (t1 - t0):.1f} ms; decode {ms:.3f} ms/token "
           f"({nbytes / ms / 1e9:.2f} TB/s of weight bytes); tokens {toks[:8]}")
     del dec

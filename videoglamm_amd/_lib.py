@@ -45,6 +45,11 @@ def _sig(lib):
         "vg_decode_gemv_w8": ([P, P, L, P, P, P, F, P, I, I, I, I, P], c_int),
         "vg_decode_attention_ws_floats": ([I, I, I, I], c_int64),
         "vg_decode_attention": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, I, I, P], c_int),
+        "vg_decode_qkv_rope_supported": ([I, I, I, I, I], c_int),
+        "vg_decode_qkv_rope": ([P, P, L, P, F, P, P, P, P, P, I, I, I, I, I, P], c_int),
+        "vg_decode_attention2_supported": ([I, I, I, I], c_int),
+        "vg_decode_attention2": ([P, P, P, P, I, I, I, I, I, F, P, P, L, I, I, P], c_int),
+        "vg_decode_advance": ([P, P, P, P, I, P, P, I, P, P, P, I, I, P], c_int),
         "vg_decode_layer_roles": ([I, I, I, I, I, I], c_int),
         "vg_decode_layer_flag_ints": ([], c_int64),
         "vg_decode_layer": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, P, P, L, P, P, P, F, P, L, P, P, L, P, I, I, I, P], c_int),

@@ -72,6 +72,10 @@ struct DecGemvArgs {
   const void* x; const void* W; void* y; const float* nw; const void* R;
   int N, K; int64_t ldw; float eps; int ppw;
   const float* wscale;   // fp8 weights only: one fp32 scale per weight row
+  // RoPE epilogue (vg_decode_qkv_rope): the rows are the fused q|k|v projection of the new token; pairs are (d, d + D/2) of one head, rotated in
+  // registers with the CURRENT position's cos / sin row (rope_cs: [2][D/2] fp32 at a fixed address, refreshed by vg_decode_advance), q heads go to
+  // y, the new key / value rows straight into the caches at *pos_dev
+  const float* rope_cs; const int* pos_dev; void* kc; void* vc; int H, Hkv;
 };
 
 template <typename T, typename TO, bool GLU>
@@ -115,11 +119,14 @@ constexpr int DEC_MAX_PPW = 64;
 // divides by 128 chunks, e.g. Phi-3's hidden 3072 = 3 x 2 x 64 x 8).
 // W8: the weights are fp8 (OCP e4m3, one byte each) with a per-row scale; a weight chunk then covers 16 K elements = TWO
 // x chunks, and NB x CPB x 64 counts weight chunks (K = 16 x that).
-template <typename T, typename TO, bool GLU, int NB, int CPB = 4, bool W8 = false>
+// RHD = D/2 > 0: the RoPE form above (pairs (d, d + RHD) of a head instead of adjacent rows)
+template <typename T, typename TO, bool GLU, int NB, int CPB = 4, bool W8 = false, int RHD = 0>
 __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dec_smem[];
   __shared__ float red[4];
   __shared__ float res[4][DEC_MAX_PPW][2];
+  __shared__ float rope_lds[RHD > 0 ? 2 * RHD : 1];
+  static_assert(RHD == 0 || (!GLU && !W8 && 2 * RHD <= 256), "RoPE form: plain bf16 / fp32 rows");
   constexpr int KPC = 16 / sizeof(T);
   constexpr int NWV = KPC / 4;     // float4 loads of norm weight per chunk
   static_assert(!W8 || sizeof(T) == 2, "fp8 weights pair with bf16 activations");
@@ -147,12 +154,14 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
 #pragma unroll
       for (int j = 0; j < NWV; ++j) nwr[i][j] = ((const f32x4_t*)p.nw)[min(tid + 256 * i, NCH - 1) * NWV + j];
   }
+  float ropev = 0.f;               // cos (tid < RHD) / sin (RHD <= tid < 2 RHD) of the current position: requested BEFORE the weights, so the wait below costs the stream nothing
+  if constexpr (RHD > 0) ropev = p.rope_cs[min(tid, 2 * RHD - 1)];
   int ipi = p0, icb = 0;           // issue cursor (pair, batch within the pair)
   u32x4_t va0[CPB], va1[CPB], vb0[CPB], vb1[CPB];
   auto issue = [&](u32x4_t (&v0)[CPB], u32x4_t (&v1)[CPB]) {
     const int pc = min(ipi, npair - 1);                      // clamped: the two prologue issues are unconditional
-    const int n0 = GLU ? pc : 2 * pc;
-    const int n1 = GLU ? p.N + pc : min(2 * pc + 1, p.N - 1);
+    const int n0 = RHD > 0 ? (pc / max(RHD, 1)) * (2 * RHD) + pc % max(RHD, 1) : GLU ? pc : 2 * pc;
+    const int n1 = RHD > 0 ? n0 + RHD : GLU ? p.N + pc : min(2 * pc + 1, p.N - 1);
     const u32x4_t* w0 = (const u32x4_t*)(W + (int64_t)n0 * p.ldw) + icb * (64 * CPB) + lane;
     const u32x4_t* w1 = (const u32x4_t*)(W + (int64_t)n1 * p.ldw) + icb * (64 * CPB) + lane;
 #pragma unroll
@@ -195,6 +204,9 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
 #pragma unroll
     for (int i = 0; i < XN; ++i)
       if (tid + 256 * i < NCH) xs[tid + 256 * i] = xr[i];
+    if constexpr (RHD > 0) {
+      if (tid < 2 * RHD) rope_lds[tid] = ropev;
+    }
     __syncthreads();
   }
 
@@ -245,7 +257,33 @@ __global__ __launch_bounds__(256) void decode_gemv_fast_kernel(DecGemvArgs p) {
     consume(va0, va1);
   }
   // ---- 4. epilogue: one lane per pair
-  for (int i = lane; i < np; i += 64) dec_gemv_store<T, TO, GLU>(p, p0 + i, res[wave][i][0], res[wave][i][1]);
+  if constexpr (RHD > 0) {
+    const int pos = *p.pos_dev;
+    for (int i = lane; i < np; i += 64) {
+      const int pi = p0 + i, hh = pi / RHD, d = pi % RHD;
+      const float x1 = dec_round<TO>(res[wave][i][0]), x2 = dec_round<TO>(res[wave][i][1]);      // the projection materialises in the activation dtype (HF)
+      float o1 = x1, o2 = x2;
+      TO* dst;
+      if (hh < p.H + p.Hkv) {      // q and k heads: rotate-half RoPE, the arithmetic of vg_rope_kv_append / decode_attn_kernel
+        const float c = rope_lds[d], sv = rope_lds[RHD + d];
+        if (sizeof(TO) == 2) {
+          const float cb = bf2f(f2bf(c)), sb = bf2f(f2bf(sv));
+          o1 = bf2f(f2bf(x1 * cb)) + bf2f(f2bf(-x2 * sb));
+          o2 = bf2f(f2bf(x2 * cb)) + bf2f(f2bf(x1 * sb));
+        } else {
+          o1 = x1 * c - x2 * sv;
+          o2 = x2 * c + x1 * sv;
+        }
+        dst = hh < p.H ? (TO*)p.y + (int64_t)hh * (2 * RHD) : (TO*)p.kc + ((int64_t)pos * p.Hkv + (hh - p.H)) * (2 * RHD);
+      } else {
+        dst = (TO*)p.vc + ((int64_t)pos * p.Hkv + (hh - p.H - p.Hkv)) * (2 * RHD);
+      }
+      vg_elt<TO>::st(dst + d, o1);
+      vg_elt<TO>::st(dst + d + RHD, o2);
+    }
+  } else {
+    for (int i = lane; i < np; i += 64) dec_gemv_store<T, TO, GLU>(p, p0 + i, res[wave][i][0], res[wave][i][1]);
+  }
 }
 
 template <typename T, typename TO, bool GLU>
@@ -415,6 +453,47 @@ extern "C" int vg_decode_gemv(const void* x, const void* W, int64_t ldw, void* y
 #undef VG_DEC_GEMV
   vg_set_error("vg_decode_gemv: unsupported dtype combination %d -> %d", in_dtype, out_dtype);
   return VG_ERR_UNSUPPORTED;
+}
+
+// q|k|v projection of the new token with RMSNorm in front and RoPE + KV-cache append behind it (r06): the rows of a rotate-half pair
+// (d, d + D/2) go to ONE lane of the GEMV's epilogue, so the rotation is two fmas on values that are in registers anyway, the new key / value
+// rows are written where the attention kernel reads them, and that kernel (vg_decode_attention2) starts on its K / V loads instead of on a
+// RoPE phase.  rope_cs = [cos row | sin row] of position *pos_dev (vg_decode_advance keeps it current): a fixed address, no dependent load.
+extern "C" int vg_decode_qkv_rope_supported(int H, int Hkv, int D, int K, int dtype) {
+  if (H <= 0 || Hkv <= 0 || D != 128) return 0;
+  if (dtype == VG_BF16) return K == 4096 || K == 2048;
+  if (dtype == VG_F32) return K == 4096;
+  return 0;
+}
+
+template <typename T, int NB>
+static int launch_decode_qkv_rope(DecGemvArgs p, hipStream_t st) {
+  const int npair = p.N / 2;
+  const int maxw = 256 * 2 * 4;
+  int ppw = (npair + maxw - 1) / maxw;
+  for (int c = ppw; c <= 2 * ppw; ++c)
+    if (((npair + 4 * c - 1) / (4 * c)) % 256 == 0 && npair % (4 * c) == 0) { ppw = c; break; }
+  if (ppw > DEC_MAX_PPW) ppw = DEC_MAX_PPW;
+  p.ppw = ppw;
+  const int blocks = (npair + 4 * ppw - 1) / (4 * ppw);
+  decode_gemv_fast_kernel<T, T, false, NB, 4, false, 64><<<blocks, 256, (size_t)p.K * sizeof(T), st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_decode_qkv_rope(const void* x, const void* Wqkv, int64_t ldw, const float* norm_w, float eps, void* q_out, void* k_cache,
+                                  void* v_cache, const float* rope_cs, const int* pos_dev, int H, int Hkv, int D, int K, int dtype,
+                                  vg_stream_t stream) {
+  VG_CHECK(x && Wqkv && q_out && k_cache && v_cache && rope_cs && pos_dev, VG_ERR_ARG, "vg_decode_qkv_rope: null pointer");
+  VG_CHECK(vg_decode_qkv_rope_supported(H, Hkv, D, K, dtype), VG_ERR_UNSUPPORTED, "vg_decode_qkv_rope: H=%d Hkv=%d D=%d K=%d dtype=%d not covered", H, Hkv, D, K,
+           dtype);
+  const int kpc = dtype == VG_BF16 ? 8 : 4;
+  VG_CHECK(ldw % kpc == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)Wqkv & 15) == 0 && ((uintptr_t)norm_w & 15) == 0, VG_ERR_ARG,
+           "vg_decode_qkv_rope: alignment (16 bytes; ldw a multiple of %d)", kpc);
+  DecGemvArgs p{x, Wqkv, q_out, norm_w, nullptr, (H + 2 * Hkv) * D, K, ldw, eps, 1, nullptr, rope_cs, pos_dev, k_cache, v_cache, H, Hkv};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VG_BF16) return K == 4096 ? launch_decode_qkv_rope<bf16_t, 2>(p, st) : launch_decode_qkv_rope<bf16_t, 1>(p, st);
+  return launch_decode_qkv_rope<float, 4>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -625,6 +625,56 @@ def decode_attention(qkv, k_cache, v_cache, cos, sin, H, Hkv, D, pos_dev, scale,
     return out
 
 
+def decode_rope_path(H, Hkv, D, K, dtype):
+    """True when vg_decode_qkv_rope + vg_decode_attention2 cover this shape (bf16, head_dim 128: Llama-3)."""
+    lib = _lib.load()
+    dt = F32 if dtype == torch.float32 else BF16
+    return bool(lib.vg_decode_qkv_rope_supported(H, Hkv, D, K, dt) and lib.vg_decode_attention2_supported(H, Hkv, D, dt))
+
+
+def decode_qkv_rope(x, wqkv, norm_w, eps, k_cache, v_cache, rope_cs, pos_dev, H, Hkv, D, out=None):
+    """RMSNorm -> q|k|v GEMV -> RoPE -> KV append of ONE row (vg_decode_qkv_rope): -> rotated q [1, H*D]; k_cache / v_cache row *pos_dev written."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    assert x.numel() == K and x.is_contiguous() and wqkv.stride(1) == 1 and wqkv.shape == ((H + 2 * Hkv) * D, K)
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == x.dtype and pos_dev.dtype == torch.int32
+    assert rope_cs.dtype == torch.float32 and rope_cs.numel() == D and rope_cs.is_contiguous()
+    q = out if out is not None else torch.empty(1, H * D, dtype=x.dtype, device=x.device)
+    rc = lib.vg_decode_qkv_rope(_p(x), _p(wqkv), wqkv.stride(0), _p(_f32(norm_w)), float(eps), _p(q), _p(k_cache), _p(v_cache), _p(rope_cs),
+                                _p(pos_dev), H, Hkv, D, K, _dt(x), _stream())
+    _lib.check(rc, "vg_decode_qkv_rope")
+    return q
+
+
+def decode_attention2(q, k_cache, v_cache, H, Hkv, D, pos_dev, scale, ws, window=0, keys_per_wg=256):
+    """attention of the one new (pre-rotated) query row against caches that already hold its key / value row (vg_decode_attention2)."""
+    lib = _lib.load()
+    assert q.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and pos_dev.dtype == torch.int32
+    out = torch.empty(1, H * D, dtype=q.dtype, device=q.device)
+    rc = lib.vg_decode_attention2(_p(q), _p(k_cache), _p(v_cache), _p(out), H, Hkv, D, k_cache.shape[0], int(window), float(scale), _p(pos_dev),
+                                  _p(ws), ws.numel(), int(keys_per_wg), _dt(q), _stream())
+    _lib.check(rc, "vg_decode_attention2")
+    return out
+
+
+def decode_advance_(pos_dev, inc, tok_dev=None, step_dev=None, forced=None, hist=None, raw=None, rope=None):
+    """device-side bookkeeping of the decode loop (vg_decode_advance).  tok_dev + step_dev: record / force the emitted token and count the step;
+    inc: added to *pos_dev; rope = (cos, sin, rope_cs): refresh the cos / sin row of the (new) position."""
+    lib = _lib.load()
+    assert pos_dev.dtype == torch.int32 and (tok_dev is None) == (step_dev is None)
+    assert tok_dev is None or (tok_dev.dtype == torch.int64 and step_dev.dtype == torch.int32)
+    cap = 0 if hist is None else hist.numel()
+    assert (raw is None or raw.numel() == cap) and all(t is None or t.dtype == torch.int64 for t in (forced, hist, raw))
+    cos, sin, rope_cs = rope if rope is not None else (None, None, None)
+    hd = 0
+    if rope is not None:
+        hd = cos.shape[1]
+        assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and rope_cs.numel() == 2 * hd and rope_cs.dtype == torch.float32
+    rc = lib.vg_decode_advance(_p(tok_dev), _p(pos_dev), _p(step_dev), _p(forced), 0 if forced is None else forced.numel(), _p(hist), _p(raw), cap,
+                               _p(cos), _p(sin), _p(rope_cs), hd, int(inc), _stream())
+    _lib.check(rc, "vg_decode_advance")
+
+
 def decode_layer_roles(H, Hkv, D, hidden, inter, dtype):
     """0 / 1 / 3: which roles vg_decode_layer covers for this shape (0: use decode_attention + decode_gemv)."""
     return int(_lib.load().vg_decode_layer_roles(H, Hkv, D, hidden, inter, F32 if dtype == torch.float32 else BF16))

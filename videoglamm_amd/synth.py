@@ -279,7 +279,11 @@ def forced_tokens_hook(mapping):
     if not mapping:
         return None
     table = {int(k): int(v) for k, v in mapping.items()}
-    return lambda step, tok: table.get(step)
+
+    def hook(step, tok):
+        return table.get(step)
+    hook.forced_table = table      # vlm.generate applies a table-carrying hook on the device (LlamaDecoder.set_forced): no host round trip per token
+    return hook
 
 
 def install_forced_tokens(model, mapping=None):

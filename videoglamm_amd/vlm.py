@@ -175,6 +175,7 @@ class LlamaDecoder:
     cache position and the KV length all live in device memory (tok_dev / pos_dev) — so it is captured ONCE into
     a HIP graph (torch.cuda.CUDAGraph around the same C-ABI launches) and replayed per generated token: ~330
     kernel launches per token stop costing host time.  One instance is kept per model and max_len bucket."""
+    HIST = 4096      # generated tokens per clip the device-side history holds (the reference's chat caps max_new_tokens at 512)
 
     def __init__(self, params, cfg, max_len, use_graph=None):
         self.P, self.c = params, cfg
@@ -184,8 +185,9 @@ class LlamaDecoder:
         self.max_len = max_len
         self.window = int(c["sliding_window"]) + 1 if c.get("sliding_window") else 0     # visible keys, own position included
         dev, dt = params.device, params.dtype
-        self.kc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
-        self.vc = [torch.empty(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
+        # zero-filled: vg_decode_attention2 masks rows past the position instead of skipping them (every row must hold finite values)
+        self.kc = [torch.zeros(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
+        self.vc = [torch.zeros(max_len, self.Hkv, self.hd, dtype=dt, device=dev) for _ in range(c["num_layers"])]
         inv = 1.0 / (c["rope_theta"] ** (torch.arange(0, self.hd, 2, dtype=torch.int64).float() / self.hd))
         fr = torch.arange(max_len).float()[:, None] * inv[None]
         self.cos = fr.cos().to(dev).contiguous()
@@ -193,6 +195,12 @@ class LlamaDecoder:
         self.pos = 0
         self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.tok_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        # device-side loop state (vg_decode_advance): step counter, emitted / raw (pre-forcing) token history, forced-token table
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.hist = torch.zeros(self.HIST, dtype=torch.int64, device=dev)
+        self.raw = torch.zeros(self.HIST, dtype=torch.int64, device=dev)
+        self.forced = torch.full((self.HIST,), -1, dtype=torch.int64, device=dev)
+        self.rope_cs = torch.zeros(self.hd, dtype=torch.float32, device=dev)     # [cos row | sin row] of *pos_dev for vg_decode_qkv_rope
         self.hid_all = torch.empty(max_len, self.D, dtype=dt, device=dev)   # final-norm state of every position
         self.use_graph = (dev.type == "cuda") if use_graph is None else use_graph
         self.graph, self.graphs = None, {}
@@ -221,10 +229,15 @@ class LlamaDecoder:
             self.chain_roles = min(ops.decode_layer_roles(self.H, self.Hkv, self.hd, self.D, ffn, dt), int(os.environ.get("VG_DECODE_CHAIN", "0")))
             if self.chain_roles == 2:
                 self.chain_roles = 1
+        # r06: RoPE + KV append in the q|k|v GEMV's epilogue, attention as a wave-private flash pass (bf16, head_dim 128); VG_DECODE_ROPE=0 = A/B knob
+        self.rope_path = (self.fused_decode and dev.type == "cuda" and not self.chain_roles and os.environ.get("VG_DECODE_ROPE", "1") != "0"
+                          and ops.decode_rope_path(self.H, self.Hkv, self.hd, self.D, dt))
+        self.kpw2 = int(os.environ.get("VG_DEC2_KPW", "256"))
 
     def reset(self):
         self.pos = 0
         self.pos_dev.zero_()
+        self.step_dev.zero_()
 
     def _layers(self, x, pos0, pos_dev, kv_hook=None):
         """decoder stack on x [S,D]; KV appended at pos (host value pos0, or *pos_dev when given).
@@ -268,7 +281,7 @@ class LlamaDecoder:
 
     def _layers_decode(self, x):
         """the same stack for ONE new row at position *pos_dev, on the fused decode kernels: 5 launches per layer
-        (norm+qkv, rope+append+attention+merge, o+residual, norm+gate|up+SwiGLU, down+residual) instead of 9."""
+        (norm+qkv[+rope+append], [rope+append+]attention+merge, o+residual, norm+gate|up+SwiGLU, down+residual) instead of 9."""
         P, c = self.P, self.c
         if self.attn_ws is None:
             self.attn_ws = ops.decode_attention_workspace(self.H, self.Hkv, self.hd, self.max_len, x.device)
@@ -278,13 +291,26 @@ class LlamaDecoder:
                 self.chain_err = torch.zeros((), dtype=torch.int32, device=x.device)
             self.chain_err.add_(self.chain_flags[:, 1].sum())      # the previous token's gave-up words survive the memset below (generate() checks)
             self.chain_flags.zero_()          # one memset per token: every layer's arrival stripes and go flags
+        if self.rope_path:
+            ops.decode_advance_(self.pos_dev, 0, rope=(self.cos, self.sin, self.rope_cs))      # the cos / sin row of *pos_dev, once per token
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
             qkv_names = [l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"]
             gu_names = [l + "mlp.gate_proj", l + "mlp.up_proj"]
             wqkv, _ = P.fused(qkv_names, stored=l + "self_attn.qkv_proj")
-            qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
-            if self.chain_roles:
+            if self.rope_path:
+                # norm -> q|k|v -> RoPE -> append in one launch; the attention starts on its K / V loads (4 launches per layer + the MLP's 2)
+                q = ops.decode_qkv_rope(x, wqkv, P.f32(l + "input_layernorm.weight"), c["rms_eps"], self.kc[i], self.vc[i], self.rope_cs,
+                                        self.pos_dev, self.H, self.Hkv, self.hd)
+                o = ops.decode_attention2(q, self.kc[i], self.vc[i], self.H, self.Hkv, self.hd, self.pos_dev, self.hd ** -0.5, self.attn_ws,
+                                          window=self.window, keys_per_wg=self.kpw2)
+                x = ops.decode_gemv(o, P.w(l + "self_attn.o_proj"), residual=x)
+                qkv = None
+            else:
+                qkv = ops.decode_gemv(x, wqkv, norm_w=P.f32(l + "input_layernorm.weight"), eps=c["rms_eps"])
+            if qkv is None:
+                pass
+            elif self.chain_roles:
                 # r03: attention, o_proj and (bf16 Llama widths) the MLP as roles of ONE launch whose GEMV workgroups fetch their weight
                 # rows while the producer role still runs (vg_decode_layer) — bit-identical to the separate launches below
                 w_o = P.w(l + "self_attn.o_proj")
@@ -376,24 +402,37 @@ class LlamaDecoder:
         h = self._layers_decode(x) if self.fused_decode else self._layers(x, 0, self.pos_dev)
         ops.store_row_(h, self.hid_all, self.pos_dev)
         self.next_token(h)
-        ops.add_int_(self.pos_dev, 1)
+        self.advance(1)
+
+    def advance(self, inc):
+        """the host's part of HF generate()'s loop, on the device: force / record the token in tok_dev, count the step, move the position"""
+        ops.decode_advance_(self.pos_dev, inc, self.tok_dev, self.step_dev, self.forced, self.hist, self.raw)
+
+    def set_forced(self, table):
+        """{step: token id} applied to the emitted tokens on the device (step 0 = the token the prefill emits); None / {} = no forcing"""
+        f = torch.full((self.HIST,), -1, dtype=torch.int64)
+        for k, v in (table or {}).items():
+            if 0 <= int(k) < self.HIST:
+                f[int(k)] = int(v)
+        self.forced.copy_(f.to(self.forced.device))
 
     def decode_step(self):
         assert self.pos + 1 <= self.max_len
         # long caches: two 64-key blocks per decode-attention workgroup (half the partials to publish, arrive and merge: the merge of a C2 prompt's
         # 54 splits took two passes); a launch parameter, so each setting has its own captured graph.  VG_DEC_KPW_MIN = first position that uses it
-        self.kpw = 128 if self.pos >= self.kpw_min else 0
+        self.kpw = 128 if (self.pos >= self.kpw_min and not self.rope_path) else 0
         self.graph = self.graphs.get(self.kpw)
         if not self.use_graph:
             self._decode_step()
         else:
             if self.graph is None:
                 # one eager step first (lazy weight packing, kernel attribute setup), then rewind and capture
-                snap_tok, snap_pos = self.tok_dev.clone(), self.pos_dev.clone()
+                snap_tok, snap_pos, snap_step = self.tok_dev.clone(), self.pos_dev.clone(), self.step_dev.clone()
                 self._decode_step()
                 torch.cuda.synchronize()
                 self.tok_dev.copy_(snap_tok)
                 self.pos_dev.copy_(snap_pos)
+                self.step_dev.copy_(snap_step)
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: in multi-GPU runs the RCCL watchdog thread of torch.distributed polls events of
                 # finished collectives; under the default (global) mode such a call from another thread can invalidate the capture
@@ -402,6 +441,7 @@ class LlamaDecoder:
                 self.graph = self.graphs[self.kpw] = g
                 self.tok_dev.copy_(snap_tok)
                 self.pos_dev.copy_(snap_pos)
+                self.step_dev.copy_(snap_step)
             self.graph.replay()
         self.pos += 1
 
@@ -468,19 +508,65 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     if after_prefill is not None:
         after_prefill()   # e.g. enqueue the (LLM-independent, MFMA-bound) Hiera pass on a side stream so that it
         #                   overlaps the HBM-bound decode loop below
-    for step in range(max_new_tokens):
-        nxt = int(dec.tok_dev[0])
-        if trace is not None:
-            trace.setdefault("argmax", []).append(nxt)
-        if token_hook is not None:
-            repl = token_hook(step, nxt)
-            if repl is not None and int(repl) != nxt:
-                nxt = int(repl)
-                dec.tok_dev.fill_(nxt)
-        ids.append(nxt)
-        if nxt in eos or step == max_new_tokens - 1:
-            break
-        dec.decode_step()
+    # The loop.  Forcing / recording / the position bump happen on the device (LlamaDecoder.advance), so with no Python hook in the way step k + 1 is
+    # enqueued BEFORE token k is read back: the id's trip to the host and hipGraphLaunch (~85 us per token, r05 gap census) leave the critical path.
+    # The price: the step launched while an EOS token was in flight is wasted (it writes cache rows past the end that nobody reads).
+    # token_hook: a dict-carrying hook (synth.forced_tokens_hook: hook.forced_table = {step: id}) is applied on the device; any other callable
+    # is opaque Python and keeps the synchronous hand-over.  VG_DECODE_AHEAD=0: synchronous always (A/B knob).
+    table = getattr(token_hook, "forced_table", None) if token_hook is not None else {}
+    ahead = (table is not None and os.environ.get("VG_DECODE_AHEAD", "1") != "0" and max_new_tokens <= dec.HIST and params.device.type == "cuda"
+             and dec.use_graph)
+    if max_new_tokens > 0:
+        dec.set_forced(table if ahead else None)
+        dec.step_dev.zero_()
+        dec.advance(0)                       # token 0 (emitted by the prefill): forced / recorded; the position stays
+    if ahead:
+        # tokens come back on a side stream that waits only for the step that emitted them (an event per step), never for the step enqueued after it
+        main = torch.cuda.current_stream()
+        rb = dec.__dict__.setdefault("_rb_stream", torch.cuda.Stream())
+        host = dec.__dict__.setdefault("_rb_host", torch.zeros(2, dec.HIST, dtype=torch.int64).pin_memory())
+        evs = [torch.cuda.Event()]           # evs[j]: token j is in hist[j] / raw[j]
+        evs[0].record(main)
+        known = 0
+        while max_new_tokens > 0:
+            if len(evs) < max_new_tokens:    # run ahead by one: step len(evs) - 1 consumes token len(evs) - 1 and emits token len(evs)
+                dec.decode_step()
+                evs.append(torch.cuda.Event())
+                evs[-1].record(main)
+                upto = len(evs) - 1          # read what the steps BEFORE this one emitted
+            else:
+                upto = len(evs)              # nothing left to launch: read the last token too
+            with torch.cuda.stream(rb):
+                rb.wait_event(evs[upto - 1])
+                host[0, known:upto].copy_(dec.hist[known:upto], non_blocking=True)
+                if trace is not None:
+                    host[1, known:upto].copy_(dec.raw[known:upto], non_blocking=True)
+            rb.synchronize()
+            stop = False
+            for j in range(known, upto):
+                if trace is not None:
+                    trace.setdefault("argmax", []).append(int(host[1, j]))
+                ids.append(int(host[0, j]))
+                known += 1
+                if ids[-1] in eos or known == max_new_tokens:
+                    stop = True
+                    break
+            if stop:
+                break
+    else:
+        for step in range(max_new_tokens):
+            nxt = int(dec.tok_dev[0])
+            if trace is not None:
+                trace.setdefault("argmax", []).append(nxt)
+            if token_hook is not None:
+                repl = token_hook(step, nxt)
+                if repl is not None and int(repl) != nxt:
+                    nxt = int(repl)
+                    dec.tok_dev.fill_(nxt)
+            ids.append(nxt)
+            if nxt in eos or step == max_new_tokens - 1:
+                break
+            dec.decode_step()
     if dec.chain_roles and dec.chain_flags is not None and int(dec.chain_err) + int(dec.chain_flags[:, 1].sum()):
         # VG_DECODE_CHAIN: a workgroup of a chained layer launch stopped waiting for its producer role (bounded wait) — the ids above are not to be trusted
         raise ops._lib.VGKernelError("vg_decode_layer: a device-side wait gave up (flags[1] set); rerun with VG_DECODE_CHAIN=0")
