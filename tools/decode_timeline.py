@@ -11,11 +11,13 @@ rows = list(db.execute("select name, start, end from kernels order by start"))
 
 
 def role(name):
-    if "decode_attn_kernel" in name:
+    if "decode_attn_kernel" in name or "decode_attn2_kernel" in name:
         return "attention"
     if "decode_gemv_fast_kernel" in name:
-        if ", true," in name:
+        if "short, true," in name or "float, true," in name:
             return "gate|up (norm + SwiGLU)"
+        if name.rstrip(">(DecGemvArgs) ").endswith(", 64"):
+            return "qkv (norm + RoPE + append)"          # r06: the RoPE form (last template argument = D/2)
         return "down (+ residual)" if ", 7, " in name else "qkv / o"
     return None
 
@@ -34,11 +36,13 @@ last = clips[-1]
 lo, hi = last[0], last[-1]
 seq = rows[lo:hi + 1]
 dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
-prev_end, qo = None, 0
+prev_end, qo, rope_form = None, 0, False
 for name, s, e in seq:
     r = role(name)
+    if r == "qkv (norm + RoPE + append)":
+        rope_form = True
     if r == "qkv / o":
-        r = "qkv (norm fused)" if qo % 2 == 0 else "o (+ residual)"
+        r = "o (+ residual)" if rope_form else ("qkv (norm fused)" if qo % 2 == 0 else "o (+ residual)")
         qo += 1
     if r is None:
         r = "per-token tail: " + name.split("(")[0].replace("void ", "")[:60]

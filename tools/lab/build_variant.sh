@@ -7,7 +7,7 @@ name=$1; src=$2; shift 2
 V=../../build/variants; mkdir -p $V
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-variable "$@" -c "$src" -o "$V/${src%.hip}_$name.o"
 objs=""
-for o in vg_api.o vg_gemm.o vg_gemm_p8.o vg_gemm_p8n.o vg_gemm_rr.o vg_gemm_rows.o vg_mlp_rows.o vg_twoway.o vg_attention.o vg_decode.o vg_rowops.o vg_pointwise.o vg_spatial.o vg_postproc.o vg_preproc.o; do
+for o in $(sed -n "s/^SRCS = //p" Makefile | sed "s/\.hip/.o/g; s/\.cpp/.o/g"); do
   if [ "$o" = "${src%.hip}.o" ]; then objs="$objs $V/${src%.hip}_$name.o"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$V/libvg_$name.so"
