@@ -162,39 +162,66 @@ __global__ __launch_bounds__(NW * 64) void decode_attn2_kernel(DecAttn2Args p) {
   if (tid == 0) ticket = __hip_atomic_fetch_add(&p.cnt[kvh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket != nact - 1) return;
-  // ---- 5. merge by the last workgroup of this KV head to arrive: <= 16 partials per fabric round trip, sc1 loads
-  if (tid < G * 32) {
-    const int g = tid >> 5, d4 = tid & 31;
+  // ---- 5. merge by the last workgroup of this KV head to arrive.  ALL its threads load: thread group q (128 threads = one (head, 4 columns) map)
+  //         takes the partials q, q + NG, ... — 8 per thread and pass: up to 32 (NW = 8) / 16 (NW = 4) splits at G <= 4 are requested in ONE
+  //         fabric round trip (sc1 loads) — and the groups' (max, sum, acc) meet in LDS (the arrays of step 3 are free again)
+  {
+    constexpr int GS = G * 32 <= 128 ? 128 : G * 32;      // threads of one (head, 4 columns) map
+    constexpr int NG = NW * 64 / GS;
+    const int grp = tid / GS, t7 = tid % GS, g = (t7 >> 5) % G, d4 = t7 & 31;
+    const bool live = t7 < G * 32;
     const int mbase = (int)((((int64_t)kvh * p.nsplit + first) * G) * A2_PS * 4);
     float M = -INFINITY, L = 0.f;
     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < nact; b0 += 16) {
-      f32x4_t pv[16], pm[16];
+    for (int b0 = 0; b0 < nact; b0 += 8 * NG) {
+      f32x4_t pv[8], pm[8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int off = mbase + ((min(b0 + u, nact - 1) * G + g) * A2_PS) * 4;
+      for (int u = 0; u < 8; ++u) {
+        const int off = mbase + ((min(b0 + u * NG + grp, nact - 1) * G + g) * A2_PS) * 4;
         pv[u] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + d4 * 16, 0, 16));
         pm[u] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + A2_D * 4, 0, 16));
       }
       float Mn = M;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (b0 + u < nact) Mn = fmaxf(Mn, pm[u][0]);
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u * NG + grp < nact) Mn = fmaxf(Mn, pm[u][0]);
       const float fo = M == -INFINITY ? 0.f : __expf(M - Mn);
       o *= fo;
       L *= fo;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (b0 + u < nact) {
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u * NG + grp < nact) {
           const float f = pm[u][0] == -INFINITY ? 0.f : __expf(pm[u][0] - Mn);
           L = fmaf(f, pm[u][1], L);
           o += pv[u] * f;
         }
       M = Mn;
     }
-    const float inv = 1.0f / L;
-    uint2 ov = {f2bf2(o[0] * inv, o[1] * inv), f2bf2(o[2] * inv, o[3] * inv)};
-    *(uint2*)(p.o + (int64_t)(kvh * G + g) * A2_D + d4 * 4) = ov;
+    float* gml = red;                       // [NG][GS][2]
+    float* gacc = red + NG * GS * 2;        // [NG][GS][4]
+    if (live) {
+      gml[(grp * GS + t7) * 2] = M;
+      gml[(grp * GS + t7) * 2 + 1] = L;
+      *(f32x4_t*)(gacc + (grp * GS + t7) * 4) = o;
+    }
+    __syncthreads();
+    if (grp == 0 && live) {
+      float Mt = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) Mt = fmaxf(Mt, gml[(q * GS + t7) * 2]);
+      float Lt = 0.f;
+      f32x4_t ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const float mq = gml[(q * GS + t7) * 2];
+        const float f = mq == -INFINITY ? 0.f : __expf(mq - Mt);
+        Lt = fmaf(f, gml[(q * GS + t7) * 2 + 1], Lt);
+        ot += *(const f32x4_t*)(gacc + (q * GS + t7) * 4) * f;
+      }
+      const float inv = 1.0f / Lt;
+      uint2 ov = {f2bf2(ot[0] * inv, ot[1] * inv), f2bf2(ot[2] * inv, ot[3] * inv)};
+      *(uint2*)(p.o + (int64_t)(kvh * G + g) * A2_D + d4 * 4) = ov;
+    }
   }
   if (tid == 0) __hip_atomic_store(&p.cnt[kvh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
