@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-quality", action="store_true", help="skip the fp32 parity-mode re-run that fills the \"quality\" object")
     ap.add_argument("--no-video-record", action="store_true", help="skip the video-branch sub-run that fills the \"video_branch\" object of a framewise line")
     ap.add_argument("--video-steps", type=int, default=5, help="timed steps of the video-branch sub-run")
+    ap.add_argument("--no-config-records", action="store_true", help="skip the C1 / C4-clip sub-records of the default (C2) line")
     ap.add_argument("--llm", default="llama3-8b", choices=["llama3-8b", "phi3-mini"],
                     help="llama3-8b = BASELINE configs C1-C3 (default); phi3-mini = the released checkpoint's LLM")
     ap.add_argument("--tiny", action="store_true", help="plumbing check on a toy architecture (NOT a valid bench)")
@@ -525,6 +526,45 @@ def video_record(args, model, ops, inputs):
     return rec
 
 
+def config_record(args, cfg, model, device, frames, src, objects, te, fp8=False, steps=3):
+    """Another BASELINE configuration on the SAME loaded model, timed like the headline (inputs resident in HBM -> ids + masks on the host; barrier-free:
+    one GPU), as a sub-record of the default line — so that every single-GPU configuration has a driver-timed number: C1 (8 x 512^2, one [SEG]) and C4's
+    clip on one GPU (64 x 1024^2, 8 [SEG]; bf16, and with the fp8 LLM path BASELINE config C4 names: fp8 MFMA prefill GEMMs + fp8 decode weights)."""
+    import argparse
+    from videoglamm_amd import synth
+    seg = cfg["seg_token_idx"]
+    forced = {8: seg} if objects == 1 else {4 + 3 * i: seg for i in range(objects)}
+    saved_llm, saved_dec, saved_hook = model.cfg["llm"], getattr(model.P, "_decoder", None), model.token_hook
+    if fp8:
+        model.cfg["llm"] = dict(saved_llm, decode_weights="fp8", prefill_gemm="fp8")
+        model.P._decoder = None
+    try:
+        synth.install_forced_tokens(model, forced)
+        images, context, sam, ids = make_inputs(cfg, argparse.Namespace(te=te, frames=frames, scaling="strong"), 1, device)
+
+        def cstep():
+            return model.inference([images], [context], [sam], ids, [(1024, 1024)], [(src, src)], max_new_tokens=args.max_new_tokens, use_sam2_video_branch=False)
+        cstep()
+        cstep()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            out = cstep()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        n_obj = len(next(iter(out[1][0].values()))) if out[1][0] else 0
+        rec = {"frames": frames, "source": src, "encoder_frames": te, "objects": n_obj, "steps": steps, "warmup": 2, "ms_per_step": round(1e3 * dt / steps, 2),
+               "value": round(frames * steps / dt, 3), "unit": "frames/sec", "generated_tokens": int(out[0].shape[1] - ids.shape[1]),
+               "dtype": "bf16" if not fp8 else "bf16 model; LLM prefill GEMMs fp8, decode-step MLP / lm_head weights fp8 (e4m3, row scales)"}
+        del images, context, sam, out
+    finally:
+        model.cfg["llm"], model.token_hook = saved_llm, saved_hook
+        if fp8:
+            model.P._decoder = saved_dec
+        torch.cuda.empty_cache()
+    return rec
+
+
 def mask_decoder_record(model, device, frames=64, objects=8, reps=3):
     """The SAM2 mask decoder (S7 / S8: two-way transformer, upscaling, hypernetwork product, mask selection) at BASELINE config C4's size on ONE
     GPU — 64 frames x 8 [SEG] objects = 512 (frame, object) instances — as a sub-record of the C2 line, where the stage is 32 instances and too
@@ -890,6 +930,13 @@ def main():
         res["video_branch"] = video_record(args, model, ops, (images, context, sam, ids))
     if world == 1 and not use_video and not args.tiny and not args.no_video_record:
         res["roofline_mask_decoder_c4clip"] = mask_decoder_record(model, device)
+    is_c2 = (args.frames, args.src, args.objects, args.te) == (32, 1024, 1, 16) and args.llm == "llama3-8b" and (args.decode_weights, args.prefill) == ("bf16", "bf16")
+    if world == 1 and not use_video and not args.tiny and not args.no_config_records and not args.no_video_record and is_c2:
+        # the other single-GPU configurations of BASELINE.json on the same model, 3 timed steps each (C3 / C4's 8-GPU split need the node)
+        res["configs"] = {"note": "BASELINE configs beside the headline (C2), timed after it on the same loaded model: inputs in HBM -> ids + masks on the host",
+                          "c1": config_record(args, cfg, model, device, 8, 512, 1, 8),
+                          "c4_clip_one_gpu_bf16": config_record(args, cfg, model, device, 64, 1024, 8, 16),
+                          "c4_clip_one_gpu_fp8_llm": config_record(args, cfg, model, device, 64, 1024, 8, 16, fp8=True)}
     if world == 1 and not args.no_quality and not args.tiny:
         res["quality"] = quality(cfg, args, model, step, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:      # the CPU leg runs at N = 1 only

@@ -118,6 +118,90 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, q):
+    """world 8 (BASELINE configs C3 / C4's split): the partition maths and every collective of dist.py with 8 participants, on the micro model"""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    import _cpu_ops
+    import _golden as G
+    from oracle import seeded
+    from videoglamm_amd import ops
+    from videoglamm_amd.dist import FrameSharder
+    from videoglamm_amd.params import Params
+    from videoglamm_amd.sam2 import SAM2
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(1)
+    for name in _cpu_ops.ALL:
+        if hasattr(ops, name):
+            setattr(ops, name, getattr(_cpu_ops, name))
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sd = G.weights("sam2_micro_manifest.json", 1, seeded.sam2_overrides())
+    m = SAM2(Params(sd, "cpu", torch.float32), "", G.sam2_cfg())
+    hw = (40, 56)
+    comm = FrameSharder()
+    shard = FrameSharder(gather_masks=False)
+    # ---- the partition itself: C3 = 32 frames / 8, C4 = 64 frames / 8 and 8 objects / 8, T < world, ragged
+    assert comm.my_frames(32) == list(range(4 * rank, 4 * rank + 4)) and comm.my_frames(64) == list(range(8 * rank, 8 * rank + 8))
+    assert comm.block(8) == (rank, 1) and comm.block(3) == ((rank, 1) if rank < 3 else (3, 0))
+    cover = [None] * world
+    dist.all_gather_object(cover, comm.my_frames(37))
+    assert sorted(sum(cover, [])) == list(range(37)) and max(len(c) for c in cover) - min(len(c) for c in cover) <= 5      # blocks of ceil(37 / 8)
+    # ---- C3: a 32-frame clip, one [SEG] object, frames sharded 8-way; the [SEG] embedding broadcast from rank 0; masks all-gathered
+    T = 32
+    images = G.rnd((T, 3, 256, 256), 61)
+    text1 = G.rnd((1, 256), 62, 0.5)
+    emb = comm.sync_seg_embeddings(text1 + 0.01 * rank)
+    assert torch.equal(emb, text1)
+    masks, fids = comm.framewise(m, images, emb, hw)
+    local, lf = shard.framewise(m, images, emb, hw)
+    assert fids == list(range(T)) and lf == comm.my_frames(T) and torch.equal(local, masks[lf[0]:lf[-1] + 1])
+    # ---- C4's split: 8 [SEG] objects, one per rank, over all-gathered Hiera features (a 12-frame clip keeps the CPU run short; the frame
+    #      count enters only through the partition checked above); every rank ends with every object's masks
+    T4, N4 = 12, 8
+    text8 = G.rnd((N4, 256), 63, 0.5)
+    feats = comm.hiera_all_frames(m, images[:T4])
+    assert sorted(feats) == list(range(T4))
+    vid_obj, oids = comm.video_branch_objects(m, images[:T4], text8, hw, feats)
+    lobj, lo = shard.video_branch_objects(m, images[:T4], text8, hw, feats)
+    assert oids == list(range(N4)) and lo == [rank] and torch.equal(lobj, vid_obj[:, rank:rank + 1])
+    # ---- T < world: 3 frames over 8 ranks (ranks 3..7 own none and still join every collective)
+    m3, f3 = comm.framewise(m, images[:3], emb, hw)
+    feats3 = comm.hiera_all_frames(m, images[:3])
+    assert f3 == [0, 1, 2] and sorted(feats3) == [0, 1, 2]
+    l3, lf3 = shard.framewise(m, images[:3], emb, hw)
+    assert lf3 == ([rank] if rank < 3 else []) and l3.shape[0] == len(lf3)
+    if rank == 0:
+        ref_logits, _ = m.framewise_branch(images, text1, hw)
+        ok_c3 = bool(torch.equal(masks, (ref_logits > 0).to(torch.uint8))) and bool(torch.equal(m3, (ref_logits[:3] > 0).to(torch.uint8)))
+        ref_vid = (m.video_branch(images[:T4], text8, hw) > 0).to(torch.uint8)
+        ok_c4 = bool(vid_obj.shape == ref_vid.shape) and float((vid_obj != ref_vid).float().mean()) < 1e-4      # per-object batches: summation order
+        ok_feats = all(torch.equal(a, b) for t in range(3) for a, b in zip(feats3[t], feats[t]))
+        q.put((ok_c3, ok_c4 and ok_feats, tuple(masks.shape), tuple(vid_obj.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_and_object_sharding_world8():
+    """BASELINE configs C3 (32 frames sharded 8-way, RCCL all-gather of the [SEG] state) and C4's split (8 [SEG] objects over 8 ranks) as
+    world-size-8 gloo processes on the CPU twins: the sharded result IS the single-process result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ok_c3, ok_c4, shape, vshape = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert shape == (32, 1, 40, 56) and vshape == (12, 8, 40, 56)
+    assert ok_c3, "C3: frame-sharded (8-way) framewise masks differ from the single-process result"
+    assert ok_c4, "C4 split: object-sharded (8-way) propagation / T < world feature exchange differ from the single-process result"
+
+
 def test_frame_sharding_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -81,6 +81,7 @@ def test_decode_chain_launch_equals_separate(cuda, dt, monkeypatch):
     c, sd, x = _llama2(cuda, S + G)
     P = Params({k: v.float() if dt == torch.float32 else v for k, v in sd.items()}, cuda, dt)
     got = {}
+    monkeypatch.setenv("VG_DECODE_ROPE", "0")          # the chained launch is built from the r05 kernels (RoPE + merge inside the attention role): compare like with like
     for chain in ("0", "3"):
         monkeypatch.setenv("VG_DECODE_CHAIN", chain)
         dec = LlamaDecoder(P, c, 1024, use_graph=False)

@@ -508,13 +508,16 @@ def generate(params, cfg, towers, images, context_images, input_ids, max_new_tok
     if after_prefill is not None:
         after_prefill()   # e.g. enqueue the (LLM-independent, MFMA-bound) Hiera pass on a side stream so that it
         #                   overlaps the HBM-bound decode loop below
-    # The loop.  Forcing / recording / the position bump happen on the device (LlamaDecoder.advance), so with no Python hook in the way step k + 1 is
-    # enqueued BEFORE token k is read back: the id's trip to the host and hipGraphLaunch (~85 us per token, r05 gap census) leave the critical path.
-    # The price: the step launched while an EOS token was in flight is wasted (it writes cache rows past the end that nobody reads).
-    # token_hook: a dict-carrying hook (synth.forced_tokens_hook: hook.forced_table = {step: id}) is applied on the device; any other callable
-    # is opaque Python and keeps the synchronous hand-over.  VG_DECODE_AHEAD=0: synchronous always (A/B knob).
+    # The loop.  Forcing / recording / the position bump can happen on the device (LlamaDecoder.advance), so with no Python hook in the way step k + 1
+    # can be enqueued BEFORE token k is read back (VG_DECODE_AHEAD=1: tokens return on a side stream behind per-step events; the step launched while
+    # an EOS token was in flight is wasted — it writes cache rows past the end that nobody reads).  Built for VERDICT r05 item 1(c) and measured r06 on C2
+    # (tools/lab/r06_c2_ab.sh, same box): the synchronous hand-over costs ~16 us per token in the serial decode stage (2.98 ms wall vs 2.966 ms of graph
+    # time), and the run-ahead loop's events + side-stream copies make every replayed step ~0.17 ms LONGER (3.13 vs 2.97 ms per token; clip 252.6 vs
+    # 248.2 ms) — so the default is the synchronous loop; the opt-in stays for runtimes where the hand-over is the larger term.
+    # token_hook: a dict-carrying hook (synth.forced_tokens_hook: hook.forced_table = {step: id}) can be applied on the device; any other callable
+    # is opaque Python and always keeps the synchronous hand-over.
     table = getattr(token_hook, "forced_table", None) if token_hook is not None else {}
-    ahead = (table is not None and os.environ.get("VG_DECODE_AHEAD", "1") != "0" and max_new_tokens <= dec.HIST and params.device.type == "cuda"
+    ahead = (table is not None and os.environ.get("VG_DECODE_AHEAD", "0") == "1" and max_new_tokens <= dec.HIST and params.device.type == "cuda"
              and dec.use_graph)
     if max_new_tokens > 0:
         dec.set_forced(table if ahead else None)
