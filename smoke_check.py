@@ -1,11 +1,11 @@
-"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0 (HIP kernels, fp32 parity mode)
+"""TEST INFRASTRUCTURE (repo root, outside the product package: it imports oracle/).  __graft_entry__.smoke(): one small invocation of the hot path on cuda:0 (HIP kernels, fp32 parity mode)
 checked against the oracle (CPU restatement of the reference) on the same seeded weights and inputs."""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def run():

@@ -98,6 +98,80 @@ def test_c3_two_ranks_on_one_gpu(cuda):
         assert r["t1"] and r["llm_sharded_ids"] and r["llm_sharded_iou"] > 0.999, (rank, r)
 
 
+def _worker_c3_full(rank, world, port, q):
+    """BASELINE config C3's REAL workload — 32 x 1024^2 SAM frames, Te = 16, Llama-3-8B + InternVideo2-1B + CLIP-L/336 + SAM2-L in bf16, one forced [SEG],
+    32 greedy tokens — as two ranks on the one GPU of the box (gloo moves host copies): frames sharded 16 + 16 for Hiera + FPN and the mask decoder,
+    the [SEG] embedding synchronised from rank 0, masks gathered; against the SAME model run unsharded in the same process."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+
+    from videoglamm_amd import synth
+    from videoglamm_amd.dist import FrameSharder
+    from videoglamm_amd.model import VideoGLaMMForCausalLM
+
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = synth.videoglamm_llama3_8b()
+    cfg["forced_tokens"] = {8: cfg["seg_token_idx"]}
+    sd = synth.device_state_dict(synth.manifest(cfg), dev, torch.bfloat16)
+    model = synth.install_forced_tokens(VideoGLaMMForCausalLM(sd, cfg, torch_dtype=torch.bfloat16, device=dev))
+    del sd
+    g = torch.Generator().manual_seed(1234)
+    te, T = 16, 32
+    images = torch.randn(te, 3, 224, 224, generator=g).to(dev)
+    context = torch.randn(te, 3, 336, 336, generator=g).to(dev)
+    sam = torch.randn(T, 3, 1024, 1024, generator=g).to(dev)
+    ids = torch.cat([torch.tensor([1, 5, 6]), torch.full((te,), -200), torch.randint(3, cfg["llm"]["vocab"] - 2, (30,), generator=g)])[None]
+
+    def run(frames=sam):
+        out_ids, segs = model.inference([images], [context], [frames], ids, [(1024, 1024)], [(1024, 1024)], max_new_tokens=32, use_sam2_video_branch=False)
+        return out_ids[0].tolist(), segs[0]
+
+    ref_ids, ref_seg = run()                                   # the whole clip unsharded, this process
+    _, half_seg = run(sam[16 * rank:16 * rank + 16])           # this rank's 16 frames unsharded: the batch composition of its shard
+    model.comm = FrameSharder()                                # whole clip back on every rank
+    got_ids, got_seg = run()
+    a, b = _stack(got_seg), _stack(ref_seg)
+    mine = a[16 * rank:16 * rank + 16]
+    res = {"ids": got_ids == ref_ids, "n_ids": len(got_ids) - ids.shape[1], "frames": sorted(got_seg) == list(range(T)), "shape": tuple(a.shape),
+           "whole_clip_bitexact": bool(np.array_equal(a, b)), "pixel_agreement_vs_unsharded_32": float((a == b).mean()), "mask_fraction": float(b.mean()),
+           "own_frames_bitexact_vs_unsharded_16": bool(np.array_equal(mine, _stack(half_seg)))}
+    inter, union = (a & b).sum(axis=(1, 2, 3)), (a | b).sum(axis=(1, 2, 3))
+    res["min_frame_iou"] = float((inter / np.maximum(union, 1)).min())
+    model.comm = FrameSharder(gather_masks=False)              # every rank keeps its 16 frames
+    _, my_seg = run()
+    res["shard"] = sorted(my_seg) == list(range(16 * rank, 16 * rank + 16)) and bool(np.array_equal(_stack(my_seg), mine))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_c3_full_size_two_ranks_on_one_gpu(cuda):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_c3_full, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=1500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = got[rank]
+        print(f"  C3 full size, rank {rank}: {r}")
+        assert r["ids"] and r["n_ids"] == 32 and r["frames"] and r["shape"] == (32, 1, 1024, 1024), (rank, r)
+        # a rank's shard IS the unsharded run of its 16 frames, bit for bit (same launches on the same data); against the unsharded 32-frame run the
+        # mask decoder's batch is 16 instead of 32 (frame, object) pairs — other GEMM tile routes, another bf16 rounding order: the random-weight
+        # masks (58 % foreground, boundary everywhere) move in ~0.2 % of the pixels; ids are equal by construction (LLM side replicated)
+        assert r["own_frames_bitexact_vs_unsharded_16"] and r["shard"], (rank, r)
+        assert r["pixel_agreement_vs_unsharded_32"] > 0.99 and r["min_frame_iou"] > 0.985 and 0.0 < r["mask_fraction"] < 1.0, (rank, r)
+
+
 def _worker_rccl(port, q):
     """ONE rank, backend "nccl" (= RCCL): the device-buffer branches of FrameSharder (dist.all_gather on device tensors, all_gather_into on
     recv.chunk() views, the async all_gather_into_tensor of the streamed features) — the code the driver's multi-GPU run takes, which the

@@ -1,7 +1,7 @@
 """End-to-end against the ORACLE on ragged shapes the golden fixtures do not cover: a one-frame clip, odd output sizes,
 one / three [SEG] objects, both SAM2 branches, Te = 4 and 8.  Random weights never emit [SEG], so the product forces it at
 given decode steps (after the full lm_head + argmax) and the oracle — which restates the reference and has no such knob —
-replays the emitted ids by teacher forcing (videoglamm_amd/smoke.py:_oracle, the same scheme as __graft_entry__.smoke())."""
+replays the emitted ids by teacher forcing (smoke_check.py:_oracle, the same scheme as __graft_entry__.smoke())."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +26,7 @@ def check(device, case):
     from oracle import pipeline, seeded
     from videoglamm_amd import synth
     from videoglamm_amd.model import VideoGLaMMForCausalLM
-    from videoglamm_amd.smoke import _oracle
+    from smoke_check import _oracle
 
     T, te, hw, forced, branch = case
     cfg = dict(CFG, forced_tokens=forced)

@@ -75,24 +75,14 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
   }
 }
 
-#ifndef VG_ATTN_PREFETCH
+// measured constants of the tile loop (DESIGN_HISTORY.md section 5d has the A/B of each): K/V tile prefetch, Q fragments in registers, V through
+// ds_read_b64_tr_b16, two K/V tile buffers in the DV = 64 form, minimum workgroups per CU in __launch_bounds__
 #define VG_ATTN_PREFETCH 1
-#endif
-#ifndef VG_ATTN_QREG
 #define VG_ATTN_QREG 1
-#endif
-#ifndef VG_ATTN_VTR
 #define VG_ATTN_VTR 1
-#endif
-#ifndef VG_ATTN_DB
 #define VG_ATTN_DB 1
-#endif
-#ifndef VG_ATTN_MINW
 #define VG_ATTN_MINW 2
-#endif
-#ifndef VG_ATTN_MINW96
 #define VG_ATTN_MINW96 2
-#endif
 
 // KS = 2 (head dim 256, SAM2's memory attention): the two 32-key halves of every KV tile go to two different waves of the same
 // 32 query rows — 8 waves on the LDS footprint of 4, each with its own (O, m, l) over its half of the keys, merged through LDS

@@ -61,7 +61,7 @@ __device__ __forceinline__ float wave_max(float v) {
 //   (2) everything in terms of x (the 1/sqrt 2 folded into the constants, 0.5 folded into the polynomial), exp2 argument c * x * x, and the branch
 //       "x < 0 ? q : 1 - q" as 0.5 + copysign(0.5 - q, x): one v_bfi instead of compare + select, and straight-line code the compiler packs into
 //       v_pk_fma_f32 / v_pk_mul_f32 pairs.  (0.5 - q loses the RELATIVE accuracy of Phi deep in the negative tail — absolute error of x * Phi(x)
-//       <= |x| * 6e-8 there, the rounding level of every other term; libm's erff: -DVG_LIBM_ERF.)
+//       <= |x| * 6e-8 there, the rounding level of every other term.)
 __device__ __forceinline__ float vg_gelu_erf(float x) {
   const float a = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, a, 1.0f));
@@ -81,11 +81,7 @@ __device__ __forceinline__ float vg_silu(float g) { return g * __builtin_amdgcn_
 // activation codes (vg_kernels.h): 0 none, 1 gelu(erf), 2 quick_gelu, 3 relu, 4 silu, 5 sigmoid
 __device__ __forceinline__ float vg_act(float x, int act) {
   switch (act) {
-#ifdef VG_LIBM_ERF
-    case VG_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-#else
     case VG_ACT_GELU: return vg_gelu_erf(x);
-#endif
     case VG_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case VG_ACT_RELU: return x > 0.f ? x : 0.f;
     case VG_ACT_SILU: return vg_silu(x);

@@ -190,9 +190,6 @@ __device__ __forceinline__ void gemm_epilogue128(const GemmArgs& p, f32x16_t (&a
 // by an XOR swizzle applied to the per-lane SOURCE chunk and again to the fragment reads (slot = chunk ^ ((row>>1)&7):
 // within a ds_read_b128 lane group the 16 rows then hit 16 distinct 4-bank slots).  Out-of-range rows are clamped
 // and discarded by the epilogue; a partial last K step goes through registers (issue_tail).
-#ifndef VG_GLDS_SPREAD
-#define VG_GLDS_SPREAD 0
-#endif
 template <typename T, typename TO, bool FRAG_ALL = false>
 __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,13 +247,6 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
     }
   };
 
-  [[maybe_unused]] auto issue_piece = [&](int kt, int buf, int i) {      // A and W pieces i (of 4) of a stage (VG_GLDS_SPREAD)
-    char* sa = smem + buf * 2 * TILEB + wave * 32 * 128;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)kt * BK),
-                                     (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (int64_t)kt * BK),
-                                     (__attribute__((address_space(3))) void*)(sa + TILEB + i * 1024), 16, 0, 0);
-  };
   f32x16_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -296,18 +286,8 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-#if VG_GLDS_SPREAD
-    // the next stage's 8 DMA instructions go out two at a time between the MFMA groups (FRAG_ALL path): a wave issues in
-    // order, and a burst of DMAs that backs up the address path stalls the MFMAs queued behind it
-    const bool spread = FRAG_ALL && kt + 1 < nkf;
-    if (!spread) {
-      if (kt + 1 < nkf) issue(kt + 1, buf ^ 1);
-      else if (kt + 1 < nk) issue_tail(kt + 1, buf ^ 1);
-    }
-#else
     if (kt + 1 < nkf) issue(kt + 1, buf ^ 1);
     else if (kt + 1 < nk) issue_tail(kt + 1, buf ^ 1);
-#endif
     const char* sa = smem + buf * 2 * TILEB + ra * 128;
     const char* sb = smem + buf * 2 * TILEB + TILEB + rb * 128;
     if constexpr (FRAG_ALL) {
@@ -333,13 +313,6 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
           acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b1, acc[0][1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b0, acc[1][0], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           acc[1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b1, acc[1][1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-#if VG_GLDS_SPREAD
-          if (spread) {
-            issue_piece(kt + 1, buf ^ 1, 2 * G);
-            issue_piece(kt + 1, buf ^ 1, 2 * G + 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       } else {
 #pragma unroll
@@ -348,10 +321,6 @@ __global__ __launch_bounds__(256) void gemm_tile_glds_kernel(GemmArgs p) {
           MmaOp<T>::run(fa0[g], fb1[g], acc[0][1]);
           MmaOp<T>::run(fa1[g], fb0[g], acc[1][0]);
           MmaOp<T>::run(fa1[g], fb1[g], acc[1][1]);
-#if VG_GLDS_SPREAD
-          if (spread) issue_piece(kt + 1, buf ^ 1, g);
-          __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       }
     } else {

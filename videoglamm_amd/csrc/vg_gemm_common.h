@@ -88,21 +88,7 @@ __device__ __forceinline__ i32x8_t f8_operand(const u32x4_t& lo, const u32x4_t& 
 
 // Output-tile store flavour of the 256x256 kernel's epilogue (A/B macro): 0 plain, 1 nontemporal (nt), 2 write-through (sc0 sc1: the
 // line is not kept in the XCD's L2), 3 sc1 only
-#ifndef VG_EPI_ST
-#define VG_EPI_ST 0
-#endif
 __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v, int nt = 0) {
-#if defined(P8_ABL) && P8_ABL == 3
-  asm volatile("" ::"v"(v), "v"(ptr));
-  return;      // ablation build: no output stores
-#endif
-#if VG_EPI_ST == 1
-  __builtin_nontemporal_store(v, (u32x4_t*)ptr);
-#elif VG_EPI_ST == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
-#elif VG_EPI_ST == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
-#else
   // nt (wave-uniform): a streaming store.  Measured r03 (tools/bench_gemm.py with VG_BENCH_ACT, same-box A/B against the r02 library) on
   // Hiera's stage-2 GEMMs, whose outputs (150-600 MB) are read by the next kernel long after they have left the caches: the 128x128
   // kernels are bound by their output stores (a build without them: -35...50 %), and with nt stores qkv runs 389 -> 252 us, fc1 487 -> 338,
@@ -111,7 +97,6 @@ __device__ __forceinline__ void epi_store16(void* ptr, const u32x4_t& v, int nt 
   // plain store" into one plain store — the hint is dropped.
   if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
   else *(u32x4_t*)ptr = v;
-#endif
 }
 
 // Row-major side of the LDS-staged epilogues, fast path: the lane's 8 columns are whole inside N, 16-byte aligned rows, no fp8 scales.

@@ -333,9 +333,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
   // statement that reads it; s_nop 4 covers "SALU wrote the base / M0 -> VMEM reads it" (cdna_hip_programming.md section 5.7 item 2)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto stage = [&](int kind, int buf, int kt) {
-#if defined(P8_ABL) && P8_ABL == 2
-    return;      // ablation build: no LDS-DMA (garbage results; timing only)
-#endif
     const char* base = (kind < 2 ? Ab : Wb) + (int64_t)kt * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -346,14 +343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
 
   f32x16_t acc[4][2];
   u32x4_t fa[2][4], fb[2][4];
-#ifdef P8_ABL
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { fa[i >> 2][i & 3] = u32x4_t{(uint32_t)lane, 1u, 2u, 3u}; fb[i >> 2][i & 3] = u32x4_t{(uint32_t)lane, 5u, 6u, 7u}; }
-#endif
   auto readA = [&](int buf, int q) {
-#if defined(P8_ABL) && P8_ABL == 1
-    return;      // ablation build: no fragment reads
-#endif
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -383,9 +373,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
   //   phase 4: read B0(t+1)          stage A0(t+2) -> this buffer       MFMA (A1, B0)
   // Steady state: every wait is vmcnt(8) (four half-tiles issued after the one needed next).
   auto readBinto = [&](int set, int buf, int q) {
-#if defined(P8_ABL) && P8_ABL == 1
-    return;
-#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s) fb[set][s] = *(const u32x4_t*)(smem + boff[s] + (region(2 + q, buf) - 4 * P8_HALF));
   };
@@ -470,12 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_p8_kernel(GemmArgs p) {
       prologue();
     }
     asm volatile("" : "+v"(lane_t));
-#if defined(P8_ABL) && P8_ABL == 4
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1])); }      // ablation build: no epilogue
-#else
     p8_epilogue<TO>(p, acc, smem, cbm, cbn, cbz, wave, lane_t);
-#endif
     if (!more) break;
     t = tn;
     // the source offsets are recomputed here instead of living across the epilogue (whose bias / LayerScale registers next to the 128 accumulator
