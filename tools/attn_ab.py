@@ -9,7 +9,8 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for name, B, H, Hkv, Sq, Skv, D, causal in [("llm prefill c2", 1, 32, 8, 3361, 3361, 128, True), ("hiera glob 16f", 16, 8, 8, 4096, 4096, 72, False),
-                                            ("iv2", 4, 16, 16, 1025, 1025, 88, False), ("llm prefill c1", 1, 32, 8, 1697, 1697, 128, True)]:
+                                            ("iv2", 4, 16, 16, 1025, 1025, 88, False), ("llm prefill c1", 1, 32, 8, 1697, 1697, 128, True),
+                                            ("clip 16f", 16, 16, 16, 577, 577, 64, False), ("hiera glob s4", 16, 16, 16, 1024, 1024, 72, False)]:
     q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.bfloat16); k = torch.randn(B, Skv, Hkv, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k)
     ms = t(lambda: ops.attention(q, k, v, D ** -0.5, causal))
     fl = 4.0 * B * H * Sq * Skv * D * (0.5 if causal else 1.0)

@@ -13,19 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 
-struct AttnArgs {
-  const void* Q; const void* K; const void* V; void* O;
-  int B, Hq, Hkv, Sq, Skv, D, causal;
-  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
-  float scale;
-  int nsplit, split_len;   // split-KV: blockIdx.x = q_tile * nsplit + split; partials go to `part`
-  int xcd;                 // 1: (batch, head) blocks per XCD (see attn_kernel); needs (Hq * B) % 8 == 0
-  float* part;             // [B, Hq, nsplit, Sq, D + 2]  (unnormalised O, running max m, running sum l)
-  const int* skv_dev;      // optional: Skv = *skv_dev + Sq read on the device (graph-replayable decode step)
-  int DV;                  // value / output head dim (== D except for the low-rank memory attention: vg_attention_dv)
-  int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
-                           // (row = g*Sq + q) of ONE query tile, so K/V are staged once per KV head (G*Sq <= tile)
-};
+#include "vg_attn_args.h"
 
 template <typename T> struct AMma;
 template <> struct AMma<bf16_t> {
@@ -1055,7 +1043,11 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD
   constexpr int ks2 = 1;
   int rc;
-  if (DV != D) {
+  // r06: 64 query rows per wave, one wave per SIMD (vg_attention64.hip) for the long bf16 sequences; VG_ATTN64=0: the r05 kernels (A/B knob)
+  static const int a64_on = getenv("VG_ATTN64") ? atoi(getenv("VG_ATTN64")) : 1;
+  if (a64_on && dtype == VG_BF16 && attn64_eligible(p)) {
+    rc = attn64_launch(p, st);
+  } else if (DV != D) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);
   } else if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2>(p, st);
