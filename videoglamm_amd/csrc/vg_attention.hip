@@ -1043,11 +1043,7 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD
   constexpr int ks2 = 1;
   int rc;
-  // r06: 64 query rows per wave, one wave per SIMD (vg_attention64.hip) for the long bf16 sequences; VG_ATTN64=0: the r05 kernels (A/B knob)
-  static const int a64_on = getenv("VG_ATTN64") ? atoi(getenv("VG_ATTN64")) : 1;
-  if (a64_on && dtype == VG_BF16 && attn64_eligible(p)) {
-    rc = attn64_launch(p, st);
-  } else if (DV != D) {
+  if (DV != D) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);
   } else if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2>(p, st);

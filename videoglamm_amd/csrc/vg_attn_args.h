@@ -1,4 +1,4 @@
-// Arguments of the flash-attention kernels (vg_attention.hip, vg_attention64.hip).
+// Arguments of the flash-attention kernels (vg_attention.hip; tools/lab/attn64/ builds its experiment against the same struct).
 #pragma once
 #include "vg_common.h"
 
@@ -15,7 +15,3 @@ struct AttnArgs {
   int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
                            // (row = g*Sq + q) of ONE query tile, so K/V are staged once per KV head (G*Sq <= tile)
 };
-
-// vg_attention64.hip: the 64-rows-per-wave kernel (bf16, head dim <= 128, no split / fold / window); true when it took the launch
-bool attn64_eligible(const AttnArgs& p);
-int attn64_launch(const AttnArgs& p, hipStream_t st);
