@@ -63,6 +63,8 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
   }
 }
 
+// bytes of padding behind a bf16 V row in LDS so that row r + 1 starts 64 bytes (mod 256) behind row r: 256 -> 320, 192 -> 192, 128 -> 192, 64 -> 64
+#define ATTN_VPAD(DP) ((DP) == 128 ? 64 : (DP) == 96 ? 0 : (DP) == 64 ? 64 : (DP) == 32 ? 0 : 16)
 // measured constants of the tile loop (DESIGN_HISTORY.md section 5d has the A/B of each): K/V tile prefetch, Q fragments in registers, V through
 // ds_read_b64_tr_b16, two K/V tile buffers in the DV = 64 form, minimum workgroups per CU in __launch_bounds__
 #define VG_ATTN_PREFETCH 1
@@ -71,6 +73,14 @@ __device__ __forceinline__ void pv_step_f32(const char* vs, int col, int h, cons
 #define VG_ATTN_DB 1
 #define VG_ATTN_MINW 2
 #define VG_ATTN_MINW96 2
+
+// combine a value with the other half-wave's (lane ^ 32): v_permlane32_swap instead of __shfl_xor's ds_bpermute — no LDS instruction, no lgkmcnt wait in a loop
+// that is bound by its LDS traffic
+__device__ __forceinline__ float attn_xor32(float x, bool mx) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+  return mx ? fmaxf(a, b) : a + b;
+}
 
 // KS = 2 (head dim 256, SAM2's memory attention): the two 32-key halves of every KV tile go to two different waves of the same
 // 32 query rows — 8 waves on the LDS footprint of 4, each with its own (O, m, l) over its half of the keys, merged through LDS
@@ -100,7 +110,9 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
   // ds_read_b64_tr_b16 — the transposing staging pass (≈ 80 bit-shuffle VALU instructions per thread and tile in a VALU-bound loop) is gone.
   // Row stride: the 16 lanes of a transpose read touch 4 rows x 4 column quads of 8 bytes; rows must land 8 banks apart
   constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
-  constexpr int RSV = DP * ES + (DP == 128 ? 32 : 16);
+  // (r06: a ds_read_b64_tr_b16 is serviced in two 32-lane groups — 4 key rows x 64 bytes each, MI355X_MICROARCH.md LDS table — so consecutive rows must sit 16
+  // banks = 64 bytes apart modulo 256, not 8: SQ_LDS_BANK_CONFLICT was 32 % of the LDS cycles of the Hiera global blocks with rows 52 / 72 dwords apart)
+  constexpr int RSV = DP * ES + ATTN_VPAD(DP);
   // DB (key-split kernel with 64-wide values, vg_attention_dv): TWO K / V tile buffers — a wave writes tile t + 1 into the other buffer as soon as
   // it is done multiplying tile t, so the loop has one barrier per tile instead of two and the staging writes of the early waves run under the MFMAs
   // of the late ones (K 33 KB + V^T 8 KB per buffer: 148 KB with the Q tile; the head-dim-256 values of the self-attention form do not fit twice)
@@ -349,10 +361,15 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
       mx *= sl2;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);                       // log2 units
+    mx = attn_xor32(mx, true);
+    // Deferred maximum (r06): the reference m_i only moves when some row of the wave has no reference yet or its maximum outgrew the reference by more than
+    // 2^24 — P <= 2^24 is as exact in fp32 / bf16 as P <= 1 (same mantissa, exponents far from the range's ends; terms that flush to zero are far below the
+    // row's largest).  With a reference that tracks every new maximum the rescale of O and l ran in nearly every tile of a 64-lane wave (a new row maximum
+    // somewhere is the rule for the first hundred tiles of random data); now it runs in a row's first tile and then almost never.
+    const bool move = __any(mx > m_i + 24.0f || (m_i == -INFINITY && mx != -INFINITY));
+    const float m_new = move ? fmaxf(m_i, mx) : m_i;          // log2 units
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_i - m_safe);
+    const float alpha = move ? exp2f(m_i - m_safe) : 1.0f;
     float rs = 0.f;
     if (need_mask) {
 #pragma unroll
@@ -374,10 +391,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : (DP <= 96 ? VG_ATTN_MINW96 :
           rs += pv;
         }
     }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = attn_xor32(rs, false);
     l_i = l_i * alpha + rs;
     m_i = m_new;
-    if (__any(alpha != 1.0f)) {      // the running max settles after a few tiles: skip the 16*NDT rescale multiplies then
+    if (move) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -557,7 +574,7 @@ static int launch_attn(const AttnArgs& p, hipStream_t st) {
   constexpr int RS = DP * sizeof(T) + 16;
   constexpr int RSVF = DVP * sizeof(T) + 16;
   constexpr bool VTR = VG_ATTN_VTR && sizeof(T) == 2 && DP <= 128;
-  constexpr int RSV = DP * (int)sizeof(T) + (DP == 128 ? 32 : 16);
+  constexpr int RSV = DP * (int)sizeof(T) + ATTN_VPAD(DP);
   constexpr int vbytes = VTR ? BKV * RSV : (sizeof(T) == 2 ? DVP * 128 : BKV * RSVF);   // bf16, head dim 256: transposed V image, DP rows of 64 keys
   constexpr int BQ = NW / KS * 32;
   constexpr bool DB = VG_ATTN_DB && sizeof(T) == 2 && KS == 2 && DVP <= 64;
