@@ -1,0 +1,47 @@
+"""vg_attention_dma.hip (-m gpu): the LDS-DMA-staged flash kernel that takes the long bf16 sequences (LLM prefill d = 128 causal, Hiera's global
+blocks d = 72, the towers d = 64 / 88) against the fp32 statement on the same bf16-rounded operands — ragged lengths on both axes, GQA, Skv > Sq
+with the causal diagonal shifted, strided (fused q|k|v) operands, head dims below the padded tile width."""
+import pytest
+import torch
+
+import _cpu_ops as ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,H,Hkv,Sq,Skv,D,causal", [
+    (1, 8, 2, 1300, 1300, 128, True),      # LLM prefill shape family: GQA, causal, ragged (5.08 query tiles of 256, 20.3 key tiles of 64)
+    (1, 4, 4, 600, 777, 128, True),        # more keys than queries: the diagonal starts at key 177
+    (1, 4, 4, 513, 513, 128, False),
+    (2, 4, 4, 1024, 1024, 72, False),      # Hiera's global blocks (head dim 72 in a 96-wide tile)
+    (1, 2, 2, 4096, 4096, 72, False),
+    (3, 4, 4, 1025, 1025, 64, False),      # CLIP
+    (2, 4, 4, 1025, 1025, 88, False),      # InternVideo2
+    (1, 2, 2, 700, 70, 96, False),         # few keys: two key tiles, the second one ragged
+])
+def test_attention_dma_vs_fp32_statement(cuda, B, H, Hkv, Sq, Skv, D, causal):
+    from videoglamm_amd import ops
+    q, k, v = rnd(B, Sq, H, D, seed=1), rnd(B, Skv, Hkv, D, seed=2), rnd(B, Skv, Hkv, D, seed=3)
+    want = ref.attention(q, k, v, D ** -0.5, causal).float()
+    got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5, causal).float().cpu()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+    # sharper than the bf16 output rounding: the mean absolute error is that of rounding alone (a mis-masked tile or a wrong fragment moves it by orders)
+    assert float((got - want).abs().mean()) < 2e-3
+
+
+def test_attention_dma_strided_fused_qkv(cuda):
+    """q, k, v as views of ONE fused projection [B, S, 3, H, D] (what the towers and Hiera hand over): token / head strides that are not the dense ones"""
+    from videoglamm_amd import ops
+    B, S, H, D = 2, 1025, 4, 88
+    qkv = rnd(B, S, 3, H, D, seed=5)
+    g = qkv.to(cuda)
+    got = ops.attention(g[:, :, 0], g[:, :, 1], g[:, :, 2], D ** -0.5).float().cpu()
+    want = ref.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5).float()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)

@@ -110,6 +110,7 @@ def test_decode_step_graphs_per_key_block_setting(cuda, monkeypatch):
     P = Params(sd, cuda, torch.bfloat16)
     toks = torch.randint(0, c["vocab"], (G,), generator=torch.Generator().manual_seed(11))
     got = {}
+    monkeypatch.setenv("VG_DECODE_ROPE", "0")          # the switch belongs to the r05 attention kernel (vg_decode_attention); the r06 launches have one granularity
     for kmin in ("2048", "1000000"):
         monkeypatch.setenv("VG_DEC_KPW_MIN", kmin)
         dec = LlamaDecoder(P, c, 4096, use_graph=True)

@@ -1060,7 +1060,11 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   // head dim 256 (SAM2 memory attention): key-split waves, two per SIMD
   constexpr int ks2 = 1;
   int rc;
-  if (DV != D) {
+  // r06: the LDS-DMA-staged kernel for the long bf16 sequences (vg_attention_dma.hip); VG_ATTN_DMA=0: attn_kernel everywhere (A/B knob)
+  static const int dma_on = getenv("VG_ATTN_DMA") ? atoi(getenv("VG_ATTN_DMA")) : 1;
+  if (dma_on && dtype == VG_BF16 && attn_dma_eligible(p)) {
+    rc = attn_dma_launch(p, st);
+  } else if (DV != D) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);
   } else if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2>(p, st);

@@ -1,4 +1,4 @@
-// Arguments of the flash-attention kernels (vg_attention.hip; tools/lab/attn64/ builds its experiment against the same struct).
+// Arguments of the flash-attention kernels (vg_attention.hip, vg_attention_dma.hip).
 #pragma once
 #include "vg_common.h"
 
@@ -15,3 +15,7 @@ struct AttnArgs {
   int fold;                // GQA fold: grid.y = Hkv and the G = Hq/Hkv query heads of a KV head become rows
                            // (row = g*Sq + q) of ONE query tile, so K/V are staged once per KV head (G*Sq <= tile)
 };
+
+// vg_attention_dma.hip: the LDS-DMA-staged kernel (bf16, head dim <= 128, no split / fold / window)
+bool attn_dma_eligible(const AttnArgs& p);
+int attn_dma_launch(const AttnArgs& p, hipStream_t st);
