@@ -219,6 +219,15 @@ int vg_decode_attention2_supported(int H, int Hkv, int D, int dtype);
 int vg_decode_attention2(const void* q, const void* k_cache, const void* v_cache, void* out, int H, int Hkv, int D, int max_len,
                          int window, float scale, const int* pos_dev, float* workspace, int64_t ws_floats, int keys_per_wg, int dtype,
                          vg_stream_t stream);
+/* The head and tail of a captured decode step in one launch each: vg_decode_step_begin — x = table[*tok] (vg_embed of one row) and rope_cs = rows *pos of cos /
+ *   sin (rope_cs may be NULL); vg_argmax_partial — vg_argmax's first stage: packed (value, ~index) keys atomicMax-ed into acc[row], acc zero on entry;
+ *   vg_decode_step_end — *tok = index decoded from acc[0] (acc[0] left zero), hid_all[*pos] = row (vg_store_row), then vg_decode_advance's bookkeeping with
+ *   inc = 1.  Same results as vg_embed, vg_decode_advance, vg_argmax, vg_store_row, vg_decode_advance in that order. */
+int vg_decode_step_begin(const int64_t* tok, const void* table, void* x, int D, int dtype, const int* pos, const float* cos, const float* sin,
+                         float* rope_cs, int half_dim, vg_stream_t stream);
+int vg_argmax_partial(const void* x, int64_t rows, int n, uint64_t* acc, int dtype, vg_stream_t stream);
+int vg_decode_step_end(uint64_t* acc, int64_t* tok, int* pos, int* step, const int64_t* forced, int n_forced, int64_t* hist, int64_t* raw, int cap,
+                       const void* row, void* hid_all, int D, int dtype, vg_stream_t stream);
 int vg_decode_advance(int64_t* tok, int* pos, int* step, const int64_t* forced, int n_forced, int64_t* hist, int64_t* raw, int cap,
                       const float* cos, const float* sin, float* rope_cs, int half_dim, int inc, vg_stream_t stream);
 

@@ -133,6 +133,42 @@ def test_decode_advance(cuda):
     assert c["hist"].tolist() == [100, 500, 102, 7, 104, 0] and c["raw"].tolist() == [100, 101, 102, 103, 104, 0] and int(c["pos"]) == 11
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decode_step_begin_and_end_equal_the_separate_launches(cuda, dtype):
+    """vg_decode_step_begin == vg_embed + the cos / sin row; vg_argmax_partial + vg_decode_step_end == vg_argmax + vg_store_row + vg_decode_advance(inc = 1):
+    same token (ties -> lowest index), same stored row, same history / forcing, accumulator left zero, replayed three times on one accumulator."""
+    from videoglamm_amd import ops
+    D, V, max_len, hd = 4096, 128257, 64, 64
+    cos, sin = tables(max_len, 2 * hd)
+    gcos, gsin = cos.to(cuda), sin.to(cuda)
+    table = torch.randn(V, D, device=cuda, dtype=dtype, generator=torch.Generator(device=cuda).manual_seed(1))      # (the emitted ids index it: full vocabulary)
+    st = dict(tok=torch.tensor([17], dtype=torch.int64), pos=torch.tensor([9], dtype=torch.int32), step=torch.zeros(1, dtype=torch.int32),
+              forced=torch.tensor([-1, 250, -1], dtype=torch.int64), hist=torch.zeros(4, dtype=torch.int64), raw=torch.zeros(4, dtype=torch.int64))
+    a = {k: v.to(cuda) for k, v in st.items()}
+    b = {k: v.to(cuda) for k, v in st.items()}
+    hid_a, hid_b = torch.zeros(max_len, D, dtype=dtype, device=cuda), torch.zeros(max_len, D, dtype=dtype, device=cuda)
+    cs_a, cs_b = torch.zeros(2 * hd, device=cuda), torch.zeros(2 * hd, device=cuda)
+    acc = torch.zeros(1, dtype=torch.int64, device=cuda)
+    for i in range(3):
+        logits = rnd(1, V, seed=20 + i).to(cuda)
+        logits[0, 5000 + i] = logits[0, 70000 + i] = 9.0          # a tie: the lower index wins
+        row = rnd(1, D, dtype=dtype, seed=30 + i).to(cuda)
+        # fused
+        xa = ops.decode_step_begin(a["tok"], table, a["pos"], rope=(gcos, gsin, cs_a))
+        ops.argmax_partial(logits.view(-1), acc)
+        ops.decode_step_end(acc, a["tok"], a["pos"], a["step"], row, hid_a, a["forced"], a["hist"], a["raw"])
+        # separate launches
+        xb = ops.embed(b["tok"], table)
+        ops.decode_advance_(b["pos"], 0, rope=(gcos, gsin, cs_b))
+        ops.store_row_(row, hid_b, b["pos"])
+        ops.argmax(logits, out=b["tok"])
+        ops.decode_advance_(b["pos"], 1, b["tok"], b["step"], b["forced"], b["hist"], b["raw"])
+        assert torch.equal(xa, xb) and torch.equal(cs_a, cs_b) and torch.equal(hid_a, hid_b) and int(acc[0]) == 0
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k, a[k], b[k])
+    assert a["hist"].tolist() == [5000, 250, 5002, 0] and a["raw"].tolist() == [5000, 5001, 5002, 0] and int(a["pos"]) == 12
+
+
 def _llama2(S, layers=2):
     from oracle import seeded
     from videoglamm_amd import synth

@@ -14,7 +14,7 @@ for d in ("/tmp/pmcA", "/tmp/pmcB", "/tmp/pmcC"):
         print(d, "no db"); continue
     db = sqlite3.connect(g[0])
     q = ("select k.name, k.grid_x, k.grid_y, p.counter_name, count(*), avg(p.counter_value), avg(k.end-k.start)/1e3 from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
-         "where (k.name like '%attn_kernel%' or k.name like '%attn64_kernel%') group by k.name, k.grid_x, k.grid_y, p.counter_name")
+         "where (k.name like '%attn_kernel%' or k.name like '%attn64_kernel%' or k.name like '%attn_dma_kernel%') group by k.name, k.grid_x, k.grid_y, p.counter_name")
     cur = {}
     for name, gx, gy, ctr, n, avg, us in db.execute(q):
         cur.setdefault((name[:60], gx, gy, round(us)), {})[ctr] = avg

@@ -305,3 +305,63 @@ extern "C" int vg_decode_advance(int64_t* tok, int* pos, int* step, const int64_
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The head and the tail of a captured decode step as ONE small launch each (r06: per token the step carried embed, the cos / sin row, the final-norm
+// row store, a memset + two argmax launches and the bookkeeping = 8 launches of ~5 us on the critical path; now 3: begin, argmax partials, end).
+//   vg_decode_step_begin: x = table[*tok] (the embedding row of the token the previous step emitted) and rope_cs = [cos[*pos] | sin[*pos]].
+//   vg_argmax_partial:    vg_argmax's first stage only — packed (value, ~index) keys atomicMax-ed into acc[row] (acc must be zero: step_end leaves it so).
+//   vg_decode_step_end:   *tok = index decoded from acc[0] (acc[0] = 0 again); hid_all[*pos] = row; then vg_decode_advance's bookkeeping with inc = 1.
+__global__ __launch_bounds__(256) void decode_step_begin_kernel(const int64_t* tok, const void* table, void* x, int D, int es, const int* pos, const float* cosT,
+                                                                const float* sinT, float* rope_cs, int hd) {
+  const int64_t t = *tok;
+  const int nb = D * es / 16;
+  const u32x4_t* src = (const u32x4_t*)((const char*)table + t * (int64_t)D * es);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) ((u32x4_t*)x)[i] = src[i];
+  if (blockIdx.x == 0 && rope_cs) {
+    const int np = *pos;
+    for (int d = threadIdx.x; d < 2 * hd; d += 256) rope_cs[d] = d < hd ? cosT[(int64_t)np * hd + d] : sinT[(int64_t)np * hd + d - hd];
+  }
+}
+
+extern "C" int vg_decode_step_begin(const int64_t* tok, const void* table, void* x, int D, int dtype, const int* pos, const float* cos, const float* sin,
+                                    float* rope_cs, int half_dim, vg_stream_t stream) {
+  VG_CHECK(tok && table && x && pos && D > 0 && (dtype == VG_BF16 || dtype == VG_F32), VG_ERR_ARG, "vg_decode_step_begin: bad args");
+  const int es = dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK((D * es) % 16 == 0 && (((uintptr_t)table | (uintptr_t)x) & 15) == 0, VG_ERR_ARG, "vg_decode_step_begin: rows must be whole 16-byte chunks, 16-byte aligned");
+  VG_CHECK(!rope_cs || (cos && sin && half_dim > 0), VG_ERR_ARG, "vg_decode_step_begin: rope_cs needs the cos / sin tables");
+  decode_step_begin_kernel<<<(D * es / 16 + 255) / 256, 256, 0, (hipStream_t)stream>>>(tok, table, x, D, es, pos, cos, sin, rope_cs, half_dim);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+__global__ __launch_bounds__(256) void decode_step_end_kernel(unsigned long long* acc, int64_t* tok, int* pos, int* step, const int64_t* forced, int n_forced,
+                                                              int64_t* hist, int64_t* raw, int cap, const void* row, void* hid_all, int D, int es) {
+  const int p0 = *pos;
+  const int nb = D * es / 16;
+  const u32x4_t* src = (const u32x4_t*)row;
+  u32x4_t* dst = (u32x4_t*)((char*)hid_all + (int64_t)p0 * D * es);
+  for (int i = threadIdx.x; i < nb; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) {
+    const int k = *step;
+    const int64_t t0 = (int64_t)(0xffffffffu - (uint32_t)(acc[0] & 0xffffffffull));      // vg_argmax's key: (monotone value bits) << 32 | ~index
+    acc[0] = 0;
+    int64_t t = t0;
+    if (forced && k < n_forced && forced[k] >= 0) t = forced[k];
+    if (raw && k < cap) raw[k] = t0;
+    if (hist && k < cap) hist[k] = t;
+    *tok = t;
+    *step = k + 1;
+    *pos = p0 + 1;
+  }
+}
+
+extern "C" int vg_decode_step_end(uint64_t* acc, int64_t* tok, int* pos, int* step, const int64_t* forced, int n_forced, int64_t* hist, int64_t* raw, int cap,
+                                  const void* row, void* hid_all, int D, int dtype, vg_stream_t stream) {
+  VG_CHECK(acc && tok && pos && step && row && hid_all && D > 0 && (dtype == VG_BF16 || dtype == VG_F32), VG_ERR_ARG, "vg_decode_step_end: bad args");
+  const int es = dtype == VG_BF16 ? 2 : 4;
+  VG_CHECK((D * es) % 16 == 0 && (((uintptr_t)row | (uintptr_t)hid_all) & 15) == 0, VG_ERR_ARG, "vg_decode_step_end: rows must be whole 16-byte chunks, 16-byte aligned");
+  decode_step_end_kernel<<<1, 256, 0, (hipStream_t)stream>>>((unsigned long long*)acc, tok, pos, step, forced, n_forced, hist, raw, cap, row, hid_all, D, es);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -415,6 +415,16 @@ extern "C" int vg_argmax(const void* x, int64_t rows, int n, int64_t* out, int d
   return VG_OK;
 }
 
+// vg_argmax's first stage alone (r06, the captured decode step): acc[row] must be zero on entry (vg_decode_step_end decodes the key and leaves it zero)
+extern "C" int vg_argmax_partial(const void* x, int64_t rows, int n, uint64_t* acc, int dtype, vg_stream_t stream) {
+  VG_CHECK(x && acc && rows > 0 && n > 0, VG_ERR_ARG, "vg_argmax_partial: bad args");
+  int nb = (n + 2047) / 2048;
+  if (nb > 64) nb = 64;
+  argmax_stage1<<<dim3(nb, (unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, n, (unsigned long long*)acc, nb, dtype);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
 // Mask selection after the SAM2 mask decoder (one 256-thread workgroup per object).
 //   mode 0 (multimask_output=False): dynamic multimask via stability — keep mask 0 when its stability
 //          score |{m>delta}| / |{m>-delta}| >= thresh, else the best-IoU mask of tokens 1..3

@@ -675,6 +675,36 @@ def decode_advance_(pos_dev, inc, tok_dev=None, step_dev=None, forced=None, hist
     _lib.check(rc, "vg_decode_advance")
 
 
+def decode_step_begin(tok_dev, table, pos_dev, rope=None):
+    """x = table[*tok_dev] [1, D] and (rope = (cos, sin, rope_cs)) the cos / sin row of *pos_dev: the head of a captured decode step (vg_decode_step_begin)."""
+    lib = _lib.load()
+    assert tok_dev.dtype == torch.int64 and table.is_contiguous() and pos_dev.dtype == torch.int32
+    D = table.shape[1]
+    x = torch.empty(1, D, dtype=table.dtype, device=table.device)
+    cos, sin, rope_cs = rope if rope is not None else (None, None, None)
+    rc = lib.vg_decode_step_begin(_p(tok_dev), _p(table), _p(x), D, _dt(table), _p(pos_dev), _p(cos), _p(sin), _p(rope_cs), 0 if rope is None else cos.shape[1], _stream())
+    _lib.check(rc, "vg_decode_step_begin")
+    return x
+
+
+def argmax_partial(x, acc):
+    """first stage of argmax over one long row into the zeroed uint64 accumulator `acc` (int64 tensor [1]); decode_step_end decodes it."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert acc.dtype == torch.int64 and acc.numel() >= 1
+    _lib.check(lib.vg_argmax_partial(_p(x), 1, x.numel(), _p(acc), _dt(x), _stream()), "vg_argmax_partial")
+
+
+def decode_step_end(acc, tok_dev, pos_dev, step_dev, row, hid_all, forced=None, hist=None, raw=None):
+    """the tail of a captured decode step (vg_decode_step_end): token from the argmax accumulator, final-norm row into hid_all[*pos], bookkeeping, *pos += 1."""
+    lib = _lib.load()
+    assert row.is_contiguous() and hid_all.is_contiguous() and row.dtype == hid_all.dtype and row.numel() == hid_all.shape[1]
+    cap = 0 if hist is None else hist.numel()
+    rc = lib.vg_decode_step_end(_p(acc), _p(tok_dev), _p(pos_dev), _p(step_dev), _p(forced), 0 if forced is None else forced.numel(), _p(hist), _p(raw), cap,
+                                _p(row), _p(hid_all), row.numel(), _dt(row), _stream())
+    _lib.check(rc, "vg_decode_step_end")
+
+
 def decode_layer_roles(H, Hkv, D, hidden, inter, dtype):
     """0 / 1 / 3: which roles vg_decode_layer covers for this shape (0: use decode_attention + decode_gemv)."""
     return int(_lib.load().vg_decode_layer_roles(H, Hkv, D, hidden, inter, F32 if dtype == torch.float32 else BF16))

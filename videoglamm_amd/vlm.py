@@ -201,6 +201,7 @@ class LlamaDecoder:
         self.raw = torch.zeros(self.HIST, dtype=torch.int64, device=dev)
         self.forced = torch.full((self.HIST,), -1, dtype=torch.int64, device=dev)
         self.rope_cs = torch.zeros(self.hd, dtype=torch.float32, device=dev)     # [cos row | sin row] of *pos_dev for vg_decode_qkv_rope
+        self.amax_acc = torch.zeros(1, dtype=torch.int64, device=dev)            # vg_argmax_partial's accumulator (vg_decode_step_end leaves it zero)
         self.hid_all = torch.empty(max_len, self.D, dtype=dt, device=dev)   # final-norm state of every position
         self.use_graph = (dev.type == "cuda") if use_graph is None else use_graph
         self.graph, self.graphs = None, {}
@@ -279,7 +280,7 @@ class LlamaDecoder:
             x = ops.linear(ops.linear(h, wgu, glu=True), P.w(l + "mlp.down_proj"), residual=x)
         return ops.rmsnorm(x, P.f32("model.norm.weight"), c["rms_eps"])
 
-    def _layers_decode(self, x):
+    def _layers_decode(self, x, rope_row=True):
         """the same stack for ONE new row at position *pos_dev, on the fused decode kernels: 5 launches per layer
         (norm+qkv[+rope+append], [rope+append+]attention+merge, o+residual, norm+gate|up+SwiGLU, down+residual) instead of 9."""
         P, c = self.P, self.c
@@ -291,8 +292,8 @@ class LlamaDecoder:
                 self.chain_err = torch.zeros((), dtype=torch.int32, device=x.device)
             self.chain_err.add_(self.chain_flags[:, 1].sum())      # the previous token's gave-up words survive the memset below (generate() checks)
             self.chain_flags.zero_()          # one memset per token: every layer's arrival stripes and go flags
-        if self.rope_path:
-            ops.decode_advance_(self.pos_dev, 0, rope=(self.cos, self.sin, self.rope_cs))      # the cos / sin row of *pos_dev, once per token
+        if self.rope_path and rope_row:
+            ops.decode_advance_(self.pos_dev, 0, rope=(self.cos, self.sin, self.rope_cs))      # the cos / sin row of *pos_dev, once per token (decode_step_begin does it inside a captured step)
         for i in range(c["num_layers"]):
             l = f"model.layers.{i}."
             qkv_names = [l + "self_attn.q_proj", l + "self_attn.k_proj", l + "self_attn.v_proj"]
@@ -398,11 +399,23 @@ class LlamaDecoder:
 
     def _decode_step(self):
         """static step: consume tok_dev at position *pos_dev, emit the next token into tok_dev, advance pos_dev."""
-        x = ops.embed(self.tok_dev, self.P.t("model.embed_tokens.weight"))
-        h = self._layers_decode(x) if self.fused_decode else self._layers(x, 0, self.pos_dev)
-        ops.store_row_(h, self.hid_all, self.pos_dev)
-        self.next_token(h)
-        self.advance(1)
+        if not (self.fused_decode and self.P.device.type == "cuda"):
+            x = ops.embed(self.tok_dev, self.P.t("model.embed_tokens.weight"))
+            h = self._layers_decode(x) if self.fused_decode else self._layers(x, 0, self.pos_dev)
+            ops.store_row_(h, self.hid_all, self.pos_dev)
+            self.next_token(h)
+            self.advance(1)
+            return
+        # head and tail of the step as one launch each (embed + cos / sin row; token decode + row store + bookkeeping): 3 launches where there were 8
+        x = ops.decode_step_begin(self.tok_dev, self.P.t("model.embed_tokens.weight"), self.pos_dev,
+                                  rope=(self.cos, self.sin, self.rope_cs) if self.rope_path else None)
+        h = self._layers_decode(x, rope_row=False)
+        if self.w8:
+            logits = ops.decode_gemv_w8(h.contiguous(), *self.P.fp8("lm_head"), out_dtype=torch.float32)
+        else:
+            logits = ops.linear(h, self.P.w("lm_head"), out_dtype=torch.float32)
+        ops.argmax_partial(logits.view(-1), self.amax_acc)
+        ops.decode_step_end(self.amax_acc, self.tok_dev, self.pos_dev, self.step_dev, h, self.hid_all, self.forced, self.hist, self.raw)
 
     def advance(self, inc):
         """the host's part of HF generate()'s loop, on the device: force / record the token in tok_dev, count the step, move the position"""
