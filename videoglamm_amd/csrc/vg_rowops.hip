@@ -430,31 +430,44 @@ extern "C" int vg_argmax_partial(const void* x, int64_t rows, int n, uint64_t* a
 //          score |{m>delta}| / |{m>-delta}| >= thresh, else the best-IoU mask of tokens 1..3
 //          (sam/mask_decoder.py:247-295); token out = token 0.
 //   mode 1 (multimask_output=True): best-IoU of tokens 1..3 (sam2_base.py:376-386); token out = that token.
-__global__ __launch_bounds__(256) void multimask_select_kernel(const float* __restrict__ masks, const float* __restrict__ ious,
-                                                               const void* __restrict__ tokens, float* __restrict__ out_mask,
-                                                               float* __restrict__ out_iou, void* __restrict__ out_token,
-                                                               int* __restrict__ out_idx, int64_t HW, int C, float delta,
-                                                               float thresh, int mode, int tok_dt) {
-  __shared__ float s_i[4], s_u[4];
+// (r06: 1024 threads and 16-byte accesses per workgroup — the 256-thread scalar version took 207 us per 128 instances at C4's clip size, 0.8 of the mask
+// decoder's 11.6 ms; counts are exact in fp32 up to 2^24 pixels, so the order of the partial sums does not matter)
+__global__ __launch_bounds__(1024) void multimask_select_kernel(const float* __restrict__ masks, const float* __restrict__ ious,
+                                                                const void* __restrict__ tokens, float* __restrict__ out_mask,
+                                                                float* __restrict__ out_iou, void* __restrict__ out_token,
+                                                                int* __restrict__ out_idx, int64_t HW, int C, float delta,
+                                                                float thresh, int mode, int tok_dt) {
+  __shared__ float s_i[16], s_u[16];
   __shared__ int s_sel;
-  const int n = blockIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x;
   const float* m = masks + (int64_t)n * 4 * HW;
   const float* io = ious + n * 4;
   int best = 1;
   for (int k = 2; k < 4; ++k) if (io[k] > io[best]) best = k;  // argmax, first max wins
   int sel = best;
+  const bool vec = (HW & 3) == 0 && ((((uintptr_t)masks) | ((uintptr_t)out_mask)) & 15) == 0;
   if (mode == 0) {
     float ai = 0.f, au = 0.f;
-    for (int64_t i = threadIdx.x; i < HW; i += 256) {
-      const float v = m[i];
-      ai += v > delta ? 1.f : 0.f;
-      au += v > -delta ? 1.f : 0.f;
+    if (vec) {
+      const f32x4_t* m4 = (const f32x4_t*)m;
+      for (int64_t i = tid; i < HW / 4; i += 1024) {
+        const f32x4_t v = m4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ai += v[e] > delta ? 1.f : 0.f; au += v[e] > -delta ? 1.f : 0.f; }
+      }
+    } else {
+      for (int64_t i = tid; i < HW; i += 1024) {
+        const float v = m[i];
+        ai += v > delta ? 1.f : 0.f;
+        au += v > -delta ? 1.f : 0.f;
+      }
     }
     ai = wave_sum(ai); au = wave_sum(au);
-    if ((threadIdx.x & 63) == 0) { s_i[threadIdx.x >> 6] = ai; s_u[threadIdx.x >> 6] = au; }
+    if ((tid & 63) == 0) { s_i[tid >> 6] = ai; s_u[tid >> 6] = au; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const float ti = s_i[0] + s_i[1] + s_i[2] + s_i[3], tu = s_u[0] + s_u[1] + s_u[2] + s_u[3];
+    if (tid == 0) {
+      float ti = 0.f, tu = 0.f;
+      for (int w = 0; w < 16; ++w) { ti += s_i[w]; tu += s_u[w]; }
       const float stab = tu > 0.f ? ti / tu : 1.0f;
       s_sel = stab >= thresh ? 0 : best;
     }
@@ -462,12 +475,18 @@ __global__ __launch_bounds__(256) void multimask_select_kernel(const float* __re
     sel = s_sel;
   }
   const float* src = m + (int64_t)sel * HW;
-  for (int64_t i = threadIdx.x; i < HW; i += 256) out_mask[(int64_t)n * HW + i] = src[i];
+  if (vec) {
+    const f32x4_t* s4 = (const f32x4_t*)src;
+    f32x4_t* d4 = (f32x4_t*)(out_mask + (int64_t)n * HW);
+    for (int64_t i = tid; i < HW / 4; i += 1024) d4[i] = s4[i];
+  } else {
+    for (int64_t i = tid; i < HW; i += 1024) out_mask[(int64_t)n * HW + i] = src[i];
+  }
   const int tsel = mode == 0 ? 0 : sel;
   if (tokens && out_token)
-    for (int c = threadIdx.x; c < C; c += 256)
+    for (int c = tid; c < C; c += 1024)
       st_any(out_token, (int64_t)n * C + c, tok_dt, ld_any(tokens, ((int64_t)n * 4 + tsel) * C + c, tok_dt));
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     out_iou[n] = io[sel];
     if (out_idx) out_idx[n] = sel;
   }
@@ -509,7 +528,7 @@ extern "C" int vg_multimask_select(const float* masks, const float* ious, const 
     VG_LAUNCH_CHECK();
     return VG_OK;
   }
-  multimask_select_kernel<<<dim3(N), 256, 0, (hipStream_t)stream>>>(masks, ious, tokens, out_mask, out_iou, out_token, out_idx,
+  multimask_select_kernel<<<dim3(N), 1024, 0, (hipStream_t)stream>>>(masks, ious, tokens, out_mask, out_iou, out_token, out_idx,
                                                                      HW, C, delta, thresh, mode, token_dtype);
   VG_LAUNCH_CHECK();
   return VG_OK;
