@@ -333,7 +333,7 @@ def meter_decode_gemv(model, ops, reps=3):
         return None
     return rec[0][2], [1e3 * a.elapsed_time(b) for a, b, _ in rec]
 
-PMC_TAG = "r05_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
+PMC_TAG = "r06_c2"      # profiles/<PMC_TAG>_pmc_<kernel>.json: HBM traffic per launch of the default workload
 
 
 def quality(cfg, args, model, step, device):
@@ -468,7 +468,7 @@ def attn_roofs(am, traffic_of=lambda key: None, peak=2500.0):
             continue
         label = (f"attn_kernel<bf16, 256, 64, 8, 2, DV = {str(dp).split('_dv')[1]}> (vg_attention_dv: SAM2 memory cross-attention, v-projection behind the attention; "
                  "flops = 2 Sq Skv (D + DV); + the split-KV merge)") if "_dv" in str(dp) else \
-            f"attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)"
+            f"attn_dma_kernel<{dp}> (long sequences: LDS-DMA staging, r06) / attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)"
         roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": label,
                                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
                                 "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),
@@ -923,7 +923,7 @@ def main():
             if args.decode_weights == "fp8":     # MLP and lm_head in fp8, attention projections in bf16
                 wbytes -= 0.5 * 2.0 * (c["num_layers"] * 3 * c["hidden"] * c["ffn"] + c["vocab"] * c["hidden"])
             tbs = wbytes * dec_n / (dec_ms * 1e-3) / 1e12
-            res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 + decode_attn_kernel per layer)",
+            res["roofline_decode"] = {"bound": "hbm", "kernel": "decode step (HIP graph: decode_gemv_fast_kernel x4 (q|k|v with RoPE + append) + decode_attn2_kernel per layer)",
                                       "achieved": round(tbs * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(tbs / 8.0, 4),
                                       "algorithmic_bytes_per_step": round(wbytes), "steps": dec_n, "ms_per_token": round(dec_ms / dec_n, 3)}
     if world == 1 and not use_video and not args.tiny and not args.no_video_record:

@@ -17,9 +17,9 @@ CLASSES = [
     ("gemm_s128", r"gemm_tile_s128_kernel<unsigned short"),
     ("mlp_rows", r"mlp_rows_kernel"),
     ("decode_gemv_glu", r"decode_gemv_fast_kernel<unsigned short, unsigned short, true"),
-    ("attn_d64", r"attn_kernel<unsigned short, 64,"),
-    ("attn_d96", r"attn_kernel<unsigned short, 96,"),
-    ("attn_d128", r"attn_kernel<unsigned short, 128,"),
+    ("attn_d64", r"attn_kernel<unsigned short, 64,|attn_dma_kernel<64,"),          # (r06: the long sequences run on the LDS-DMA-staged kernel)
+    ("attn_d96", r"attn_kernel<unsigned short, 96,|attn_dma_kernel<96,"),
+    ("attn_d128", r"attn_kernel<unsigned short, 128,|attn_dma_kernel<128,"),
     ("attn_d256", r"attn_kernel<unsigned short, 256,"),
     ("attn_window", r"win256_attn_kernel|tiny_win_attn_kernel"),
     ("norm_short", r"norm_short_kernel"),
