@@ -313,6 +313,10 @@ def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
     rc = lib.vg_gemm_ln(_p(x2), lda, _p(w), w.stride(0), _p(o2), ldc, _p(_f32(bias)), _p(_f32(ln[0])), _p(_f32(ln[1])), float(ln[2]), M, N, K, act,
                         1 if window is not None else 0, wa[0], wa[1], wa[2], wa[3],
                         _p(_zero_row(K, x.dtype, x.device)) if window is not None else None, BF16, _stream())
+    if rc == -3:      # VG_ERR_UNSUPPORTED (include/vg_kernels.h)
+        # the launcher's own eligibility (alignment, output stride, LDS) is stricter than the route query: take the two-launch form
+        xn = layernorm(x, ln[0], ln[1], ln[2])
+        return linear_window(xn, w, bias, *window, scatter=False, act=act) if window is not None else linear(xn, w, bias, act=act)
     _lib.check(rc, "vg_gemm_ln")
     return out
 

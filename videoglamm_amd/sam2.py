@@ -789,10 +789,14 @@ class SAM2:
                         d.copy_(f)
             st_emb.copy_(text_embeds)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph(keep_graph=True)      # (the hipGraph_t stays readable: graph_nodes() below)
+            try:
+                g, kept = torch.cuda.CUDAGraph(keep_graph=True), True      # (the hipGraph_t stays readable: video_graph_nodes() below)
+            except TypeError:                                  # torch < 2.8: no keep_graph — the node census is then unavailable, the replay is the same
+                g, kept = torch.cuda.CUDAGraph(), False
             with ops.graph_capture(g):      # (thread-local capture mode, cyclic GC held off: ops.graph_capture)
                 out = self.video_branch(images, st_emb, video_hw, frame_feats=st_feats, as_masks=as_masks)
-            g.instantiate()
+            if kept:
+                g.instantiate()
             ent = (g, st_feats, st_emb, out)
         graphs[key] = ent                       # (re-inserted last: most recently used)
         g, st_feats, st_emb, out = ent
@@ -806,7 +810,8 @@ class SAM2:
 
     def video_graph_nodes(self):
         """{(T, N, (H, W), as_masks): (kernel, memcpy, other) node counts} of the cached propagation graphs: launches per replayed clip."""
-        return {(k[0], k[1], k[2], k[4]): ops.graph_node_counts(ent[0]) for k, ent in self.__dict__.get("_video_graphs", {}).items()}
+        return {(k[0], k[1], k[2], k[4]): ops.graph_node_counts(ent[0]) for k, ent in self.__dict__.get("_video_graphs", {}).items()
+                if hasattr(ent[0], "raw_cuda_graph")}
 
     def framewise_branch(self, images, text_embeds, video_hw, frame_feats=None, frames=None, as_masks=False):
         """VideoGLaMM framewise decode — R/model/VideoGLaMM.py:205-241,676-766.  One mask-decoder batch per frame
