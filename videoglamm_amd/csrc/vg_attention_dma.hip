@@ -11,6 +11,7 @@
 // Arithmetic = attn_kernel's: swapped product S^T = K Q^T (a lane owns one query column: row statistics are lane-local + one half-wave exchange), softmax in
 // the exp2 domain with an fp32 reference that moves only when a row outgrew it by 2^64, P rounded to bf16 for the PV product, O accumulated in fp32.
 #include "vg_attn_args.h"
+#include <type_traits>
 
 namespace {
 
@@ -56,16 +57,39 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
   //      whose LOGICAL chunk is slot ^ swizzle(row).  Rows past the sequence re-read its last row (their scores are masked), chunks past the head dim
   //      re-read its last chunk (finite values against zero Q columns / unstored O columns).
   const int cmax = D / 8 - 1;
+  // source addresses of this wave's pieces: computed once (row, swizzled chunk), then bumped by 64 rows per tile — only the LAST tile of a ragged sequence needs
+  // the row clamp, and takes the slow form
+  const bf16_t* kp[PPW];
+  const bf16_t* vp[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int piece = wave * PPW + j, row = piece * 4 + (lane >> 4);
+    const int c = min((lane & 15) ^ adma_sw(row), cmax);
+    kp[j] = Kg + (int64_t)row * p.k_ss + c * 8;
+    vp[j] = Vg + (int64_t)row * p.v_ss + c * 8;
+  }
+  const int64_t kstep = (int64_t)BKV * p.k_ss, vstep = (int64_t)BKV * p.v_ss;
   auto issue = [&](int t) {
     char* st = smem + (t % 3) * STAGE;
     const int kv0 = t * BKV;
+    if (__builtin_expect(kv0 + BKV > Skv, 0)) {
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j, row = piece * 4 + (lane >> 4);
+        const int c = min((lane & 15) ^ adma_sw(row), cmax);
+        const int key = min(kv0 + row, Skv - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)key * p.k_ss + c * 8), (lptr_t)(st + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)key * p.v_ss + c * 8), (lptr_t)(st + BKV * 256 + piece * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int piece = wave * PPW + j, row = piece * 4 + (lane >> 4);
-      const int c = min((lane & 15) ^ adma_sw(row), cmax);
-      const int key = min(kv0 + row, Skv - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)key * p.k_ss + c * 8), (lptr_t)(st + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)key * p.v_ss + c * 8), (lptr_t)(st + BKV * 256 + piece * 1024), 16, 0, 0);
+      const int piece = wave * PPW + j;
+      __builtin_amdgcn_global_load_lds((gptr_t)kp[j], (lptr_t)(st + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)vp[j], (lptr_t)(st + BKV * 256 + piece * 1024), 16, 0, 0);
+      kp[j] += kstep;
+      vp[j] += vstep;
     }
   };
   if (ntile > 0) issue(0);
@@ -99,7 +123,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
   for (int g = 0; g < NG; ++g) kofs[g] = l31 * 256 + (((2 * g + h) ^ adma_sw(l31)) << 4);
   // V^T fragment (ds_read_b64_tr_b16): lane i of a 16-lane group supplies the 8-byte piece (key row i >> 2, column quad i & 3) of a 4-key x 16-column
   // block; the A operand of 16-key step t wants keys 16 t + 4 h + {0..3} (lo) and 16 t + 8 + 4 h + {0..3} (hi) — attn_kernel's map on the swizzled rows
-  int vofs[NDT][2];
+  int kofsB[NG];     // the same + two stages: a ds_read's immediate offset reaches 65535 bytes, so stages 0 / 1 are immediates on kofs, stage 2 on kofsB
+#pragma unroll
+  for (int g = 0; g < NG; ++g) kofsB[g] = kofs[g] + 2 * STAGE;
+  int vofs[NDT][2], vofsB[NDT][2];
   {
     const int vrow = 4 * h + ((lane & 15) >> 2);
     const int vchunk = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1), vin = (lane & 1) * 8;
@@ -108,12 +135,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
     for (int dt = 0; dt < NDT; ++dt) {
       vofs[dt][0] = vrow * 256 + vin + (((dt * 4 + vchunk) ^ vsw_lo) << 4);
       vofs[dt][1] = (vrow + 8) * 256 + vin + (((dt * 4 + vchunk) ^ vsw_hi) << 4);
+      vofsB[dt][0] = vofs[dt][0] + 2 * STAGE;
+      vofsB[dt][1] = vofs[dt][1] + 2 * STAGE;
     }
   }
   typedef short s16x4_t __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
 
-  auto stage_of = [&](int t) -> const char* { return smem + (t % 3) * STAGE; };
   auto xor32 = [&](float x, bool mx) -> float {      // combine with the other half-wave's value (v_permlane32_swap: no LDS round trip)
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     const float a = __uint_as_float(r[0]), b2 = __uint_as_float(r[1]);
@@ -122,7 +150,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
   const f32x16_t z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // inline-constant C operand: no accumulator initialisation
   // tiles 0 and 1 in flight (three-stage ring, prefetch distance two: a tile has two tiles of arithmetic to arrive)
   if (ntile > 1) issue(1);
-  for (int t = 0; t < ntile; ++t) {
+  // one tile; the ring stage S is a compile-time constant (the loop below is unrolled by three), so every fragment address is a lane register + an immediate
+  auto tile = [&](const int t, auto stage_c) {
+    constexpr int S = decltype(stage_c)::value;
     if (t + 1 < ntile) {      // a wave issues 2 PPW pieces per tile: everything but tile t + 1's has landed
       if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -131,17 +161,20 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
     __syncthreads();                                      // everybody's pieces of tile t are in, and everybody is done with tile t - 1's stage
     if (t + 2 < ntile) issue(t + 2);
     const int kv0 = t * BKV;
-    if (CAUSAL && kv0 > wq0 + RW - 1 + off) continue;         // the whole tile lies behind this wave's diagonal (the wave keeps the workgroup's barriers)
-    const char* Ks = stage_of(t);
+    if (CAUSAL && kv0 > wq0 + RW - 1 + off) return;         // the whole tile lies behind this wave's diagonal (the wave keeps the workgroup's barriers)
+    // stages 0 / 1: smem + immediate + kofs; stage 2: smem + immediate + kofsB (= kofs + 2 STAGE)
+    const char* Ks = smem + (S == 1 ? STAGE : 0);
     const char* Vs = Ks + BKV * 256;
+    const int (&ko)[NG] = S == 2 ? kofsB : kofs;
+    const int (&vo)[NDT][2] = S == 2 ? vofsB : vofs;
     // ---- S^T = K Q^T: one K fragment read, two MFMAs (the wave's two query blocks); fragments one step ahead
     f32x16_t sc[QB][2];
     {
       u32x4_t kf[2];
-      kf[0] = *(const u32x4_t*)(Ks + kofs[0]);
+      kf[0] = *(const u32x4_t*)(Ks + ko[0]);
 #pragma unroll
       for (int i = 0; i < 2 * NG; ++i) {      // i = 2 g + kt
-        if (i + 1 < 2 * NG) kf[(i + 1) & 1] = *(const u32x4_t*)(Ks + ((i + 1) & 1) * 8192 + kofs[(i + 1) >> 1]);
+        if (i + 1 < 2 * NG) kf[(i + 1) & 1] = *(const u32x4_t*)(Ks + ((i + 1) & 1) * 8192 + ko[(i + 1) >> 1]);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           sc[qb][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[i & 1]), __builtin_bit_cast(bf16x8_t, q[qb][i >> 1]),
@@ -198,16 +231,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
         }
       }
       const float nm = (m_i[qb] == -INFINITY) ? 0.f : -m_i[qb];
-      float rs = 0.f;
+      vg_f32x2_t rs2 = {0.f, 0.f};      // (pairs: v_pk_add_f32 halves the row-sum instructions)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sc[qb][kt][r], sl2, nm));      // (-inf scores: exp2(-inf) = 0)
-          sc[qb][kt][r] = pv;
-          rs += pv;
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[qb][kt][r], sl2, nm));      // (-inf scores: exp2(-inf) = 0)
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[qb][kt][r + 1], sl2, nm));
+          sc[qb][kt][r] = p0;
+          sc[qb][kt][r + 1] = p1;
+          rs2 += vg_f32x2_t{p0, p1};
         }
-      l_i[qb] += xor32(rs, false);
+      l_i[qb] += xor32(rs2[0] + rs2[1], false);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -217,8 +252,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
     {
       auto vread = [&](int tt, int dt) -> u32x4_t {
         const char* a = Vs + tt * 16 * 256;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vofs[dt][0]));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vofs[dt][1]));
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vo[dt][0]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vo[dt][1]));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         const u32x4_t v = {l2.x, l2.y, h2.x, h2.y};
         return v;
@@ -233,6 +268,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
           o[qb][i % NDT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[i & 1]), __builtin_bit_cast(bf16x8_t, pb[qb][i / NDT]), o[qb][i % NDT], 0, 0, 0);
       }
     }
+  };
+  {
+    int t = 0;
+    for (; t + 3 <= ntile; t += 3) {
+      tile(t, std::integral_constant<int, 0>{});
+      tile(t + 1, std::integral_constant<int, 1>{});
+      tile(t + 2, std::integral_constant<int, 2>{});
+    }
+    if (t < ntile) tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntile) tile(t + 1, std::integral_constant<int, 1>{});
   }
   // ---- epilogue: a lane holds 4 consecutive head-dim values per register quad of its query row: 8-byte stores
 #pragma unroll
