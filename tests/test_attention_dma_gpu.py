@@ -45,3 +45,45 @@ def test_attention_dma_strided_fused_qkv(cuda):
     got = ops.attention(g[:, :, 0], g[:, :, 1], g[:, :, 2], D ** -0.5).float().cpu()
     want = ref.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5).float()
     torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,Sq,Skv", [
+    (1, 4096, 4096 + 4),         # the video branch's first propagated frame: one memory + one pointer (4 tokens): split-KV, last split ragged
+    (1, 4096, 7 * 4096 + 64),    # steady state, one object: 16 query tiles x many splits
+    (8, 4096, 7 * 4096 + 64),    # eight objects (sliced check)
+    (2, 300, 1000),              # ragged query tile (300 = 256 + 44), several splits
+    (1, 256, 130),               # no split, three key tiles, the last with two keys
+    (3, 511, 64),                # one key tile
+])
+def test_attention_dma_dv_vs_fp32_statement(cuda, B, Sq, Skv):
+    """attn_dma_d256v64_kernel (vg_attention_dv's bf16 route for Sq >= 256): keys of 256 dims, 64-wide values, split-KV partials merged by
+    attn_combine_kernel; a key spike and a few large value rows force the deferred running-max update."""
+    from videoglamm_amd import ops
+    D, DV = 256, 64
+    q, k, v = rnd(B, Sq, 1, D, seed=1), rnd(B, Skv, 1, D, seed=2), rnd(B, Skv, 1, DV, seed=3)
+    v[:, Skv // 3] *= 6.0
+    k[:, Skv // 2] *= 4.0
+    k[:, -1] = q[:, 7] * 0.5
+    v[:, -1] += 8.0                  # a dropped or duplicated tail key shows
+    got = ops.attention_dv(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5).float().cpu()
+    assert got.shape == (B, Sq, 1, DV) and torch.isfinite(got).all()
+    sl = slice(0, Sq) if B * Sq * Skv <= 3e8 else slice(100, 612)
+    for b in sorted({0, B - 1}):
+        want = ref.attention(q[b:b + 1, sl], k[b:b + 1], v[b:b + 1], D ** -0.5).float()
+        torch.testing.assert_close(got[b:b + 1, sl], want, rtol=3e-2, atol=3e-2)
+        assert float((got[b:b + 1, sl] - want).abs().mean()) < 2e-3
+
+
+def test_attention_dma_dv_every_tail(cuda):
+    """every residue of Skv inside a 64-key tile, with one split and with several"""
+    from videoglamm_amd import ops
+    D, DV, Sq = 256, 64, 256
+    q = rnd(1, Sq, 1, D, seed=1)
+    for base in (64, 1024):
+        for r in range(0, 64, 1):
+            Skv = base + r
+            k, v = rnd(1, Skv, 1, D, seed=2 + r), rnd(1, Skv, 1, DV, seed=3 + r)
+            v[:, -1] += 8.0
+            k[:, -1] = q[:, 7] * 0.5
+            got = ops.attention_dv(q.to(cuda), k.to(cuda), v.to(cuda), D ** -0.5).float().cpu()
+            torch.testing.assert_close(got, ref.attention(q, k, v, D ** -0.5).float(), rtol=3e-2, atol=3e-2)

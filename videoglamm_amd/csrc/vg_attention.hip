@@ -1064,6 +1064,8 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   static const int dma_on = getenv("VG_ATTN_DMA") ? atoi(getenv("VG_ATTN_DMA")) : 1;
   if (dma_on && dtype == VG_BF16 && attn_dma_eligible(p)) {
     rc = attn_dma_launch(p, st);
+  } else if (DV != D && dma_on && attn_dma_dv_eligible(p)) {
+    rc = attn_dma_dv_launch(p, st);
   } else if (DV != D) {
     rc = launch_attn<bf16_t, 256, 64, 8, 2, 64>(p, st);
   } else if (dtype == VG_BF16 && ks2 && !p.fold && D > 128) {

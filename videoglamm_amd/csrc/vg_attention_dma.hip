@@ -301,6 +301,199 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same loop for SAM2's memory cross-attention (vg_attention_dv): head dim 256 keys, 64-wide values, no mask, split-KV partials for attn_combine_kernel.
+// K rows are 512 bytes (two 256-byte bank lines: the swizzle acts on the 16-byte slot inside a line), V rows 128 bytes kept in 256-byte LDS rows (the V^T reads
+// are then exactly the d <= 128 kernel's); a stage = K tile 32 KB + V tile 16 KB, three stages = 144 KB (one 8-wave workgroup per CU, two waves per SIMD);
+// a wave issues 4 + 2 one-KiB pieces per tile.  r05's kernel for this shape splits every 64-key tile over TWO waves of the same 32 query rows (8 waves on
+// 128 rows) and stages through registers; here a wave owns its 32 rows for all 64 keys and 8 waves share a tile over 256 rows.
+__global__ __launch_bounds__(512, 1) void attn_dma_d256v64_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NG = 16, NDT = 2, BKV = 64, BQ = 256, NW = 8;
+  constexpr int KT = BKV * 512, STAGE = KT + BKV * 256;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, wave = tid >> 6;
+  const int split = blockIdx.x % p.nsplit, qtile = blockIdx.x / p.nsplit, head = blockIdx.y, b = blockIdx.z;
+  const int q0 = qtile * BQ, Sq = p.Sq, Skv = p.Skv;
+  const bf16_t* Qg = (const bf16_t*)p.Q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
+  const bf16_t* Kg = (const bf16_t*)p.K + (int64_t)b * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* Vg = (const bf16_t*)p.V + (int64_t)b * p.v_sb + (int64_t)head * p.v_sh;
+  int kv_begin = 0, kv_end = Skv;
+  if (p.nsplit > 1) {
+    kv_begin = split * p.split_len;                   // (split_len is a whole number of 64-key tiles)
+    kv_end = min(kv_begin + p.split_len, Skv);
+  }
+  const int t0 = kv_begin / BKV, ntile = kv_end > kv_begin ? (kv_end - kv_begin + BKV - 1) / BKV : 0;
+
+  // K pieces: 32 per tile, 4 per wave, lane L -> (row 2 piece + L / 32, line (L / 16) & 1, slot L % 16); V pieces: 16 per tile, 2 per wave, as in attn_dma_kernel
+  auto issue = [&](int t) {      // t: tile index inside this split's range
+    char* st = smem + (t % 3) * STAGE;
+    const int kv0 = (t0 + t) * BKV;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j, row = piece * 2 + (lane >> 5);
+      const int c = ((lane >> 4) & 1) * 16 + ((lane & 15) ^ adma_sw(row));
+      const int key = min(kv0 + row, Skv - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)key * p.k_ss + c * 8), (lptr_t)(st + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave * 2 + j, row = piece * 4 + (lane >> 4);
+      const int c = min((lane & 15) ^ adma_sw(row), 7);      // 64-wide values: chunks 0..7 (the slots of chunks 8..15 re-read chunk 7: never used)
+      const int key = min(kv0 + row, Skv - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)key * p.v_ss + c * 8), (lptr_t)(st + KT + piece * 1024), 16, 0, 0);
+    }
+  };
+  if (ntile > 0) issue(0);
+  u32x4_t q[NG];
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  const int qr = q0 + wave * 32 + l31;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) q[g] = qr < Sq ? *(const u32x4_t*)(Qg + (int64_t)qr * p.q_ss + (2 * g + h) * 8) : zero4;
+  f32x16_t o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_i = -INFINITY, l_i = 0.f;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  int kofs[8];      // k-groups g and g + 8 sit 256 bytes apart (the row's second bank line): an immediate
+#pragma unroll
+  for (int g = 0; g < 8; ++g) kofs[g] = l31 * 512 + (((2 * g + h) ^ adma_sw(l31)) << 4);
+  int vofs[NDT][2];
+  {
+    const int vrow = 4 * h + ((lane & 15) >> 2);
+    const int vchunk = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1), vin = (lane & 1) * 8;
+    const int vsw_lo = ((((lane & 15) >> 2) & 3) << 2) | (h & 3), vsw_hi = ((((lane & 15) >> 2) & 3) << 2) | ((h + 2) & 3);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      vofs[dt][0] = vrow * 256 + vin + (((dt * 4 + vchunk) ^ vsw_lo) << 4);
+      vofs[dt][1] = (vrow + 8) * 256 + vin + (((dt * 4 + vchunk) ^ vsw_hi) << 4);
+    }
+  }
+  auto xor32 = [&](float x, bool mx) -> float {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float a = __uint_as_float(r[0]), b2 = __uint_as_float(r[1]);
+    return mx ? fmaxf(a, b2) : a + b2;
+  };
+  const f32x16_t z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ntile > 1) issue(1);
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // a wave issues 6 pieces per tile: everything but tile t + 1's has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < ntile) issue(t + 2);
+    const int kv0 = (t0 + t) * BKV;
+    const char* Ks = smem + (t % 3) * STAGE;
+    const char* Vs = Ks + KT;
+    f32x16_t sc[2];
+    {
+      u32x4_t kf[2];
+      kf[0] = *(const u32x4_t*)(Ks + kofs[0]);
+#pragma unroll
+      for (int i = 0; i < 2 * NG; ++i) {      // i = 2 g + kt
+        if (i + 1 < 2 * NG) {
+          const int g1 = (i + 1) >> 1;
+          kf[(i + 1) & 1] = *(const u32x4_t*)(Ks + ((i + 1) & 1) * 32 * 512 + (g1 >> 3) * 256 + kofs[g1 & 7]);
+        }
+        sc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[i & 1]), __builtin_bit_cast(bf16x8_t, q[i >> 1]), i < 2 ? z16 : sc[i & 1], 0, 0, 0);
+      }
+    }
+    if (__builtin_expect(kv0 + BKV > kv_end, 0)) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kt][r] = kv0 + kt * 32 + mfma32_row(r, h) < kv_end ? sc[kt][r] : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+    mx = xor32(mx * sl2, true);
+    m_i = (m_i == -INFINITY) ? mx : m_i;      // (deferred reference, as in attn_dma_kernel)
+    if (__builtin_expect(__any(mx > m_i + 64.0f), 0)) {
+      const float m_new = fmaxf(m_i, mx);
+      const float alpha = exp2f(m_i - m_new);
+      l_i *= alpha;
+      m_i = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float nm = (m_i == -INFINITY) ? 0.f : -m_i;
+    vg_f32x2_t rs2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], sl2, nm));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[kt][r + 1], sl2, nm));
+        sc[kt][r] = p0;
+        sc[kt][r + 1] = p1;
+        rs2 += vg_f32x2_t{p0, p1};
+      }
+    l_i += xor32(rs2[0] + rs2[1], false);
+    u32x4_t pb[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) pb[tt][jj] = f2bf2(sc[tt >> 1][(tt & 1) * 8 + jj * 2], sc[tt >> 1][(tt & 1) * 8 + jj * 2 + 1]);
+    {
+      auto vread = [&](int tt, int dt) -> u32x4_t {
+        const char* a = Vs + tt * 16 * 256;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vofs[dt][0]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + vofs[dt][1]));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        const u32x4_t v = {l2.x, l2.y, h2.x, h2.y};
+        return v;
+      };
+      u32x4_t vf[2];
+      vf[0] = vread(0, 0);
+#pragma unroll
+      for (int i = 0; i < 4 * NDT; ++i) {
+        if (i + 1 < 4 * NDT) vf[(i + 1) & 1] = vread((i + 1) / NDT, (i + 1) % NDT);
+        o[i % NDT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf[i & 1]), __builtin_bit_cast(bf16x8_t, pb[i / NDT]), o[i % NDT], 0, 0, 0);
+      }
+    }
+  }
+  if (qr >= Sq) return;
+  const int DV = p.DV;
+  if (p.nsplit > 1) {      // unnormalised O, reference (natural-log units) and row sum for attn_combine_kernel
+    float* pp = p.part + ((((int64_t)b * p.Hq + head) * p.nsplit + split) * Sq + qr) * (DV + 2);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        if (d0 < DV) {
+          *(float2*)(pp + d0) = float2{o[dt][4 * g], o[dt][4 * g + 1]};
+          *(float2*)(pp + d0 + 2) = float2{o[dt][4 * g + 2], o[dt][4 * g + 3]};
+        }
+      }
+    if (h == 0) { pp[DV] = m_i * 0.6931471805599453f; pp[DV + 1] = l_i; }
+    return;
+  }
+  const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+  bf16_t* Og = (bf16_t*)p.O + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + (int64_t)qr * p.o_ss;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = dt * 32 + 8 * g + 4 * h;
+      if (d0 < DV) {
+        uint2 v;
+        v.x = f2bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+        v.y = f2bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(Og + d0) = v;
+      }
+    }
+}
+
 template <int DP, bool CAUSAL, int QB, int NW>
 int launch_dma(const AttnArgs& p, hipStream_t st) {
   constexpr int lds = 3 * 2 * 64 * 256;      // three stages of (K tile + V tile)
@@ -317,6 +510,24 @@ int launch_dma(const AttnArgs& p, hipStream_t st) {
 }
 
 }  // namespace
+
+bool attn_dma_dv_eligible(const AttnArgs& p) {
+  return p.D == 256 && p.DV == 64 && p.Hq == p.Hkv && p.causal == 0 && !p.fold && !p.skv_dev && p.Sq >= 256 && (p.nsplit == 1 || p.split_len % 64 == 0) &&
+         ((p.o_ss | p.o_sh | p.o_sb) & 3) == 0 && ((uintptr_t)p.O & 7) == 0;
+}
+
+int attn_dma_dv_launch(const AttnArgs& p, hipStream_t st) {
+  constexpr int lds = 3 * (64 * 512 + 64 * 256);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)attn_dma_d256v64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once = true;
+  }
+  dim3 grid(((p.Sq + 255) / 256) * p.nsplit, p.Hq, p.B);
+  attn_dma_d256v64_kernel<<<grid, 512, lds, st>>>(p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
 
 bool attn_dma_eligible(const AttnArgs& p) {
   const int padded = (p.Sq + 255) / 256 * 256;      // 256-row query tiles: below 1024 queries at most 1/8 of the rows may idle (CLIP's 577 -> 768 stays on attn_kernel)

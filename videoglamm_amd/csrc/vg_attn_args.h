@@ -19,3 +19,6 @@ struct AttnArgs {
 // vg_attention_dma.hip: the LDS-DMA-staged kernel (bf16, head dim <= 128, no split / fold / window)
 bool attn_dma_eligible(const AttnArgs& p);
 int attn_dma_launch(const AttnArgs& p, hipStream_t st);
+// ... and its head-dim-256 / 64-wide-value form with split-KV partials (vg_attention_dv)
+bool attn_dma_dv_eligible(const AttnArgs& p);
+int attn_dma_dv_launch(const AttnArgs& p, hipStream_t st);

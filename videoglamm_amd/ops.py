@@ -448,7 +448,9 @@ def attention_dv(q, k, v, scale):
         return attention(q, k, vp, scale)[..., :DV].contiguous()
     out = torch.empty(B, Sq, H, DV, dtype=q.dtype, device=q.device)
     nsplit, ws = 1, None
-    blocks = -(-Sq // 128) * H * B
+    # r06: the LDS-DMA form (vg_attention_dma.hip) takes D = 256 / DV = 64 with 256-row query tiles; attn_kernel's key-split form has 128-row tiles
+    dma = D == 256 and DV == 64 and Sq >= 256 and q.dtype == torch.bfloat16 and _os.environ.get("VG_ATTN_DMA", "1") != "0"
+    blocks = -(-Sq // (256 if dma else 128)) * H * B
     if Skv >= 512 and blocks < 384:
         nsplit = max(1, min(64, _SPLIT_WG_D256 // blocks, Skv // 128))
     if nsplit > 1:
