@@ -32,9 +32,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
   int bx = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   if (p.xcd) {      // (batch, head) pairs in blocks per XCD: the query tiles of a pair walk the same K / V through ONE L2 (attn_kernel's order)
     const int nx = gridDim.x, BH = gridDim.y * gridDim.z;
-    const int L = (blockIdx.z * gridDim.y + blockIdx.y) * nx + blockIdx.x, j = L >> 3;
-    const int bh = (L & 7) * (BH >> 3) + j / nx;
-    bx = j % nx;
+    const int L = (blockIdx.z * gridDim.y + blockIdx.y) * nx + blockIdx.x, j = L >> 3, per = BH >> 3;
+    // causal: the query tiles' lengths differ by up to nx x — inside an XCD the workgroups go out longest-first over ALL its heads (tile rank major), so the
+    // short ones fill the tail; head-major order started a head's longest tile when the CUs were already busy (C2 prefill: 80 tile times of makespan
+    // against 56 for this order, 52.5 for a perfect balance)
+    const int bh = (L & 7) * per + (CAUSAL ? j % per : j / nx);
+    bx = CAUSAL ? j / per : j % nx;
     head = bh % (int)gridDim.y;
     b = bh / (int)gridDim.y;
   }
