@@ -21,7 +21,11 @@ def t(f, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-for B, Skv in ((1, 4160), (1, 28736), (8, 28736), (8, 12000)):
+if __name__ != "__main__":
+    SH = ()
+else:
+    SH = ((1, 4160), (1, 28736), (8, 28736), (8, 12000))
+for B, Skv in SH:
     q = torch.randn(B, 4096, 1, D, device="cuda", dtype=torch.bfloat16)
     k = torch.randn(B, Skv, 1, D, device="cuda", dtype=torch.bfloat16)
     v = torch.randn(B, Skv, 1, DV, device="cuda", dtype=torch.bfloat16)
