@@ -442,6 +442,18 @@ int vg_mask_pair_counts(const uint8_t* a, const uint8_t* b, int64_t* inter, int6
 int vg_boundary_counts(const uint8_t* fg, const uint8_t* gt, int64_t* out, int N, int H, int W, int radius,
                        vg_stream_t stream);
 
+/* ---- small MLP heads (r06) ----
+ * vg_mlp3_grouped: G independent three-layer MLPs (Linear, ReLU, Linear, ReLU, Linear; sigmoid on the outputs of head g when bit g of sig_mask is set)
+ * in one launch: SAM2's output_hypernetworks_mlps (G = 4), iou_prediction_head + pred_obj_score_head (G = 2) and obj_ptr_proj (G = 1) —
+ * R/modeling/sam/mask_decoder.py:232-245, R/modeling/sam2_base.py:425-431, MLP = R/modeling/sam2_utils.py:108-132.  bf16 rows and weights.
+ *   x: head g reads rows x + g * x_gs + r * x_rs (r < R; strides in elements, multiples of 8), K inputs each.
+ *   w0 [G, Hd, K], b0 [G, Hd] fp32, w1 [G, Hd, Hd], b1 [G, Hd], w2 [G, No, Hd], b2 [G, No]: the heads' nn.Linear parameters stacked.
+ *   out: element (r, g, c) at out + r * o_rs + g * o_gs + c (c < No), out_dtype bf16 or fp32.  K, Hd multiples of 16 in [16, 256], No in [1, 256].
+ * The activations between the layers are rounded to bf16, as vg_gemm's bf16 outputs are. */
+int vg_mlp3_grouped(const void* x, int64_t x_rs, int64_t x_gs, const void* w0, const float* b0, const void* w1, const float* b1, const void* w2,
+                    const float* b2, void* out, int64_t o_rs, int64_t o_gs, int out_dtype, int G, int R, int K, int Hd, int No, unsigned sig_mask,
+                    vg_stream_t stream);
+
 /* ---- image pre-processing: uint8 frames in HBM -> the three model inputs ---- */
 /* One 8-bit pass of Pillow's separable resampler over in:[N,H,W,C] uint8 (C <= 4): axis 1 resizes W -> out_size
  * (out:[N,H,out_size,C]), axis 0 resizes H -> out_size (out:[N,out_size,W,C]).  bounds:[out_size,2] = (first input

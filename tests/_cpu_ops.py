@@ -98,8 +98,10 @@ def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, re
     return linear(window_partition(x.view(B, H, W, -1), ws), w, bias, act, gamma)
 
 
-def bmm_nt(a, w, out_dtype=None):
+def bmm_nt(a, w, out_dtype=None, shared_a=False):
     odt = out_dtype if out_dtype is not None else a.dtype
+    if shared_a:
+        a = a[:, :w.shape[-1]]
     return (a.float() @ w.float().transpose(-1, -2)).to(odt)
 
 
@@ -505,3 +507,15 @@ def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
 
 
 ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]
+
+
+def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
+    No = w2.shape[1]
+    for g in range(G):
+        h = F.relu(x[:, g, :].float() @ w0[g].float().t() + b0[g]).to(x.dtype)
+        h = F.relu(h.float() @ w1[g].float().t() + b1[g]).to(x.dtype)
+        y = h.float() @ w2[g].float().t() + b2[g]
+        if (sigmoid_mask >> g) & 1:
+            y = torch.sigmoid(y)
+        out[:, g, :No] = y.to(out.dtype)
+    return out

@@ -53,6 +53,7 @@ def _sig(lib):
         "vg_decode_step_begin": ([P, P, P, I, I, P, P, P, P, I, P], c_int),
         "vg_argmax_partial": ([P, L, I, P, I, P], c_int),
         "vg_decode_step_end": ([P, P, P, P, P, I, P, P, I, P, P, I, I, P], c_int),
+        "vg_mlp3_grouped": ([P, L, L, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, ctypes.c_uint, P], c_int),
         "vg_decode_layer_roles": ([I, I, I, I, I, I], c_int),
         "vg_decode_layer_flag_ints": ([], c_int64),
         "vg_decode_layer": ([P, P, P, P, P, P, I, I, I, I, I, F, P, P, L, P, P, L, P, P, P, F, P, L, P, P, L, P, I, I, I, P], c_int),

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_dma_kernel(AttnArgs p) {
 // 128 rows) and stages through registers; here a wave owns its 32 rows for all 64 keys and 8 waves share a tile over 256 rows.
 __global__ __launch_bounds__(512, 1) void attn_dma_d256v64_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NG = 16, NDT = 2, BKV = 64, BQ = 256, NW = 8;
+  constexpr int NG = 16, NDT = 2, BKV = 64, BQ = 256;
   constexpr int KT = BKV * 512, STAGE = KT + BKV * 256;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;

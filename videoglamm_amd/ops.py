@@ -321,6 +321,20 @@ def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
     return out
 
 
+def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
+    """G three-layer MLP heads in one launch (vg_mlp3_grouped).  x: a bf16 [R, >= G, K] view (head g reads x[:, g, :]); w0 [G, Hd, K], w1 [G, Hd, Hd],
+    w2 [G, No, Hd] bf16, b* fp32 [G, .]; out: a bf16 / fp32 [R, G, >= No] view whose leading No columns are written."""
+    lib = _lib.load()
+    R, K = x.shape[0], x.shape[2]
+    Hd, No = w0.shape[1], w2.shape[1]
+    assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and out.stride(2) == 1 and x.shape[1] >= G and out.shape[1] >= G and out.shape[2] >= No
+    assert w0.shape == (G, Hd, K) and w1.shape == (G, Hd, Hd) and w2.shape == (G, No, Hd) and all(t.is_contiguous() for t in (w0, b0, w1, b1, w2, b2))
+    rc = lib.vg_mlp3_grouped(_p(x), x.stride(0), x.stride(1), _p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), out.stride(0), out.stride(1),
+                             _dt(out), G, R, K, Hd, No, int(sigmoid_mask), _stream())
+    _lib.check(rc, "vg_mlp3_grouped")
+    return out
+
+
 def heads_blockdiag(x, TP):
     """[N, nt, 128] -> block-diagonal [N * 8 * TP, 128]: row (h, t) holds head h's 16 channels of token t, zeros elsewhere (vg_heads_blockdiag)."""
     x = x.contiguous()
@@ -380,17 +394,23 @@ def linear_window(x, w, bias, B, H, W, ws, scatter, act=ACT_NONE, gamma=None, re
     return out
 
 
-def bmm_nt(a, w, out_dtype=None):
-    """c[b] = a[b] @ w[b]^T ; a: [B,M,K], w: [B,N,K] (or [N,K] shared) -> [B,M,N]."""
+def bmm_nt(a, w, out_dtype=None, shared_a=False):
+    """c[b] = a[b] @ w[b]^T ; a: [B,M,K], w: [B,N,K] (or [N,K] shared) -> [B,M,N].  shared_a: a is ONE [M, >= K] matrix for every batch entry (batch
+    stride 0; its leading K columns are used — a K-padded weight), w: [B,N,K]."""
     lib = _lib.load()
     a = a.contiguous()
     w = w.contiguous()
-    B, M, K = a.shape
+    if shared_a:
+        assert a.dim() == 2 and w.dim() == 3 and a.shape[1] >= w.shape[2]
+        B, (M, lda), K, sA = w.shape[0], a.shape, w.shape[2], 0
+    else:
+        B, M, K = a.shape
+        lda, sA = K, M * K
     N = w.shape[-2]
     sW = 0 if w.dim() == 2 else N * K
     odt = out_dtype if out_dtype is not None else a.dtype
     out = torch.empty(B, M, N, dtype=odt, device=a.device)
-    rc = lib.vg_gemm(_p(a), K, M * K, _p(w), K, sW, _p(out), N, M * N, None, None, None, 0, 0, M, N, K, B,
+    rc = lib.vg_gemm(_p(a), lda, sA, _p(w), K, sW, _p(out), N, M * N, None, None, None, 0, 0, M, N, K, B,
                      _dt(a), _dt(out), ACT_NONE, 0, _stream())
     _lib.check(rc, "vg_gemm(batched)")
     return out

@@ -141,6 +141,17 @@ class SAM2:
                          out_dtype=out_dtype if last else None, out=out if last else None)
         return x
 
+    def _heads_grouped(self):
+        """the small three-layer heads ride vg_mlp3_grouped in the bf16 mode (fp32 parity mode keeps one vg_gemm per layer)"""
+        return self.dtype == torch.bfloat16
+
+    def _mlp3_stack(self, names):
+        """the parameters of several equally shaped three-layer MLPs stacked for vg_mlp3_grouped: (w0 [G,Hd,K], b0, w1, b1, w2 [G,No,Hd], b2), computed once"""
+        def make(i, bias):
+            return lambda: torch.stack([self.P.sd[f"{self.p}{n}.layers.{i}.{'bias' if bias else 'weight'}"].float() for n in names])
+        key = tuple(names)
+        return tuple(self.P.const(("mlp3", key, i, bias), make(i, bias), dtype=torch.float32 if bias else None) for i in range(3) for bias in (False, True))
+
     # ------------------------------------------------------------------ S1 Hiera + FPN
     def _hiera_pos(self, h, w):
         def make():
@@ -321,8 +332,8 @@ class SAM2:
             return self.P.const((name, kind), lambda: scale * w(".k_proj").t())
         if kind == "uqT":        # image -> token: scale Wq^T
             return self.P.const((name, kind), lambda: scale * w(".q_proj").t())
-        if kind == "cq":         # [8, 128]: row 0 = scale bq (c2 = Kbd . scale bq), rows 1..7 zero (a whole 16-byte fp32 output group)
-            return self.P.const((name, kind), lambda: torch.cat([scale * b(".q_proj")[None], torch.zeros(7, 128, device=b(".q_proj").device)], 0))
+        if kind == "cq":         # [1, 128]: scale bq, the single input row of c2 = (scale bq) . Kbd^T
+            return self.P.const((name, kind), lambda: scale * b(".q_proj")[None])
         raise KeyError(kind)
 
     def _t2i_fused(self, name, queries, query_pe, xpe, x, TP):
@@ -343,8 +354,11 @@ class SAM2:
         k_bd = self._heads_bd(self.lin(name + ".k_proj", ops.add(queries, query_pe)), TP)
         v_bd = self._heads_bd(self.lin(name + ".v_proj", queries), TP)
         u2 = ops.linear(k_bd, self._tw_const(name, "uqT")).view(N, NC, 256)
-        c2 = ops.linear(k_bd, self._tw_const(name, "cq"), out_dtype=torch.float32).view(N, NC, 8)[:, :, 0].contiguous()
-        w2t = ops.linear(v_bd, self.P.w(self.p + name + ".out_proj")).view(N, NC, 256).transpose(1, 2).contiguous()      # [N, 256, NC]
+        # r06: both come out of their GEMM in the layout the kernel reads — c2 as the ONE output row of (scale bq) . Kbd^T (the roles of rows and weights
+        # swapped: a contiguous fp32 [N NC]), W2^T [N, 256, NC] as a batched Wo . Vbd[n]^T with Wo shared over the batch (stride 0) — instead of a strided
+        # column copy and a transpose copy (two ATen launches per block, four per tracked frame)
+        c2 = ops.linear(self._tw_const(name, "cq"), k_bd, out_dtype=torch.float32).view(N, NC)
+        w2t = ops.bmm_nt(self.P.w(self.p + name + ".out_proj"), v_bd.view(N, NC, -1), shared_a=True)                    # [N, 256, NC]
         return ops.twoway_image_update(xpe, x, u2, c2, w2t, self.P.b(self.p + name + ".out_proj"), self.P.f32(self.p + norm + ".weight"),
                                        self.P.f32(self.p + norm + ".bias"), 1e-5, pe, nt, TP)
 
@@ -400,8 +414,11 @@ class SAM2:
         s0, s1 = high_res            # [Bi, ...]: ops.add broadcasts them over the instance groups (instance i -> image i % Bi)
         nhy = self.P.w(self.p + f"{d}output_hypernetworks_mlps.0.layers.2").shape[0]
         hyper = torch.empty(N, 4, nhy, dtype=hs.dtype, device=hs.device)
-        for i in range(4):       # (row-strided views in and out: no per-token copies, no stack)
-            self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :], 3, out=hyper[:, i, :])
+        if self._heads_grouped():      # r06: the four hypernetwork MLPs in one launch (vg_mlp3_grouped) instead of twelve
+            ops.mlp3_grouped(mask_toks, 4, *self._mlp3_stack([f"{d}output_hypernetworks_mlps.{i}" for i in range(4)]), out=hyper)
+        else:
+            for i in range(4):       # (row-strided views in and out: no per-token copies, no stack)
+                self.mlp(f"{d}output_hypernetworks_mlps.{i}", mask_toks[:, i, :], 3, out=hyper[:, i, :])
         if fused:
             # r04: upscaling + hypernetwork product in one kernel (the two [N, 16384, 64] / [N, 65536, 32] intermediates never exist)
             masks = ops.mask_upscale(src, self.P.convT_w(self.p + d + "output_upscaling.0"), self.P.b(self.p + d + "output_upscaling.0"), s1.view(Bi, 4 * es * es, 64),
@@ -417,8 +434,15 @@ class SAM2:
             up = ops.pixel_shuffle2(g, self.P.b(self.p + d + "output_upscaling.3"), N, 2 * es, 2 * es, 32)
             up = ops.activation(ops.add(up, s0), ops.ACT_GELU)                       # [N,4es,4es,32]
             masks = ops.bmm_nt(hyper, up.view(N, 16 * es * es, 32), out_dtype=torch.float32).view(N, 4, 4 * es, 4 * es)
-        iou = self.mlp(d + "iou_prediction_head", iou_tok, 3, sigmoid_output=True, out_dtype=torch.float32)
-        obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :], 3, out_dtype=torch.float32)
+        if self._heads_grouped():      # one launch per head instead of three (their outputs stay contiguous [N, 4] / [N, 1] for the selection kernels)
+            iou = torch.empty(N, 1, 4, dtype=torch.float32, device=hs.device)
+            obj = torch.empty(N, 1, 1, dtype=torch.float32, device=hs.device)
+            ops.mlp3_grouped(hs[:, 1:2, :], 1, *self._mlp3_stack([d + "iou_prediction_head"]), out=iou, sigmoid_mask=1)
+            ops.mlp3_grouped(hs[:, 0:1, :], 1, *self._mlp3_stack([d + "pred_obj_score_head"]), out=obj)
+            iou, obj = iou.view(N, 4), obj.view(N, 1)
+        else:
+            iou = self.mlp(d + "iou_prediction_head", iou_tok, 3, sigmoid_output=True, out_dtype=torch.float32)
+            obj = self.mlp(d + "pred_obj_score_head", hs[:, 0, :], 3, out_dtype=torch.float32)
         return masks, iou, mask_toks.contiguous(), obj
 
     # ------------------------------------------------------------------ S5 memory attention
@@ -569,7 +593,10 @@ class SAM2:
         low, _, tok, _ = ops.multimask_select(masks, iou, toks, 1 if multimask_output else 0)
         low = ops.where_rows(obj, low, None, NO_OBJ_SCORE)
         high = ops.bilinear(low.view(N, 4 * self.es, 4 * self.es), self.S, self.S).view(N, 1, self.S, self.S)
-        ptr = self.mlp("obj_ptr_proj", tok, 3)
+        if self._heads_grouped():
+            ptr = ops.mlp3_grouped(tok.view(N, 1, -1), 1, *self._mlp3_stack(["obj_ptr_proj"]), out=torch.empty(N, 1, tok.shape[-1], dtype=tok.dtype, device=tok.device)).view(N, -1)
+        else:
+            ptr = self.mlp("obj_ptr_proj", tok, 3)
         ptr = ops.where_rows(obj, ptr, self.P.t(self.p + "no_obj_ptr").view(-1), out=ptr_out)
         return dict(low=low, high=high, obj_ptr=ptr, obj_logits=obj, low_multi_pre_where=masks[:, 1:], ious=iou[:, 1:])
 
