@@ -466,9 +466,14 @@ def attn_roofs(am, traffic_of=lambda key: None, peak=2500.0):
                                     "achieved_tflops": round(ach, 1), "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3),
                                     "avg_launch_us": round(1e3 * ms / n, 1), "kernel_ms_per_step": round(ms, 2), "traffic": traffic_of("attn_window")}
             continue
-        label = (f"attn_kernel<bf16, 256, 64, 8, 2, DV = {str(dp).split('_dv')[1]}> (vg_attention_dv: SAM2 memory cross-attention, v-projection behind the attention; "
-                 "flops = 2 Sq Skv (D + DV); + the split-KV merge)") if "_dv" in str(dp) else \
-            f"attn_dma_kernel<{dp}> (long sequences: LDS-DMA staging, r06) / attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)"
+        if "_dv" in str(dp):
+            label = (f"attn_dma_d256v64_kernel (r06: LDS-DMA ring, 256-dim keys, DV = {str(dp).split('_dv')[1]}; attn_kernel<bf16, 256, 64, 8, 2, 64> below 256 query rows) — "
+                     "vg_attention_dv: SAM2 memory cross-attention, v-projection behind the attention; flops = 2 Sq Skv (D + DV); + the split-KV merge")
+        elif str(dp).startswith("256"):
+            label = "attn_kernel<bf16, 256, 64, 8, 2> (head dim 256: two key-split waves per 32 query rows; flash-style, QK^T / PV on the 32x32x16 MFMA; + the split-KV merge where used)"
+        else:
+            label = (f"attn_dma_kernel<{dp}> (long sequences: LDS-DMA staging, r06) / attn_kernel<bf16, {dp}, 64, 4 | 8> (flash-style, QK^T / PV on the 32x32x16 MFMA; "
+                     "+ the split-KV merge where used)")
         roofs[f"attn_d{dp}"] = {"bound": "mfma", "kernel": label,
                                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic_of(f"attn_d{dp}"),
                                 "launches": n, "algorithmic_tflop_per_step": round(fl / 1e12, 3), "algorithmic_tflop_per_launch": round(fl / 1e12 / n, 5),

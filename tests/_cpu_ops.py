@@ -506,9 +506,6 @@ def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
     return torch.from_numpy(_n.ascontiguousarray(_n.transpose(y, (0, 3, 1, 2)))).to(out_dtype)
 
 
-ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]
-
-
 def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
     No = w2.shape[1]
     for g in range(G):
@@ -519,3 +516,6 @@ def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
             y = torch.sigmoid(y)
         out[:, g, :No] = y.to(out.dtype)
     return out
+
+
+ALL = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("torch", "F")]

@@ -152,6 +152,15 @@ def test_host_graph_fused_two_way_cpu(cpu_ops, monkeypatch):
     run_checks(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
 
 
+def test_host_graph_grouped_heads_cpu(cpu_ops, monkeypatch):
+    """r06: the mask decoder's three-layer heads through ops.mlp3_grouped (stacked parameters, the heads' inputs as strided views of the output tokens) —
+    the bf16 mode's route, forced here in fp32 on the CPU twins against the reference fixtures of the framewise graph and of the no-object video clip."""
+    from videoglamm_amd.sam2 import SAM2
+    monkeypatch.setattr(SAM2, "_heads_grouped", lambda self: True)
+    run_checks(torch.device("cpu"), dict(rtol=1e-4, atol=2e-4))
+    run_noobj(torch.device("cpu"), dict(rtol=1e-3, atol=1e-3))
+
+
 def test_video_reference_order_of_operations_cpu(cpu_ops, monkeypatch):
     """r04's / r05's reformulations of the video branch are algebra, not approximation: with every one of them switched OFF (v-projection applied to
     the memory rows in front of the attention, the mask downsampler as im2col + GEMM + LayerNorm + GELU launches, separate q / k / v projections,

@@ -41,7 +41,7 @@ def main():
     lib_sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
     # (model-build kernels — the synthetic weights' RNG and scaling — run once per process, not per pass: kept out of the per-pass total)
     rows = [r for r in rows if not re.search(INIT_KERNELS, r[0])]
-    res = {"round": 5, "lib_sha16": lib_sha, "mode": mode, "command": command, "passes": passes,
+    res = {"round": 6, "lib_sha16": lib_sha, "mode": mode, "command": command, "passes": passes,
            "total_kernel_ms_per_pass": round(sum(r[2] for r in rows) / 1e3 / passes, 2), "kernels": {}}
     for key, pat in CLASSES:
         sel = [r for r in rows if re.search(pat, r[0])]

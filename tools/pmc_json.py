@@ -44,7 +44,7 @@ def main():
         f = sum(fetch[n][0] * fetch[n][1] for n in names) / nf
         nw = sum(write[n][0] for n in names if n in write)
         w = sum(write[n][0] * write[n][1] for n in names if n in write) / max(nw, 1)
-        out = {"round": 5, "workload": workload, "command": command, "fetch_correction": 2.0, "kernel": key, "kernel_names": sorted(n[:120] for n in names),
+        out = {"round": 6, "workload": workload, "command": command, "fetch_correction": 2.0, "kernel": key, "kernel_names": sorted(n[:120] for n in names),
                "dispatches": nf, "FETCH_SIZE_KB_avg_per_dispatch": round(f, 1), "WRITE_SIZE_KB_avg_per_dispatch": round(w, 1),
                "traffic_bytes_per_launch": round((2.0 * f + w) * 1000.0)}
         with open(os.path.join(outdir, f"{tag}_pmc_{key}.json"), "w") as fh:
