@@ -324,7 +324,9 @@ static int rr_launch_v(const GemmArgs& q, int wgs, size_t lds, hipStream_t st) {
 // K in {144, 288}, bf16 in and out, N a multiple of 16, 16-byte aligned C / R rows, act none | GELU (GELU without a residual), no LayerScale / fp8 scales / batch
 bool vg_gemm_rr_eligible(const GemmArgs& p, int batch, bool out_is_bf16) {
   return (p.K == 144 || p.K == 288) && out_is_bf16 && batch == 1 && !p.a_op && !p.sa && !p.gamma && p.vec_out && p.N % 16 == 0 && p.N >= 16 &&
-         (p.act == VG_ACT_NONE || (p.act == VG_ACT_GELU && !p.R)) && p.ksplit <= 1 && !((p.ln_w || p.ln_b) && p.R);
+         (p.act == VG_ACT_NONE || (p.act == VG_ACT_GELU && !p.R)) && p.ksplit <= 1 && !((p.ln_w || p.ln_b) && p.R) &&
+         // the streamed form's LDS: bias per 64-column chunk + gamma | beta + the epilogue slabs + two weight slots (vg_gemm_rr_launch) within 158 KB
+         (size_t)((p.N + 63) / 64) * 256 + 8 * (size_t)p.K + 8 * 4096 + 2 * 64 * (size_t)(p.K * 2 + 16) <= 158 * 1024;
 }
 
 int vg_gemm_rr_launch(const GemmArgs& q, int ncu, hipStream_t st) {

@@ -49,6 +49,16 @@ class FrameSharder:
         # text side's small collectives (tower tokens, K/V rows, [SEG]) would queue behind every Hiera chunk of the slowest rank.  new_group is
         # collective over the default group, and every rank constructs its FrameSharder with the same arguments.
         self.feat_group = group
+        if self.world > 1:
+            # new_group below is collective: ranks that disagree on the setting (an env var set on some of them) would deadlock — agree first, loudly
+            flag = torch.tensor([int(self.stream_features)], dtype=torch.int64)
+            lo, hi = flag.clone(), flag.clone()
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            lo, hi = lo.to(dev), hi.to(dev)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if int(lo) != int(hi):
+                raise RuntimeError("FrameSharder: the ranks disagree on stream_features / VG_FEATURES_STREAMED")
         if self.stream_features and self.world > 1:
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             self.feat_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))

@@ -92,7 +92,8 @@ class SAM2:
     def video_static_feats(self, n):
         """persistent per-level buffers [n, h, w, c] the graph-replayed propagation reads (video_branch_graphed): handed to hiera_frames as `bufs`,
         Hiera's last kernels write the clip's features straight into them — the replay then has nothing to copy (r05: 96 staging copies = 268 MB
-        per 32-frame clip before)."""
+        per 32-frame clip before).  The features hiera_frames returns for these buffers are views of them: valid until the next clip of this length
+        is encoded.  Buffers of lengths without a cached graph are dropped when the graph cache evicts (video_branch_graphed)."""
         st = self.__dict__.setdefault("_video_static", {})
         if n not in st:
             st[n] = [torch.empty((n,) + shp, dtype=self.dtype, device=self.device) for shp in self.level_shapes()]
@@ -268,7 +269,7 @@ class SAM2:
                 nap = self.P.t(self.p + "sam_prompt_encoder.not_a_point_embed.weight")
                 return nap.view(1, 1, 256).expand(n, 2, 256).contiguous()
             t = self.P.const(("sparse_empty", n), make)
-            self.__dict__.setdefault("_const_sparse", set()).add(t.data_ptr())
+            t._vg_const_prompt = True      # an explicit mark on THIS tensor object (a view or a slice of it does not carry it); read-only by contract
             return t
         parts = []
         if with_empty_point:
@@ -399,7 +400,8 @@ class SAM2:
         out_tokens = self.P.const("mask_decoder_out_tokens", lambda: torch.cat([self.P.t(self.p + d + "obj_score_token.weight"), self.P.t(self.p + d + "iou_token.weight"),
                                                                                  self.P.t(self.p + d + "mask_tokens.weight")], dim=0))
         mk_tokens = lambda: torch.cat([out_tokens.unsqueeze(0).expand(N, -1, -1), sparse], dim=1).contiguous()      # noqa: E731
-        tokens = self.P.const(("mask_decoder_tokens_empty", N), mk_tokens) if sparse.data_ptr() in self.__dict__.get("_const_sparse", ()) else mk_tokens()
+        # the constant empty prompt (sparse_prompt marks it) has a constant token tensor: cached per object count, never written in place (queries / query_pe)
+        tokens = self.P.const(("mask_decoder_tokens_empty", N), mk_tokens) if getattr(sparse, "_vg_const_prompt", False) else mk_tokens()
         no_mask = self.P.t(self.p + "sam_prompt_encoder.no_mask_embed.weight").view(-1)
         src = ops.add(image_embed, no_mask).view(Bi, es * es, 256)  # dense prompt = no_mask_embed broadcast (prompt_encoder.py:183-187)
         # the fused image side needs the bf16 kernels (vg_twoway_image_update, head-dim-256 attention); fp32 parity mode keeps the reference's order
@@ -803,6 +805,11 @@ class SAM2:
         if ent is None:
             while len(graphs) >= 4:
                 graphs.pop(next(iter(graphs)))
+            # the persistent feature buffers of clip lengths no cached graph reads any more go with them (8.4 MB per frame at SAM2-L: a long-lived
+            # process fed varied clip lengths would otherwise grow without bound)
+            st_all = self.__dict__.get("_video_static", {})
+            for n in [n for n in st_all if n != T and all(k[0] != n for k in graphs)]:
+                del st_all[n]
             self.video_branch(images, text_embeds, video_hw, frame_feats=frame_feats, as_masks=as_masks)      # eager once: lazy weight packing, kernel attributes
             # static inputs of the graph: the persistent feature buffers themselves when the caller's features already live there
             # (model.inference_video_branch hands them to Hiera), private copies otherwise
