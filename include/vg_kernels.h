@@ -447,7 +447,9 @@ int vg_boundary_counts(const uint8_t* fg, const uint8_t* gt, int64_t* out, int N
  * in one launch: SAM2's output_hypernetworks_mlps (G = 4), iou_prediction_head + pred_obj_score_head (G = 2) and obj_ptr_proj (G = 1) —
  * R/modeling/sam/mask_decoder.py:232-245, R/modeling/sam2_base.py:425-431, MLP = R/modeling/sam2_utils.py:108-132.  bf16 rows and weights.
  *   x: head g reads rows x + g * x_gs + r * x_rs (r < R; strides in elements, multiples of 8), K inputs each.
- *   w0 [G, Hd, K], b0 [G, Hd] fp32, w1 [G, Hd, Hd], b1 [G, Hd], w2 [G, No, Hd], b2 [G, No]: the heads' nn.Linear parameters stacked.
+ *   w0, w1, w2: the heads' nn.Linear weights ([Hd, K], [Hd, Hd], [No, Hd] per head) stacked over the heads and PACKED in MFMA fragment order, so that a wave's
+ *   load is one contiguous KiB: [G][ceil(out / 32)][in / 16][64][8] with element (g, t, s, lane, e) = W_g[32 t + lane % 32][16 s + 8 (lane / 32) + e], rows past
+ *   `out` zero (videoglamm_amd/ops.py:mlp3_pack is the reference packing).  b0 [G, Hd], b1 [G, Hd], b2 [G, No]: fp32, plain.
  *   out: element (r, g, c) at out + r * o_rs + g * o_gs + c (c < No), out_dtype bf16 or fp32.  K, Hd multiples of 16 in [16, 256], No in [1, 256].
  * The activations between the layers are rounded to bf16, as vg_gemm's bf16 outputs are. */
 int vg_mlp3_grouped(const void* x, int64_t x_rs, int64_t x_gs, const void* w0, const float* b0, const void* w1, const float* b1, const void* w2,

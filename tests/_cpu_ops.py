@@ -506,8 +506,22 @@ def normalize_u8(x, mean, std, mode, crop=None, out_dtype=torch.float32):
     return torch.from_numpy(_n.ascontiguousarray(_n.transpose(y, (0, 3, 1, 2)))).to(out_dtype)
 
 
+def mlp3_pack(w):
+    G, n_out, n_in = w.shape
+    T = -(-n_out // 32)
+    wp = torch.zeros(G, T * 32, n_in, dtype=w.dtype, device=w.device)
+    wp[:, :n_out] = w
+    return wp.view(G, T, 32, n_in // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(G, T, n_in // 16, 64, 8)
+
+
+def _mlp3_unpack(wp, n_out):
+    G, T, nk = wp.shape[:3]
+    return wp.view(G, T, nk, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(G, T * 32, nk * 16)[:, :n_out]
+
+
 def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
-    No = w2.shape[1]
+    Hd, No = b0.shape[1], b2.shape[1]
+    w0, w1, w2 = _mlp3_unpack(w0, Hd), _mlp3_unpack(w1, Hd), _mlp3_unpack(w2, No)
     for g in range(G):
         h = F.relu(x[:, g, :].float() @ w0[g].float().t() + b0[g]).to(x.dtype)
         h = F.relu(h.float() @ w1[g].float().t() + b1[g]).to(x.dtype)

@@ -29,10 +29,10 @@ def test_mlp3_grouped_vs_statement(cuda, G, R, K, Hd, No, out_dtype, sig):
     x = rnd(R, nt, K, seed=1)                                     # the heads read token rows 1 .. G of a wider token tensor (a strided view)
     w0, w1, w2 = rnd(G, Hd, K, seed=2, scale=K ** -0.5), rnd(G, Hd, Hd, seed=3, scale=Hd ** -0.5), rnd(G, No, Hd, seed=4, scale=Hd ** -0.5)
     b0, b1, b2 = (rnd(G, n, seed=5 + i, scale=0.3, dtype=torch.float32) for i, n in enumerate((Hd, Hd, No)))
-    want = ref.mlp3_grouped(x[:, 1:], G, w0, b0, w1, b1, w2, b2, torch.zeros(R, G, No, dtype=out_dtype), sig)
+    want = ref.mlp3_grouped(x[:, 1:], G, ref.mlp3_pack(w0), b0, ref.mlp3_pack(w1), b1, ref.mlp3_pack(w2), b2, torch.zeros(R, G, No, dtype=out_dtype), sig)
     out = torch.full((R, G, No + 3), 7.0, dtype=out_dtype, device=cuda)      # a wider destination: the columns past No stay untouched
     c = lambda t: t.to(cuda)      # noqa: E731
-    ops.mlp3_grouped(c(x)[:, 1:], G, c(w0), c(b0), c(w1), c(b1), c(w2), c(b2), out, sig)
+    ops.mlp3_grouped(c(x)[:, 1:], G, ops.mlp3_pack(c(w0)), c(b0), ops.mlp3_pack(c(w1)), c(b1), ops.mlp3_pack(c(w2)), c(b2), out, sig)
     got = out.cpu()
     assert (got[:, :, No:] == 7.0).all()
     tol = dict(rtol=2e-2, atol=2e-2) if out_dtype == torch.bfloat16 else dict(rtol=4e-3, atol=4e-3)      # (bf16 roundings between the layers may differ by one step)
@@ -46,7 +46,7 @@ def test_mlp3_grouped_vs_per_layer_route(cuda):
     x = rnd(R, G, K, seed=11).to(cuda)
     w0, w1, w2 = rnd(G, Hd, K, seed=12, scale=K ** -0.5).to(cuda), rnd(G, Hd, Hd, seed=13, scale=Hd ** -0.5).to(cuda), rnd(G, No, Hd, seed=14, scale=Hd ** -0.5).to(cuda)
     b0, b1, b2 = (rnd(G, n, seed=15 + i, scale=0.3, dtype=torch.float32).to(cuda) for i, n in enumerate((Hd, Hd, No)))
-    got = ops.mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, torch.empty(R, G, No, dtype=torch.bfloat16, device=cuda))
+    got = ops.mlp3_grouped(x, G, ops.mlp3_pack(w0), b0, ops.mlp3_pack(w1), b1, ops.mlp3_pack(w2), b2, torch.empty(R, G, No, dtype=torch.bfloat16, device=cuda))
     for g in range(G):
         h = ops.linear(x[:, g, :].contiguous(), w0[g], b0[g], act=ops.ACT_RELU)
         h = ops.linear(h, w1[g], b1[g], act=ops.ACT_RELU)
@@ -62,4 +62,4 @@ def test_mlp3_grouped_rejects_bad_shapes(cuda):
     w0, w1, w2 = (torch.zeros(1, a, b, dtype=torch.bfloat16, device=cuda) for a, b in ((32, 24), (32, 32), (4, 32)))
     b0, b1, b2 = (torch.zeros(1, n, device=cuda) for n in (32, 32, 4))
     with pytest.raises(VGKernelError):
-        ops.mlp3_grouped(x, 1, w0, b0, w1, b1, w2, b2, torch.empty(2, 1, 4, device=cuda))
+        ops._lib.check(ops._lib.load().vg_mlp3_grouped(ops._p(x), 24, 24, ops._p(w0), ops._p(b0), ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(x), 4, 4, 1, 1, 2, 24, 32, 4, 0, None), 'vg_mlp3_grouped')

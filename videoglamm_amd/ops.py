@@ -321,14 +321,25 @@ def linear_ln(x, ln, w, bias=None, act=ACT_NONE, window=None):
     return out
 
 
+def mlp3_pack(w):
+    """[G, out, in] nn.Linear weights -> vg_mlp3_grouped's fragment order [G, ceil(out / 32), in / 16, 64, 8] (lane = 32 * k-half + row; rows past `out` zero)."""
+    G, n_out, n_in = w.shape
+    T = -(-n_out // 32)
+    wp = torch.zeros(G, T * 32, n_in, dtype=w.dtype, device=w.device)
+    wp[:, :n_out] = w
+    return wp.view(G, T, 32, n_in // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(G, T, n_in // 16, 64, 8)
+
+
 def mlp3_grouped(x, G, w0, b0, w1, b1, w2, b2, out, sigmoid_mask=0):
-    """G three-layer MLP heads in one launch (vg_mlp3_grouped).  x: a bf16 [R, >= G, K] view (head g reads x[:, g, :]); w0 [G, Hd, K], w1 [G, Hd, Hd],
-    w2 [G, No, Hd] bf16, b* fp32 [G, .]; out: a bf16 / fp32 [R, G, >= No] view whose leading No columns are written."""
+    """G three-layer MLP heads in one launch (vg_mlp3_grouped).  x: a bf16 [R, >= G, K] view (head g reads x[:, g, :]); w0, w1, w2: mlp3_pack of the stacked
+    [G, Hd, K], [G, Hd, Hd], [G, No, Hd] bf16 weights, b0 / b1 / b2 fp32 [G, Hd] / [G, Hd] / [G, No]; out: a bf16 / fp32 [R, G, >= No] view whose leading No
+    columns are written."""
     lib = _lib.load()
     R, K = x.shape[0], x.shape[2]
-    Hd, No = w0.shape[1], w2.shape[1]
+    Hd, No = b0.shape[1], b2.shape[1]
     assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and out.stride(2) == 1 and x.shape[1] >= G and out.shape[1] >= G and out.shape[2] >= No
-    assert w0.shape == (G, Hd, K) and w1.shape == (G, Hd, Hd) and w2.shape == (G, No, Hd) and all(t.is_contiguous() for t in (w0, b0, w1, b1, w2, b2))
+    assert w0.shape == (G, -(-Hd // 32), K // 16, 64, 8) and w1.shape == (G, -(-Hd // 32), Hd // 16, 64, 8) and w2.shape == (G, -(-No // 32), Hd // 16, 64, 8)
+    assert all(t.is_contiguous() for t in (w0, b0, w1, b1, w2, b2)) and b0.shape == (G, Hd) and b1.shape == (G, Hd) and b2.shape == (G, No)
     rc = lib.vg_mlp3_grouped(_p(x), x.stride(0), x.stride(1), _p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), out.stride(0), out.stride(1),
                              _dt(out), G, R, K, Hd, No, int(sigmoid_mask), _stream())
     _lib.check(rc, "vg_mlp3_grouped")

@@ -149,7 +149,8 @@ class SAM2:
     def _mlp3_stack(self, names):
         """the parameters of several equally shaped three-layer MLPs stacked for vg_mlp3_grouped: (w0 [G,Hd,K], b0, w1, b1, w2 [G,No,Hd], b2), computed once"""
         def make(i, bias):
-            return lambda: torch.stack([self.P.sd[f"{self.p}{n}.layers.{i}.{'bias' if bias else 'weight'}"].float() for n in names])
+            stack = lambda: torch.stack([self.P.sd[f"{self.p}{n}.layers.{i}.{'bias' if bias else 'weight'}"].float() for n in names])      # noqa: E731
+            return stack if bias else (lambda: ops.mlp3_pack(stack()))      # (weights in the kernel's fragment order)
         key = tuple(names)
         return tuple(self.P.const(("mlp3", key, i, bias), make(i, bias), dtype=torch.float32 if bias else None) for i in range(3) for bias in (False, True))
 
