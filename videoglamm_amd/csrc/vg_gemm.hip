@@ -794,6 +794,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   const T* A = (const T*)p.A + (int64_t)bz * p.sA;
   const T* Wr = (const T*)p.W + (int64_t)bz * p.sW + (int64_t)n * p.ldw;
   const T* Wu = Wr + (int64_t)p.N * p.ldw;   // GLU only
+  // the epilogue's operands are requested BEFORE the K loop (r06): bias / LayerScale by every lane, the residual of row m by lane m — they used to be
+  // dependent loads of lane 0 behind the reduction, two more memory round trips on a kernel whose whole time is latency (K = 256: one load per lane)
+  TO* C = (TO*)p.C + (int64_t)bz * p.sC;
+  const float bv = p.bias ? p.bias[n] : 0.f;
+  const float bu = (GLU && p.bias) ? p.bias[p.N + n] : 0.f;
+  const float gv = p.gamma ? p.gamma[n] : 1.f;
+  const int row = lane;      // lane m finishes row m (every lane holds every row's sum after the butterfly)
+  float rv = 0.f;
+  if (p.R && row < p.M) rv = vg_elt<TO>::ld((const TO*)p.R + (int64_t)bz * p.sR + (int64_t)row * p.ldr + n);
   float acc[MT], accu[GLU ? MT : 1];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
@@ -833,34 +842,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
       }
     }
   }
+  float mine = 0.f, mineu = 0.f;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
-  if constexpr (GLU) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) accu[m] = wave_sum(accu[m]);
-  }
-  if (lane == 0) {
-    TO* C = (TO*)p.C + (int64_t)bz * p.sC;
-    const TO* R = p.R ? (const TO*)p.R + (int64_t)bz * p.sR : nullptr;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-    const float gv = p.gamma ? p.gamma[n] : 1.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (m < p.M) {
-        float v;
-        if constexpr (GLU) {
-          float g = acc[m] + bv, u = accu[m] + (p.bias ? p.bias[p.N + n] : 0.f);
-          if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
-          g = vg_silu(g);
-          if (sizeof(T) == 2) g = bf2f(f2bf(g));
-          v = g * u * gv;
-        } else {
-          v = vg_act(acc[m] + bv, p.act) * gv;
-        }
-        if (R) v += vg_elt<TO>::ld(R + (int64_t)m * p.ldr + n);
-        vg_elt<TO>::st(C + (int64_t)m * p.ldc + n, v);
-      }
+  for (int m = 0; m < MT; ++m) {
+    const float t = wave_sum(acc[m]);
+    mine = lane == m ? t : mine;
+    if constexpr (GLU) {
+      const float tu = wave_sum(accu[m]);
+      mineu = lane == m ? tu : mineu;
     }
+  }
+  if (row < MT && row < p.M) {      // M stores in parallel
+    float v;
+    if constexpr (GLU) {
+      float g = mine + bv, u = mineu + bu;
+      if (sizeof(T) == 2) { g = bf2f(f2bf(g)); u = bf2f(f2bf(u)); }   // gate/up projections materialise in bf16 in HF
+      g = vg_silu(g);
+      if (sizeof(T) == 2) g = bf2f(f2bf(g));
+      v = g * u * gv;
+    } else {
+      v = vg_act(mine + bv, p.act) * gv;
+    }
+    if (p.R) v += rv;
+    vg_elt<TO>::st(C + (int64_t)row * p.ldc + n, v);
   }
 }
 
