@@ -43,15 +43,44 @@ __device__ __forceinline__ void st_any(void* p, int64_t i, int dt, float v) {
   if (dt == VG_BF16) ((bf16_t*)p)[i] = f2bf(v); else ((float*)p)[i] = v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave reductions on the VALU alone (r06): four DPP steps inside the 16-lane rows, then v_permlane16_swap / v_permlane32_swap across them; the result is in
+// every lane.  __shfl_xor compiles to ds_bpermute_b32 — an LDS-pipe round trip per step, six per reduction — which the latency-bound kernels (the skinny GEMM,
+// the decode GEMVs' norm prologue and row sums, the short-row norms) paid in full: 0.3 us per reduced value at the end of a dependent chain.
+template <int CTRL>
+__device__ __forceinline__ float vg_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over aligned groups of W lanes (W = 2 ... 64), result in every lane of the group.  The steps run from the widest to the narrowest — the association
+// of the __shfl_xor butterfly (32, 16, 8, 4, 2, 1) this replaces, so every kernel's sums keep their bits, and a short row reduced by 16 lanes equals the same
+// row reduced by a whole wave whose other lanes hold zeros (fused kernels are tested bit-equal to the stand-alone ones).  row_ror:8 IS xor 8 inside a
+// 16-lane row; row_ror:4 equals xor 4 in VALUE once the row is 8-periodic (after the xor-8 step) — for a group of 8 on its own it is row_half_mirror.
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (W >= 64) {
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  }
+  if constexpr (W >= 32) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  }
+  if constexpr (W >= 16) v += vg_dpp<0x128>(v);    // row_ror:8
+  if constexpr (W >= 16) v += vg_dpp<0x124>(v);    // row_ror:4
+  else if constexpr (W == 8) v += vg_dpp<0x141>(v);    // row_half_mirror
+  if constexpr (W >= 4) v += vg_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  if constexpr (W >= 2) v += vg_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  v = fmaxf(v, vg_dpp<0x128>(v));
+  v = fmaxf(v, vg_dpp<0x124>(v));
+  v = fmaxf(v, vg_dpp<0x4E>(v));
+  return fmaxf(v, vg_dpp<0xB1>(v));
 }
 
 // Exact (erf) GELU: x * Phi(x), Phi(x) = 0.5 * (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7, i.e. fp32 rounding

@@ -784,23 +784,6 @@ __global__ __launch_bounds__(256) void gemm_small64_kernel(GemmArgs p) {
 // M <= 16 rows.  One wave per output column n streams W[n,:] once (16-byte loads, 4 independent loads in flight per
 // lane) against the L1/L2-resident A rows.  a_op == 1: W is [2N, K] = gate rows | up rows and column n of the
 // output is silu(A.gate_n) * (A.up_n) (HF LlamaMLP act(gate(x)) * up(x)) — the SwiGLU never touches HBM.
-// Wave sum on the VALU alone: four DPP steps inside the 16-lane rows, then v_permlane16_swap / v_permlane32_swap across them (result in every lane).
-// __shfl_xor compiles to ds_bpermute — an LDS-pipe round trip per step, six per row of the skinny kernel (measured r06: 0.3 us per row at K = 256).
-template <int CTRL>
-__device__ __forceinline__ float skinny_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float skinny_wave_sum(float v) {
-  v += skinny_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
-  v += skinny_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
-  v += skinny_dpp<0x141>(v);    // row_half_mirror
-  v += skinny_dpp<0x140>(v);    // row_mirror
-  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 template <typename T, typename TO, int MT, bool GLU>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   constexpr int KPC = 16 / sizeof(T);
@@ -862,10 +845,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   float mine = 0.f, mineu = 0.f;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const float t = skinny_wave_sum(acc[m]);
+    const float t = wave_sum(acc[m]);
     mine = lane == m ? t : mine;
     if constexpr (GLU) {
-      const float tu = skinny_wave_sum(accu[m]);
+      const float tu = wave_sum(accu[m]);
       mineu = lane == m ? tu : mineu;
     }
   }

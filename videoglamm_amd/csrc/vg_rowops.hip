@@ -56,11 +56,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const TI* __restrict__ x, int
   constexpr int NV = RowVec<TI>::N;
   const int t = threadIdx.x % TPR;
   auto reduce = [&](float v) {
-    if constexpr (TPR == 16) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      return v;
-    }
+    if constexpr (TPR == 16) return group_sum<16>(v);
     v = wave_sum(v);
     if constexpr (TPR == 256) {
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -216,11 +212,7 @@ __global__ __launch_bounds__(256) void norm_short_kernel(const bf16_t* __restric
   __syncthreads();
   const int t = threadIdx.x % TPR, sub = threadIdx.x / TPR;
   const int64_t ngroups = (rows + RPB - 1) / RPB;
-  auto reduce = [&](float v) {
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-  };
+  auto reduce = [&](float v) { return group_sum<TPR>(v); };
   auto rowload = [&](int64_t grp, u32x4_t (&r)[NJ]) {
     const int64_t rw = min(grp * RPB + sub, rows - 1);       // clamped: the load is unconditional
 #pragma unroll
