@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void win256_attn_kernel(WinAttnArgs p) {
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(mx);
     const float mo = mx * sl2;
     float rs = 0.f;
     uint32_t pb[8][8];                            // P^T as packed bf16 pairs: the PV MFMA's B operands
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void win256_attn_kernel(WinAttnArgs p) {
         rs += p0 + p1;
         pb[kt][r >> 1] = f2bf2(p0, p1);
       }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(rs);
     // O^T[d, q] = V^T P^T: per 32-key tile two 16-key MFMA steps per d-tile (operand layout of pv_step_bf16t)
     f32x16_t o[NDT];
 #pragma unroll
@@ -875,8 +875,7 @@ __global__ __launch_bounds__(256) void tiny_win_attn_kernel(TinyAttnArgs p) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(xor16_max(mx));
     const float mo = mx * sl2;
     float rs = 0.f;
 #pragma unroll
@@ -887,8 +886,7 @@ __global__ __launch_bounds__(256) void tiny_win_attn_kernel(TinyAttnArgs p) {
       pb[kt][qt][0] = f2bf2(e[0], e[1]);
       pb[kt][qt][1] = f2bf2(e[2], e[3]);
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(xor16_sum(rs));
     inv[qt] = 1.0f / rs;
   }
   // O^T[d, q] = V^T P^T per 16-key tile; the contraction's slots 8g + 4 .. 8g + 7 are zeros on the P side

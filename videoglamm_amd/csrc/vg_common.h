@@ -72,6 +72,23 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+// single butterfly steps across the 16-lane rows / the wave halves (the __shfl_xor(v, 16 | 32) they replace pairs the same lanes: same bits)
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
 __device__ __forceinline__ float wave_max(float v) {
   const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));

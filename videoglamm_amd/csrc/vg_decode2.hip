@@ -88,8 +88,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn2_kernel(DecAttn2Args p) {
       if (j > pos || j < lo) sc[g][i] = -INFINITY;
       mx = fmaxf(mx, sc[g][i]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(xor16_max(mx));      // across the wave's four 16-lane rows on the VALU (__shfl_xor is an LDS-pipe round trip per step)
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -97,8 +96,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn2_kernel(DecAttn2Args p) {
       sc[g][i] = e;
       sum += e;
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = xor32_sum(xor16_sum(sum));
     mw[g] = mx;
     lw[g] = sum;
   }

@@ -119,14 +119,14 @@ __global__ __launch_bounds__(256) void twoway_image_update_kernel(TwoWayArgs p) 
           if (t0 + e >= p.nt) v[e] = -INFINITY;
           m = fmaxf(m, v[e]);
         }
-        if (TP == 16) m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (TP == 16) m = xor32_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           v[e] = __expf(v[e] - m);
           sum += v[e];
         }
-        if (TP == 16) sum += __shfl_xor(sum, 32, 64);
+        if (TP == 16) sum = xor32_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[2 * j + gp][e] = f2bf2(v[2 * e] * inv, v[2 * e + 1] * inv);
@@ -177,14 +177,12 @@ __global__ __launch_bounds__(256) void twoway_image_update_kernel(TwoWayArgs p) 
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[e];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = group_sum<32>(s);
       const float mean = s * (1.0f / 256.0f);
       float q2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[e] -= mean; q2 = fmaf(v[e], v[e], q2); }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+      q2 = group_sum<32>(q2);
       const float rstd = __builtin_amdgcn_rsqf(q2 * (1.0f / 256.0f) + p.eps);
       u32x4_t xo, xpo;
 #pragma unroll
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void mask_upscale_kernel(UpscaleArgs p) {
               sum += v[jf][g][jj];
             }
           }
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor32_sum(sum);
         const float mean = sum * (1.0f / 64.0f);
         float q2 = 0.f;
 #pragma unroll
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void mask_upscale_kernel(UpscaleArgs p) {
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { v[jf][g][jj] -= mean; q2 = fmaf(v[jf][g][jj], v[jf][g][jj], q2); }
-        q2 += __shfl_xor(q2, 32, 64);
+        q2 = xor32_sum(q2);
         const float rstd = __builtin_amdgcn_rsqf(q2 * (1.0f / 64.0f) + p.eps);
         // the 64 activations as product 2's B operand: 16-channel step q = 2 jf + gp holds channels 32 jf + 16 gp + 8 h + e in slot 8 h + e
         u32x4_t uf[4];
