@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
     for (int j = 0; j < KS; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) sum += __uint_as_float(a[j][e] << 16) + __uint_as_float(a[j][e] & 0xffff0000u);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = xor32_sum(sum);
     const float invK = 1.0f / (float)K, mean = sum * invK;
     // (the packed rows are re-unpacked in every pass: left to itself the compiler keeps all K / 2 unpacked values of the lane alive across the three passes —
     //  72 / 144 more registers, 150-330 of them spilled)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rr_kernel(GemmArgs p) {
         const float d0 = __uint_as_float(a[j][e] << 16) - mean, d1 = __uint_as_float(a[j][e] & 0xffff0000u) - mean;
         q += d0 * d0 + d1 * d1;
       }
-    q += __shfl_xor(q, 32, 64);
+    q = xor32_sum(q);
     const float rstd = rsqrtf(q * invK + p.ln_eps);
     opaque();
 #pragma unroll
