@@ -278,3 +278,18 @@ def test_video_branch_graph_replay(cuda, dtype):
             out = m.video_branch_graphed(images, text[:n], hw, feats)
             assert torch.equal(out, m.video_branch(images, text[:n], hw, frame_feats=feats))
     assert len(m._video_graphs) <= 4
+
+
+def test_mlp3_pack_layout_cpu():
+    """vg_mlp3_grouped's weight packing (ops.mlp3_pack; the layout stated in include/vg_kernels.h): element (g, t, s, lane, e) = W_g[32 t + lane % 32][16 s + 8 (lane / 32) + e],
+    rows past `out` zero — checked element-wise on the product's packer, and as a round trip through the CPU twin's unpacker."""
+    import _cpu_ops
+    from videoglamm_amd import ops
+    G, n_out, n_in = 2, 40, 48
+    w = torch.arange(G * n_out * n_in, dtype=torch.float32).view(G, n_out, n_in)
+    p = ops.mlp3_pack(w)
+    assert p.shape == (G, 2, n_in // 16, 64, 8)
+    for g, t, s, lane, e in ((0, 0, 0, 0, 0), (1, 1, 2, 37, 5), (0, 1, 1, 7, 7), (1, 0, 2, 63, 3)):
+        r, c = 32 * t + lane % 32, 16 * s + 8 * (lane // 32) + e
+        assert float(p[g, t, s, lane, e]) == (float(w[g, r, c]) if r < n_out else 0.0)
+    assert torch.equal(_cpu_ops._mlp3_unpack(p, n_out), w) and torch.equal(_cpu_ops.mlp3_pack(w), p)
