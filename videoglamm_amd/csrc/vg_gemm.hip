@@ -728,17 +728,6 @@ __global__ __launch_bounds__(256) void gemm_small64_kernel(GemmArgs p) {
                                        (__attribute__((address_space(3))) void*)(da + (nseg + sg) * SEG), 16, 0, 0);
     }
   }
-  // the epilogue's bias / LayerScale values go out with the operand DMAs (r06): loaded after the MFMAs they were one more dependent round trip of a
-  // kernel that is all latency at these sizes
-  const int cg = lane & 3, rsub = lane >> 2;          // 4 column groups x 16 rows per pass
-  const int n0w = bn * 64 + wn * 32, m0w = bm * 64 + wm * 32;
-  const int n0 = n0w + cg * 8;
-  float bv[8], gv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
-    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
-  }
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -768,6 +757,15 @@ __global__ __launch_bounds__(256) void gemm_small64_kernel(GemmArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) ws[mfma32_row(r, h) * ES + l31] = acc[r];
   vg_lds_barrier();
+  const int cg = lane & 3, rsub = lane >> 2;          // 4 column groups x 16 rows per pass
+  const int n0w = bn * 64 + wn * 32, m0w = bm * 64 + wm * 32;
+  const int n0 = n0w + cg * 8;
+  float bv[8], gv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = (p.bias && n0 + e < N) ? p.bias[n0 + e] : 0.f;
+    gv[e] = (p.gamma && n0 + e < N) ? p.gamma[n0 + e] : 1.f;
+  }
   if (n0w + 32 <= N && epi_dispatch(p.act, R != nullptr, p.gamma != nullptr, [&](auto act, auto res, auto gam) {
         epi_rows_fast<TO, decltype(act)::value, decltype(res)::value != 0, 2, ES, 16, decltype(gam)::value != 0>(p, ws, m0w, n0, cg, rsub, bv, gv, C, R);
       }))
